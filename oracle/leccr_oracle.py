@@ -1,0 +1,308 @@
+"""CPU oracle for the LECCR retrieval hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A plain PyTorch fp32 (CPU) restatement of what one step of the reference computes, written
+as functions over a flat {state_dict key: tensor} mapping.  It is the checker for the HIP path
+in leccr_amd/: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it.
+leccr_amd never imports this package and fails loudly when its HIP library is missing.
+
+Parity pinning: tests/test_oracle_golden.py checks every function here against fixtures captured
+from the reference's own classes (tests/golden/make_golden.py, run in the build container):
+ViT trunk, BERT, caption interaction, every loss (value + gradients), the full 5-loss forward with
+gradients at W=1 and under 2-rank DDP, and itm_eval's integer ranks.  The text tower's arithmetic
+is third-party (HF transformers BertModel, `transformers==4.12.5` per LECCR/requirements.txt:2;
+the fixtures were captured with transformers 5.15.0) -- the reference ships no tests or golden
+vectors of its own, so the captured fixtures are the only pin.
+
+Each function cites the reference lines it restates (paths relative to /root/reference/LECCR).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------- primitives
+def layer_norm(x, w, b, eps):
+    """nn.LayerNorm over the last axis, statistics in fp32 (clip/model.py:157-163)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def quick_gelu(x):
+    """clip/model.py:166-168."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def gelu_erf(x):
+    """Exact GELU (HF BERT hidden_act='gelu'; attention.py:16-17 F.gelu)."""
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def attention_core(q, k, v, heads, key_padding_mask=None):
+    """Scaled dot-product attention, batch-major.  q [b,Lq,d], k/v [b,Lk,d]; mask [b,Lk] True = ignore.
+
+    Semantics of torch nn.MultiheadAttention / HF BertSelfAttention: scores/sqrt(head_dim), masked keys get
+    -inf (BERT: finfo.min, same softmax result), softmax over keys, no dropout (eval / p=0).
+    """
+    b, Lq, d = q.shape
+    Lk = k.shape[1]
+    hd = d // heads
+    qh = q.reshape(b, Lq, heads, hd).permute(0, 2, 1, 3)
+    kh = k.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    vh = v.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask[:, None, None, :], float('-inf'))
+    p = torch.softmax(s, dim=-1)
+    o = p @ vh
+    return o.permute(0, 2, 1, 3).reshape(b, Lq, d)
+
+
+def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None):
+    """nn.MultiheadAttention with packed in_proj ordered q,k,v (clip/model.py:175,187; attention.py:27,47).
+    Batch-major in/out."""
+    w, bias = sd[pre + 'in_proj_weight'], sd[pre + 'in_proj_bias']
+    d = w.shape[1]
+    q = F.linear(query, w[:d], bias[:d])
+    k = F.linear(memory, w[d:2 * d], bias[d:2 * d])
+    v = F.linear(memory, w[2 * d:], bias[2 * d:])
+    o = attention_core(q, k, v, heads, key_padding_mask)
+    return F.linear(o, sd[pre + 'out_proj.weight'], sd[pre + 'out_proj.bias'])
+
+
+# --------------------------------------------------------------------------------------- CLIP ViT
+def vit_trunk(sd, pre, image):
+    """VisionTransformer.forward (clip/model.py:223-240): patch conv -> CLS + pos -> ln_pre -> blocks.
+    Returns [b, N, d] (batch-major; the reference's LND permutes are layout only)."""
+    w = sd[pre + 'conv1.weight']
+    d, _, p, _ = w.shape
+    b = image.shape[0]
+    g = image.shape[-1] // p
+    # stride == kernel: the conv is a GEMM over non-overlapping patches
+    patches = image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
+    x = patches @ w.reshape(d, -1).t()
+    cls = sd[pre + 'class_embedding'].reshape(1, 1, d).expand(b, 1, d)
+    x = torch.cat([cls, x], 1) + sd[pre + 'positional_embedding']
+    x = layer_norm(x, sd[pre + 'ln_pre.weight'], sd[pre + 'ln_pre.bias'], 1e-5)
+    heads = d // 64
+    i = 0
+    while f'{pre}transformer.resblocks.{i}.ln_1.weight' in sd:
+        bp = f'{pre}transformer.resblocks.{i}.'
+        # ResidualAttentionBlock (clip/model.py:171-192): pre-LN attention + pre-LN QuickGELU MLP
+        h = layer_norm(x, sd[bp + 'ln_1.weight'], sd[bp + 'ln_1.bias'], 1e-5)
+        x = x + torch_mha(sd, bp + 'attn.', h, h, heads)
+        h = layer_norm(x, sd[bp + 'ln_2.weight'], sd[bp + 'ln_2.bias'], 1e-5)
+        h = quick_gelu(F.linear(h, sd[bp + 'mlp.c_fc.weight'], sd[bp + 'mlp.c_fc.bias']))
+        x = x + F.linear(h, sd[bp + 'mlp.c_proj.weight'], sd[bp + 'mlp.c_proj.bias'])
+        i += 1
+    return x
+
+
+def encode_image(sd, pre, image):
+    """CLIP.encode_image(return_hidden=True) (clip/model.py:340-346): ln_post on ALL tokens, then @ proj."""
+    x = vit_trunk(sd, pre, image)
+    return layer_norm(x, sd[pre + 'ln_post.weight'], sd[pre + 'ln_post.bias'], 1e-5) @ sd[pre + 'proj']
+
+
+# --------------------------------------------------------------------------------------- BERT
+def bert_forward(sd, pre, ids, mask, heads):
+    """HF BertModel(ids, attention_mask).last_hidden_state as called at models/xvlm.py:238.
+
+    word + position(0..L-1) + token_type(0) -> LayerNorm(1e-12); 12x post-LN layers with erf-GELU; additive
+    key mask only (padded query rows are still computed).  The word table is nn.Embedding(padding_idx=
+    pad_token_id=0): row 0 is read like any row but receives NO gradient.
+    """
+    L = ids.shape[1]
+    x = F.embedding(ids, sd[pre + 'embeddings.word_embeddings.weight'], padding_idx=0) \
+        + sd[pre + 'embeddings.position_embeddings.weight'][:L] \
+        + sd[pre + 'embeddings.token_type_embeddings.weight'][0]
+    x = layer_norm(x, sd[pre + 'embeddings.LayerNorm.weight'], sd[pre + 'embeddings.LayerNorm.bias'], 1e-12)
+    kpm = ~mask.bool()
+    i = 0
+    while f'{pre}encoder.layer.{i}.attention.self.query.weight' in sd:
+        lp = f'{pre}encoder.layer.{i}.'
+        q = F.linear(x, sd[lp + 'attention.self.query.weight'], sd[lp + 'attention.self.query.bias'])
+        k = F.linear(x, sd[lp + 'attention.self.key.weight'], sd[lp + 'attention.self.key.bias'])
+        v = F.linear(x, sd[lp + 'attention.self.value.weight'], sd[lp + 'attention.self.value.bias'])
+        a = attention_core(q, k, v, heads, kpm)
+        a = F.linear(a, sd[lp + 'attention.output.dense.weight'], sd[lp + 'attention.output.dense.bias'])
+        x = layer_norm(x + a, sd[lp + 'attention.output.LayerNorm.weight'],
+                       sd[lp + 'attention.output.LayerNorm.bias'], 1e-12)
+        h = gelu_erf(F.linear(x, sd[lp + 'intermediate.dense.weight'], sd[lp + 'intermediate.dense.bias']))
+        h = F.linear(h, sd[lp + 'output.dense.weight'], sd[lp + 'output.dense.bias'])
+        x = layer_norm(x + h, sd[lp + 'output.LayerNorm.weight'], sd[lp + 'output.LayerNorm.bias'], 1e-12)
+        i += 1
+    return x
+
+
+# --------------------------------------------------------------------------------------- caption interaction
+def cross_attention(sd, pre, tgt, memory, key_padding_mask=None, heads=8):
+    """CrossAttention / CrossAttentionLayer (models/attention.py:24-83), batch-major.
+
+    Per layer: a = MHA(tgt, memory); out = norm2(tgt + linear2(gelu(linear1(a)))).  norm1 is unused and the
+    attention output is NOT residual-added before the FFN (attention.py:47-54).
+    """
+    i = 0
+    while f'{pre}layers.{i}.linear1.weight' in sd:
+        lp = f'{pre}layers.{i}.'
+        a = torch_mha(sd, lp + 'multihead_attn.', tgt, memory, heads, key_padding_mask)
+        h = gelu_erf(F.linear(a, sd[lp + 'linear1.weight'], sd[lp + 'linear1.bias']))
+        h = F.linear(h, sd[lp + 'linear2.weight'], sd[lp + 'linear2.bias'])
+        tgt = layer_norm(tgt + h, sd[lp + 'norm2.weight'], sd[lp + 'norm2.bias'], 1e-5)
+        i += 1
+    return tgt
+
+
+def interaction_with_caption(sd, image_embeds, caption_hidden, key_padding_mask):
+    """RetrievalModel.interaction_with_caption (models/model_retrieval_caption.py:76-84).
+    All tensors batch-major here: returns (after_image [b,N,vw], after_caption [b,n,vw], ori_caption [b,n,vw])."""
+    b = image_embeds.shape[0]
+    queries = sd['queries'].permute(1, 0, 2).expand(b, -1, -1)
+    cap = F.linear(caption_hidden, sd['caption_proj.weight'], sd['caption_proj.bias'])
+    ori_caption = cross_attention(sd, 'crossattn_query.', queries, cap, key_padding_mask)
+    after_image = cross_attention(sd, 'crossattn.', image_embeds, ori_caption)
+    after_caption = cross_attention(sd, 'crossattn2.', ori_caption, image_embeds)
+    return after_image, after_caption, ori_caption
+
+
+# --------------------------------------------------------------------------------------- all-gather
+class _SliceBackwardGather(torch.autograd.Function):
+    """AllGather (models/xvlm.py:50-70): forward all_gather + cat, backward keeps the LOCAL row slice only."""
+
+    @staticmethod
+    def forward(ctx, t):
+        import torch.distributed as dist
+        W, r = dist.get_world_size(), dist.get_rank()
+        out = [torch.empty_like(t) for _ in range(W)]
+        dist.all_gather(out, t.contiguous())
+        ctx.r, ctx.b = r, t.shape[0]
+        return torch.cat(out, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.b * ctx.r: ctx.b * (ctx.r + 1)]
+
+
+def gather_rows(t):
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return t
+    return _SliceBackwardGather.apply(t)
+
+
+# --------------------------------------------------------------------------------------- losses
+def soft_labels(idx_all):
+    """xvlm.py:283-287: labels = eq(idx, idx^T) / rowsum."""
+    pos = torch.eq(idx_all.view(-1, 1), idx_all.view(1, -1)).float()
+    return pos / pos.sum(1, keepdim=True)
+
+
+def contrastive_loss(feat_a, feat_b, temp, idx=None):
+    """XVLMBase.get_contrastive_loss (models/xvlm.py:260-292)."""
+    a, b = gather_rows(feat_a), gather_rows(feat_b)
+    logits = a @ b.t() / temp
+    if idx is None:
+        labels = torch.arange(a.shape[0])
+        return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
+    lab = soft_labels(gather_rows(idx.view(-1, 1)))
+    i2t = -(torch.log_softmax(logits, 1) * lab).sum(1).mean()
+    t2i = -(torch.log_softmax(logits.t(), 1) * lab).sum(1).mean()
+    return (i2t + t2i) / 2
+
+
+def caption_contrastive_loss(cq, text_feat, temp):
+    """get_caption_contrastive_loss (model_retrieval_caption.py:145-152).  cq [b,n,D] batch-major; LOCAL batch."""
+    sim = torch.einsum('ind,jd->nij', cq, text_feat)
+    logits = sim.max(0)[0] / temp
+    labels = torch.arange(text_feat.shape[0])
+    return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.t(), labels)) / 2
+
+
+def _norm_score(s):
+    """norm_score (model_retrieval_caption.py:87-90): GLOBAL min / max."""
+    s = s - s.min()
+    return s / s.max()
+
+
+def dstl_loss(feat_v, cq, feat_s, feat_t, alpha=0.8):
+    """dstl_loss (model_retrieval_caption.py:94-116).  cq [b,n,D] batch-major.  logits_tv has NO temperature."""
+    v, c, s, t = gather_rows(feat_v), gather_rows(cq), gather_rows(feat_s), gather_rows(feat_t)
+    logits_tv = t @ v.t()
+    logits_sv = _norm_score(s @ v.t())
+    # reference: sim[n*G + i, j] = <c[i,n], s[j]>, max over n -> [i (caption), j (source text)]
+    logits_sc = _norm_score(torch.einsum('ind,jd->nij', c, s).max(0)[0])
+    labels = torch.softmax(alpha * logits_sv + (1.0 - alpha) * logits_sc, 1).detach()
+    logp = torch.log_softmax(logits_tv, 1)
+    # F.kl_div(logp, labels, 'batchmean') = sum(labels * (log labels - logp)) / G
+    return (torch.xlogy(labels, labels) - labels * logp).sum() / logits_tv.shape[0]
+
+
+def caption_vision_loss(sd, ori_caption, ori_image, idx):
+    """caption_vision_loss (model_retrieval_caption.py:118-143), exactly as written: all-gather the token
+    tensors, project, F.normalize with its default dim=1 (the TOKEN axis), all token pairs, mean over both
+    token axes, soft-label CE in one direction.  ori_caption [b,n,vw], ori_image [b,N,vw] batch-major."""
+    img, cap = gather_rows(ori_image), gather_rows(ori_caption)
+    cap = F.normalize(F.linear(cap, sd['cproj.weight'], sd['cproj.bias']), dim=1)
+    img = F.normalize(F.linear(img, sd['vproj.weight'], sd['vproj.bias']), dim=1)
+    sim = torch.einsum('icd,jvd->ijcv', cap, img).mean(-1).mean(-1)
+    lab = soft_labels(gather_rows(idx.view(-1, 1)))
+    return -(torch.log_softmax(sim, 1) * lab).sum(1).mean()
+
+
+def caption_regularization(ori_caption):
+    """caption_regularization (model_retrieval_caption.py:65-73).  ori_caption [b,n,vw] batch-major."""
+    c = F.normalize(ori_caption, dim=-1)
+    sim = c @ c.transpose(1, 2)
+    return (sim - torch.eye(c.shape[1])).mean()
+
+
+def get_features(sd, image_embeds=None, text_embeds=None):
+    """XVLMBase.get_features (models/xvlm.py:241-256): CLS -> Linear -> L2 normalise."""
+    if image_embeds is not None:
+        return F.normalize(F.linear(image_embeds[:, 0, :], sd['vision_proj.weight'], sd['vision_proj.bias']), dim=-1)
+    return F.normalize(F.linear(text_embeds[:, 0, :], sd['text_proj.weight'], sd['text_proj.bias']), dim=-1)
+
+
+# --------------------------------------------------------------------------------------- full step
+def retrieval_forward(sd, cfg, image, ids_s, mask_s, ids_t, mask_t, ids_c, mask_c, idx, text_heads):
+    """RetrievalModel.forward (models/model_retrieval_caption.py:154-199) -> the 5 weighted losses."""
+    vis = encode_image(sd, 'clip_encoder.visual.', image)
+    with torch.no_grad():
+        cap_hidden = bert_forward(sd, 'text_encoder.', ids_c, mask_c, text_heads)
+    after_image, after_caption, ori_caption = interaction_with_caption(sd, vis, cap_hidden, ~mask_c.bool())
+    loss_cv = caption_vision_loss(sd, ori_caption, vis, idx) * cfg['weight_cv_loss']
+    loss_reg = caption_regularization(ori_caption)
+    feat_v = get_features(sd, image_embeds=after_image)
+    feat_s = get_features(sd, text_embeds=bert_forward(sd, 'text_encoder.', ids_s, mask_s, text_heads))
+    feat_t = get_features(sd, text_embeds=bert_forward(sd, 'text_encoder.', ids_t, mask_t, text_heads))
+    temp = sd['temp']
+    l_vs = contrastive_loss(feat_v, feat_s, temp, idx)
+    l_vt = contrastive_loss(feat_v, feat_t, temp, idx)
+    l_st = contrastive_loss(feat_s, feat_t, temp, idx)
+    cq = F.linear(after_caption, sd['caption_proj1.weight'], sd['caption_proj1.bias'])
+    l_c = caption_contrastive_loss(cq, feat_s, temp) + caption_contrastive_loss(cq, feat_t, temp)
+    wd = cfg['weight_dstl_loss']
+    l_vt = l_vt * (1 - wd) + dstl_loss(feat_v, cq, feat_s, feat_t) * wd
+    return l_vs + loss_cv, l_vt, l_st, l_c * cfg['weight_caption_loss'], loss_reg * cfg['weight_reg_loss']
+
+
+# --------------------------------------------------------------------------------------- evaluation
+def itm_eval(scores_i2t, scores_t2i, txt2img, img2txt):
+    """itm_eval (image_Retrieval_caption.py:261-317).  rank of a ground-truth item = number of strictly larger
+    scores in its row (== position in the descending argsort for tie-free scores)."""
+    scores_i2t, scores_t2i = np.asarray(scores_i2t), np.asarray(scores_t2i)
+    ranks = np.zeros(scores_i2t.shape[0])
+    for i, row in enumerate(scores_i2t):
+        ranks[i] = min(int((row > row[t]).sum()) for t in img2txt[i])
+    tr = [100.0 * float((ranks < k).sum()) / len(ranks) for k in (1, 5, 10)]
+    ranks = np.zeros(scores_t2i.shape[0])
+    for t, row in enumerate(scores_t2i):
+        ranks[t] = int((row > row[txt2img[t]]).sum())
+    ir = [100.0 * float((ranks < k).sum()) / len(ranks) for k in (1, 5, 10)]
+    tr_mean, ir_mean = sum(tr) / 3, sum(ir) / 3
+    return {'txt_r1': tr[0], 'txt_r5': tr[1], 'txt_r10': tr[2], 'txt_r_mean': tr_mean, 'txt_sum_r': sum(tr),
+            'img_r1': ir[0], 'img_r5': ir[1], 'img_r10': ir[2], 'img_r_mean': ir_mean,
+            'r_mean': (tr_mean + ir_mean) / 2, 'img_sumr': sum(ir),
+            'sumr_avg': np.round((sum(tr) + sum(ir)) / 6, 2), 'sumr_sum': sum(tr) + sum(ir)}

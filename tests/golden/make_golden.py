@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE implementation.
+
+Runs only in the build container (needs /root/reference, CPU only).  It imports the
+reference's own classes (LECCR/clip/model.py, LECCR/models/*.py) and HF BertModel (the
+third-party text tower the reference instantiates at LECCR/models/xvlm.py:91-103), feeds
+them seeded inputs and seeded random weights at tiny geometries, and stores inputs,
+weights, outputs and gradients as .npz.  Nothing of the reference's source text is
+stored - only tensors.
+
+    python tests/golden/make_golden.py            # writes tests/golden/*.npz, *.json
+
+The fixtures pin oracle/ (the CPU restatement) to the reference; see tests/test_oracle_golden.py.
+"""
+import importlib.util
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+REF = '/root/reference/LECCR'
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ----------------------------------------------------------------------------- reference import
+def import_reference():
+    """Make the reference's model classes importable (SURVEY.md section 8c recipe).
+
+    models/vit.py and models/swin_transformer.py need `timm` (absent); only two helper
+    symbols used by the never-called load_pretrained() come from them, so empty modules with
+    those names are pre-seeded.  clip/__init__ pulls torchvision (absent), so clip/model.py is
+    loaded by path (it needs only torch + numpy).
+    """
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    for name, attrs in [('models.vit', ['interpolate_pos_embed']),
+                        ('models.swin_transformer', ['interpolate_relative_pos_embed'])]:
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, None)
+            sys.modules[name] = m
+    spec = importlib.util.spec_from_file_location('ref_clip_model', os.path.join(REF, 'clip/model.py'))
+    clip_model = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(clip_model)
+    import models.xvlm as xvlm
+    return clip_model, xvlm
+
+
+# standalone encoder fixtures (2 heads of 64 for the ViT = the production head size)
+TINY_VIT = dict(embed_dim=64, image_resolution=64, vision_layers=2, vision_width=128, vision_patch_size=16,
+                context_length=8, vocab_size=32, transformer_width=64, transformer_heads=1, transformer_layers=1)
+TINY_BERT = dict(vocab_size=100, hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                 intermediate_size=128, max_position_embeddings=40, hidden_dropout_prob=0.1,
+                 attention_probs_dropout_prob=0.1)
+# towers inside the full-model fixtures (smaller: every weight and gradient is stored)
+MODEL_VIT = dict(TINY_VIT, embed_dim=32, vision_width=64)
+TINY_CFG = {'embed_dim': 16, 'temp': 0.07, 'use_one_cl_proj_only': False, 'caption_encoder_name': 'mbert',
+            'num_queries': 4, 'caption_ca_layer': 2, 'caption_interaction_layer': 2, 'weight_reg_loss': 0.01,
+            'weight_caption_loss': 0.01, 'weight_dstl_loss': 0.5, 'weight_cv_loss': 0.01}
+
+
+def randomize_(module, seed, std=0.05):
+    """Seeded, non-degenerate values for every parameter (LN gains near 1, the rest N(0,std))."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n == 'temp':
+                continue
+            r = torch.randn(p.shape, generator=g)
+            if p.dim() == 1 and ('ln' in n.lower() or 'norm' in n.lower()) and n.endswith('weight'):
+                p.copy_(1.0 + 0.1 * r)
+            elif n.endswith('logit_scale'):
+                continue
+            else:
+                p.copy_(std * r)
+
+
+def make_ids(g, b, L, vocab, min_len=3):
+    """[CLS]=1 first, [SEP]=2 at a per-row length, 0 padding after (SURVEY.md 8d layout, tiny vocab)."""
+    ids = torch.randint(5, vocab, (b, L), generator=g)
+    lens = torch.randint(min_len, L + 1, (b,), generator=g)
+    lens[0] = L
+    pos = torch.arange(L)[None, :]
+    ids[:, 0] = 1
+    for i in range(b):
+        ids[i, lens[i] - 1] = 2
+    mask = (pos < lens[:, None]).long()
+    ids = ids * mask
+    return ids, mask
+
+
+class Enc:
+    def __init__(self, ids, mask):
+        self.input_ids, self.attention_mask = ids, mask
+
+
+def sd_np(module, prefix='w/'):
+    # caption_encoder.* is an alias of text_encoder.* (model_retrieval_caption.py:35): stored once
+    return {prefix + k: v.detach().cpu().numpy() for k, v in module.state_dict().items()
+            if not k.startswith('caption_encoder.')}
+
+
+def grads_np(module, prefix='g/'):
+    return {prefix + n: p.grad.detach().cpu().numpy() for n, p in module.named_parameters() if p.grad is not None}
+
+
+# ----------------------------------------------------------------------------- fixtures
+def fixture_vit(clip_model):
+    torch.manual_seed(0)
+    clip = clip_model.CLIP(**TINY_VIT).float().eval()
+    randomize_(clip.visual, 11)
+    g = torch.Generator().manual_seed(12)
+    image = torch.randn(3, 3, 64, 64, generator=g).requires_grad_(True)
+    cls, hidden = clip.encode_image(image, return_hidden=True)
+    # intermediate: output of the transformer trunk before ln_post/proj
+    trunk = clip.visual(image)
+    probe = torch.randn(hidden.shape, generator=g)
+    (hidden * probe).sum().backward()
+    out = {'image': image.detach().numpy(), 'hidden': hidden.detach().numpy(), 'cls': cls.detach().numpy(),
+           'trunk': trunk.detach().numpy(), 'probe': probe.numpy(), 'g_image': image.grad.numpy()}
+    out.update(sd_np(clip.visual))
+    out.update({k: v for k, v in grads_np(clip.visual).items() if 'resblocks.1.' not in k})
+    np.savez_compressed(os.path.join(OUT, 'vit_tiny.npz'), **out)
+    print('vit_tiny', hidden.shape, float(hidden.abs().mean()))
+
+
+def build_bert(seed):
+    from transformers import BertConfig, BertModel
+    bert = BertModel(BertConfig(**TINY_BERT)).eval()
+    randomize_(bert, seed)
+    return bert
+
+
+def fixture_bert():
+    bert = build_bert(21)
+    g = torch.Generator().manual_seed(22)
+    ids, mask = make_ids(g, 3, 9, TINY_BERT['vocab_size'])
+    h = bert(ids, attention_mask=mask, return_dict=True).last_hidden_state
+    probe = torch.randn(h.shape, generator=g)
+    (h * probe).sum().backward()
+    out = {'ids': ids.numpy(), 'mask': mask.numpy(), 'last_hidden_state': h.detach().numpy(), 'probe': probe.numpy()}
+    out.update(sd_np(bert))
+    out.update(grads_np(bert))
+    np.savez_compressed(os.path.join(OUT, 'bert_tiny.npz'), **out)
+    print('bert_tiny', h.shape, float(h.abs().mean()))
+
+
+def build_model(clip_model, xvlm, seed=31):
+    """Reference RetrievalModel at tiny geometry with seeded weights."""
+    def _clip(config=None):
+        return clip_model.CLIP(**MODEL_VIT).float(), MODEL_VIT['embed_dim']
+
+    def _bert(config=None):
+        from transformers import BertConfig, BertModel
+        return BertModel(BertConfig(**TINY_BERT)), TINY_BERT['hidden_size']
+
+    xvlm.build_clip_encoder = _clip
+    xvlm.build_text_encoder = _bert
+    from models.model_retrieval_caption import RetrievalModel
+    torch.manual_seed(seed)
+    model = RetrievalModel(dict(TINY_CFG))
+    model.init_caption_encoder()
+    randomize_(model, seed)
+    return model.eval()
+
+
+def make_batch(seed, b):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(b, 3, 64, 64, generator=g)
+    ids_s, m_s = make_ids(g, b, 7, TINY_BERT['vocab_size'])
+    ids_t, m_t = make_ids(g, b, 9, TINY_BERT['vocab_size'])
+    ids_c, m_c = make_ids(g, b, 12, TINY_BERT['vocab_size'])
+    idx = torch.arange(b) + 100
+    idx[b - 1] = idx[1]  # one duplicate -> soft labels (xvlm.py:283-290)
+    return dict(image=image, ids_s=ids_s, mask_s=m_s, ids_t=ids_t, mask_t=m_t, ids_c=ids_c, mask_c=m_c, idx=idx)
+
+
+def run_forward(model, batch, sl=slice(None)):
+    return model(batch['image'][sl], [Enc(batch['ids_s'][sl], batch['mask_s'][sl]),
+                                      Enc(batch['ids_t'][sl], batch['mask_t'][sl])],
+                 captions=Enc(batch['ids_c'][sl], batch['mask_c'][sl]), idx=batch['idx'][sl])
+
+
+def fixture_model_w1(clip_model, xvlm):
+    model = build_model(clip_model, xvlm)
+    batch = make_batch(32, 8)
+    # intermediates through the public helper methods (model_retrieval_caption.py:154-170)
+    with torch.no_grad():
+        v, _ = model.get_vision_embeds(batch['image'])
+        c = model.get_caption_embeds(batch['ids_c'], batch['mask_c'])
+        a_img, a_cap, o_cap = model.interaction_with_caption(image_embeds=v, caption_embeds=c,
+                                                             key_padding_mask=~batch['mask_c'].bool())
+        feat_v = model.get_features(a_img.transpose(0, 1).contiguous(), None)
+        feat_s = model.get_features(None, model.get_text_embeds(batch['ids_s'], batch['mask_s']))
+        feat_t = model.get_features(None, model.get_text_embeds(batch['ids_t'], batch['mask_t']))
+    losses = run_forward(model, batch)
+    sum(losses).backward()
+    out = {k: v_.numpy() for k, v_ in batch.items()}
+    out.update({'vision_embeds': v.numpy(), 'caption_hidden': c.numpy(), 'after_image': a_img.numpy(),
+                'after_caption': a_cap.numpy(), 'ori_caption': o_cap.numpy(), 'feat_v': feat_v.numpy(),
+                'feat_s': feat_s.numpy(), 'feat_t': feat_t.numpy(),
+                'losses': np.array([float(l) for l in losses], dtype=np.float64)})
+    out.update(sd_np(model))
+    out.update(grads_np(model))
+    np.savez_compressed(os.path.join(OUT, 'model_tiny_w1.npz'), **out)
+    print('model_tiny_w1 losses', out['losses'])
+
+
+def _w2_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    clip_model, xvlm = import_reference()
+    model = build_model(clip_model, xvlm)
+    ddp = torch.nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+    batch = make_batch(32, 8)
+    b = 8 // world
+    sl = slice(rank * b, (rank + 1) * b)
+    losses = ddp(batch['image'][sl], [Enc(batch['ids_s'][sl], batch['mask_s'][sl]),
+                                      Enc(batch['ids_t'][sl], batch['mask_t'][sl])],
+                 captions=Enc(batch['ids_c'][sl], batch['mask_c'][sl]), idx=batch['idx'][sl])
+    sum(losses).backward()
+    out = {'losses': np.array([float(l) for l in losses], dtype=np.float64)}
+    out.update(grads_np(model))
+    ret[rank] = out
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def fixture_model_w2():
+    """Same global batch as model_tiny_w1 sharded over 2 ranks under gloo DDP (xvlm.py:50-70 semantics)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_w2_worker, args=(2, 29611, ret), nprocs=2, join=True)
+    out = {}
+    for r in (0, 1):
+        for k, v in ret[r].items():
+            if r == 0 or k == 'losses':      # DDP-averaged gradients are identical on both ranks
+                out[f'r{r}/{k}'] = v
+            else:
+                assert np.allclose(v, ret[0][k], atol=1e-7), k
+    np.savez_compressed(os.path.join(OUT, 'model_tiny_w2.npz'), **out)
+    print('model_tiny_w2 losses', out['r0/losses'], out['r1/losses'])
+
+
+def fixture_losses(clip_model, xvlm):
+    """Each loss function on its own, with gradients w.r.t. its inputs and temp."""
+    model = build_model(clip_model, xvlm)
+    D, vw, n, b, N = TINY_CFG['embed_dim'], MODEL_VIT['embed_dim'], TINY_CFG['num_queries'], 6, 5
+    g = torch.Generator().manual_seed(41)
+    nrm = lambda x: torch.nn.functional.normalize(x, dim=-1)
+    fv = nrm(torch.randn(b, D, generator=g)).requires_grad_(True)
+    fs = nrm(torch.randn(b, D, generator=g)).requires_grad_(True)
+    ft = nrm(torch.randn(b, D, generator=g)).requires_grad_(True)
+    cq = torch.randn(n, b, D, generator=g).requires_grad_(True)          # caption_proj1 output, LND
+    cap = torch.randn(n, b, vw, generator=g).requires_grad_(True)         # ori_caption_embeds, LND
+    img = torch.randn(b, N, vw, generator=g).requires_grad_(True)         # ori_image_embeds
+    idx = torch.tensor([7, 3, 9, 3, 5, 7])
+    out = dict(fv=fv, fs=fs, ft=ft, cq=cq, cap=cap, img=img)
+    out = {k: v.detach().numpy() for k, v in out.items()}
+    out['idx'] = idx.numpy()
+
+    def rec(name, loss, inputs):
+        for p in model.parameters():
+            p.grad = None
+        for t in inputs.values():
+            t.grad = None
+        loss.backward()
+        out[f'{name}/loss'] = np.float64(loss.item())
+        for k, t in inputs.items():  # inputs that only feed detached labels get no gradient -> zeros
+            out[f'{name}/g_{k}'] = (t.grad if t.grad is not None else torch.zeros_like(t)).numpy().copy()
+        for pn in ('temp', 'cproj.weight', 'cproj.bias', 'vproj.weight', 'vproj.bias'):
+            p = dict(model.named_parameters())[pn]
+            if p.grad is not None:
+                out[f'{name}/g_{pn}'] = p.grad.numpy().copy()
+
+    rec('itc_idx', model.get_contrastive_loss(fv, fs, idx=idx), dict(fv=fv, fs=fs))
+    rec('itc_noidx', model.get_contrastive_loss(fv, ft, idx=None), dict(fv=fv, ft=ft))
+    rec('cap_itc', model.get_caption_contrastive_loss(cq, fs), dict(cq=cq, fs=fs))
+    rec('dstl', model.dstl_loss(fv, cq, fs, ft, idx), dict(fv=fv, cq=cq, fs=fs, ft=ft))
+    rec('cv', model.caption_vision_loss(cap, img, idx), dict(cap=cap, img=img))
+    rec('reg', model.caption_regularization(cap), dict(cap=cap))
+    for pn in ('temp', 'cproj.weight', 'cproj.bias', 'vproj.weight', 'vproj.bias'):
+        out['w/' + pn] = dict(model.named_parameters())[pn].detach().numpy()
+    np.savez_compressed(os.path.join(OUT, 'losses.npz'), **out)
+    print('losses', {k: float(v) for k, v in out.items() if k.endswith('/loss')})
+
+
+def fixture_itm_eval():
+    """itm_eval (image_Retrieval_caption.py:261-317) on tie-free scores: integer ranks pinned bit-exact."""
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    # the task script imports ruamel/dataset at module import; load only the function's module-level deps
+    src_path = os.path.join(REF, 'image_Retrieval_caption.py')
+    import ast
+    tree = ast.parse(open(src_path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'itm_eval'][0]
+    fn.decorator_list = []
+    ns = {'np': np}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), src_path, 'exec'), ns)
+    itm_eval = ns['itm_eval']
+    rng = np.random.default_rng(51)
+    cases = {}
+    for name, (ni, nt, per) in {'sq': (50, 50, 1), 'five': (20, 100, 5)}.items():
+        s = rng.permutation(ni * nt).reshape(ni, nt).astype(np.float32) / (ni * nt)  # tie-free
+        # plant a correlated diagonal so R@K is non-trivial
+        img2txt = {i: list(range(i * per, (i + 1) * per)) for i in range(ni)}
+        txt2img = {t: t // per for t in range(nt)}
+        for i in range(ni):
+            for t in img2txt[i]:
+                if rng.random() < 0.6:
+                    s[i, t] += 0.7
+        res = itm_eval(s, s.T.copy(), txt2img, img2txt)
+        cases[name] = {'result': {k: float(v) for k, v in res.items()}, 'per': per}
+        np.save(os.path.join(OUT, f'itm_scores_{name}.npy'), s)
+    json.dump(cases, open(os.path.join(OUT, 'itm_eval.json'), 'w'), indent=1, sort_keys=True)
+    print('itm_eval', {k: v['result']['sumr_sum'] for k, v in cases.items()})
+
+
+def main():
+    torch.set_num_threads(4)
+    clip_model, xvlm = import_reference()
+    if not dist.is_initialized():
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29610')
+        dist.init_process_group('gloo', rank=0, world_size=1)
+    fixture_vit(clip_model)
+    fixture_bert()
+    fixture_model_w1(clip_model, xvlm)
+    fixture_losses(clip_model, xvlm)
+    fixture_itm_eval()
+    dist.destroy_process_group()
+    fixture_model_w2()
+
+
+if __name__ == '__main__':
+    main()
