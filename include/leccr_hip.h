@@ -1,0 +1,207 @@
+/* leccr_hip.h - C ABI of libleccr_hip.so, the MI355X (gfx950) kernels behind the LECCR retrieval hot path.
+ *
+ * The reference (LiJiaBei-7/leccr) is pure Python: it has no FFI/operator layer, every op on its hot path is an
+ * ATen op sequence.  Each entry point below replaces one such sequence; the comment in front of it cites the
+ * reference lines it replaces (paths relative to /root/reference/LECCR).  INTEGRATION.md shows the ctypes stub
+ * a maintainer of the reference would add to call them.
+ *
+ * Conventions
+ *  - plain pointers to DEVICE memory + sizes; no torch types; the caller owns every buffer (kernels allocate
+ *    nothing); `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous.
+ *  - return 0 on success, a negative LECCR_E* code on a rejected argument, or -1000-hipError_t on a launch error.
+ *  - dtype codes: LECCR_F32 = 0, LECCR_BF16 = 1.  "T" buffers below have the dtype passed as `dtype`.
+ *    Statistics, losses, biases, LayerNorm gains and every parameter gradient are always f32.
+ *  - all activation tensors are batch-major and row-major: [rows, features] with a leading dimension in
+ *    ELEMENTS.  (The reference's LND layout for nn.MultiheadAttention is a layout choice only.)
+ */
+#ifndef LECCR_HIP_H
+#define LECCR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LECCR_F32 0
+#define LECCR_BF16 1
+
+#define LECCR_OK 0
+#define LECCR_EINVAL (-1)      /* bad shape / null pointer / unsupported combination */
+#define LECCR_EALIGN (-2)      /* pointer or leading dimension not aligned as the kernel requires */
+
+/* ---- library ---------------------------------------------------------------------------------------------- */
+int leccr_version(void);                       /* ABI version, bumps on any signature change */
+const char* leccr_last_error(void);            /* text of the last error on this thread */
+int leccr_set_force_generic(int on);           /* 1: route every op through the simple f32-arithmetic kernels */
+
+/* ---- GEMM -------------------------------------------------------------------------------------------------
+ * C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )      (+ C if accumulate)
+ *   trans_a = 0: A is [M,K] row-major (lda >= K)      trans_a = 1: A is [K,M] row-major (lda >= M)
+ *   trans_b = 0: B is [N,K] row-major (nn.Linear weight layout)   trans_b = 1: B is [K,N] row-major
+ * Replaces F.linear / torch.mm / addmm on every projection of the path:
+ *   clip/model.py:175-191 (in_proj, out_proj, c_fc, c_proj), :211 (conv1 as a GEMM over patches), :342 (@ proj);
+ *   HF BertModel dense layers called at models/xvlm.py:238; models/attention.py:28-31,47-52;
+ *   models/xvlm.py:241-256 (vision_proj/text_proj); and their autograd backward (dX: trans_b=1, dW: trans_a=1,trans_b=1).
+ * Epilogue order: v = alpha*acc (+bias[n]) ; if aux_out: aux_out[m,n] = v ; v = act(v) or v * act'(aux[m,n]) ;
+ *                 v += residual[m,n] ; C = v (or C += v).
+ */
+#define LECCR_EPI_NONE 0
+#define LECCR_EPI_QUICKGELU 1     /* x * sigmoid(1.702 x)                    clip/model.py:166-168 */
+#define LECCR_EPI_GELU 2          /* 0.5 x (1 + erf(x / sqrt 2))             attention.py:16-17, HF BERT 'gelu' */
+#define LECCR_EPI_DQUICKGELU 3    /* v * d/du quickgelu(u), u = aux[m,n]     (backward through the activation) */
+#define LECCR_EPI_DGELU 4         /* v * d/du gelu(u)                                                          */
+
+typedef struct leccr_gemm_params {
+    const void* A;
+    const void* B;
+    void* C;
+    int64_t M, N, K;
+    int64_t lda, ldb, ldc;
+    int32_t ab_dtype;            /* dtype of A and B */
+    int32_t c_dtype;             /* dtype of C, aux, aux_out, residual */
+    int32_t trans_a, trans_b;
+    const float* bias;           /* [N] f32 or NULL */
+    int32_t epilogue;
+    int32_t accumulate;          /* 1: C += v (c_dtype must be f32); split-K uses f32 atomics */
+    const void* aux;             /* [M,N] pre-activation for the D* epilogues */
+    int64_t ldaux;
+    void* aux_out;               /* [M,N] optional pre-activation output (ld = ldc) */
+    const void* residual;        /* [M,N] optional */
+    int64_t ldr;
+    float alpha;
+    int32_t reserved;
+} leccr_gemm_params;
+
+int leccr_gemm(const leccr_gemm_params* p, void* stream);
+
+/* ---- LayerNorm --------------------------------------------------------------------------------------------
+ * y = (x - mean) * rstd * gamma + beta over the last axis, statistics in f32.
+ * Replaces clip/model.py:157-163 (eps 1e-5), HF BERT LayerNorm (eps 1e-12), attention.py:35,53 norm2.
+ * fwd: x [rows, d] (T, ldx) optionally plus `add` [rows,d] (T, same ld) summed first (post-LN residual:
+ *      y = LN(x + add)); writes y (T), mean/rstd [rows] f32, and, if sum_out != NULL, x+add (T).
+ * bwd: dx = LN'(dy) (+ dres if non-null), dgamma/dbeta ACCUMULATED (+=) into f32 [d] buffers.
+ *      x_in must be the tensor that was normalised (x+add).
+ */
+int leccr_layernorm_fwd(const void* x, const void* add, const float* gamma, const float* beta, void* y,
+                        void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, int dtype,
+                        void* stream);
+int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
+                        const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype,
+                        void* stream);
+
+/* ---- Attention --------------------------------------------------------------------------------------------
+ * softmax(Q K^T / sqrt(hd) + key mask) V per (batch, head); no materialised score matrix.
+ * Replaces nn.MultiheadAttention's core (clip/model.py:187; attention.py:43-46,103-106) and HF BertSelfAttention
+ * (xvlm.py:238).  Q [b, Lq, heads*hd] with row stride ldq (elements) and batch stride Lq*ldq; K,V likewise
+ * with Lk (so packed qkv projections are addressed in place).  kmask: [b, Lk] uint8, 1 = ignore key, or NULL.
+ * lse [b, heads, Lq] f32 = log-sum-exp of the scaled scores (saved for backward).
+ * A row whose keys are all masked returns zeros (the reference would return NaN; never happens on the path:
+ * [CLS] is always unmasked).
+ */
+int leccr_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+                   int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
+                   int64_t ldv, int64_t ldo, int dtype, void* stream);
+/* dq/dk/dv have the same strides as q/k/v.  delta [b, heads, Lq] f32 is workspace (rowsum(dO*O)). */
+int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, int64_t b, int64_t heads,
+                   int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                   int dtype, void* stream);
+
+/* ---- ViT input stage --------------------------------------------------------------------------------------
+ * patchify: image [b,3,R,R] f32 NCHW -> patches [b*g*g, Kp] (T), g = R/p, column order (c, py, px) = the
+ *   flattening of conv1.weight [d,3,p,p]; columns 3p^2..Kp-1 are zero padding.  (clip/model.py:211,224-226)
+ * vit_assemble: tok [b, N, d] = concat(class_embedding, patch_out[b, N-1, d]) + positional_embedding
+ *   (clip/model.py:227-228); its backward scatters dtok into dpatch_out (T) and ACCUMULATES dcls [d], dpos [N,d] f32.
+ */
+int leccr_patchify(const float* image, void* patches, int64_t b, int64_t R, int64_t p, int64_t Kp, int dtype,
+                   void* stream);
+int leccr_vit_assemble_fwd(const void* patch_out, const float* cls, const float* pos, void* tok, int64_t b,
+                           int64_t N, int64_t d, int dtype, void* stream);
+int leccr_vit_assemble_bwd(const void* dtok, void* dpatch_out, float* dcls, float* dpos, int64_t b, int64_t N,
+                           int64_t d, int dtype, void* stream);
+
+/* ---- BERT embedding stage ---------------------------------------------------------------------------------
+ * emb[b,L,:] = word[ids] + position[0..L-1] + token_type[0]    (HF BertEmbeddings, called at xvlm.py:238)
+ * bwd ACCUMULATES f32: dword[ids] += demb (rows with id == pad_id skipped: nn.Embedding padding_idx),
+ *     dpos[l] += sum_b, dtype0 += sum_{b,l}.
+ */
+int leccr_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, void* emb,
+                         int64_t b, int64_t L, int64_t d, int64_t vocab, int dtype, void* stream);
+int leccr_bert_embed_bwd(const int64_t* ids, const void* demb, float* dword, float* dpos, float* dtype0, int64_t b,
+                         int64_t L, int64_t d, int64_t vocab, int64_t pad_id, int dtype, void* stream);
+
+/* ---- small reductions -------------------------------------------------------------------------------------
+ * colsum: out[n] += sum_m x[m,n]  (bias gradients).   l2norm: y = x / max(||x||_2, 1e-12) per row
+ * (F.normalize(dim=-1), xvlm.py:245-256) and its backward.
+ */
+int leccr_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, void* stream);
+int leccr_l2norm_fwd(const void* x, void* y, float* inv_norm, int64_t rows, int64_t d, int dtype, void* stream);
+int leccr_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, int64_t rows, int64_t d,
+                     int dtype, void* stream);
+
+/* ---- similarity + contrastive losses (f32 in, f32 out) ----------------------------------------------------
+ * sim_infonce: get_contrastive_loss (models/xvlm.py:260-292).  a,b [G,D] L2-normalised, idx [G] int64 or NULL.
+ *   logits = a b^T / temp ; labels = eq(idx,idx^T)/rowsum (or identity) ; loss = (CE_rows + CE_cols)/2.
+ *   Never writes the G x G logits: row/column log-sum-exps in `ws` (>= 2*G floats).
+ *   loss: 1 float.  Backward gives da, db [G,D] (full gathered rows; the caller keeps its local slice,
+ *   xvlm.py:62-67) and dtemp (1 float), all scaled by `gscale`.
+ * capsim: get_caption_contrastive_loss (model_retrieval_caption.py:145-152).  c [b,n,D], t [b,D]:
+ *   logits[i,j] = max_n <c[i,n], t[j]> / temp, hard labels.  argmax [b,b] int32 and ws (>= b*b + 2*b floats:
+ *   logits + row/column log-sum-exps) are saved for backward.
+ * dstl: dstl_loss (model_retrieval_caption.py:94-116): KL(softmax(a*norm(s v^T) + (1-a)*norm(max_n c s^T)) ||
+ *   softmax(t v^T)) batchmean; gradients flow to t and v only (labels detached).  ws >= 3*G*G + G + 8 floats.
+ * cvpool: caption_vision_loss (model_retrieval_caption.py:118-143) in pooled form: the mean over both token axes
+ *   is linear, so sim[i,j] = <mean_c chat_i, mean_v vhat_j>; chat/vhat are normalised over the TOKEN axis
+ *   (F.normalize default dim=1).  cvpool_fwd: x [b, L, d] (projected tokens, T) -> pooled [b, d] f32 +
+ *   inv_norm [b, d] f32; cvpool_bwd: dpooled -> dx.   The G x G soft-label CE on the pooled vectors is
+ *   sim_infonce_rows (one direction, no temperature).
+ * capreg: caption_regularization (model_retrieval_caption.py:65-73): mean(c_hat c_hat^T - I), c [b,n,d].
+ */
+int leccr_sim_infonce_fwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
+                          int both_dirs, float* loss, float* ws, void* stream);
+int leccr_sim_infonce_bwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
+                          int both_dirs, const float* ws, float gscale, float* da, float* db, float* dtemp,
+                          void* stream);
+int leccr_capsim_fwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D, float* loss,
+                     int32_t* argmax, float* ws, void* stream);
+int leccr_capsim_bwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D,
+                     const int32_t* argmax, const float* ws, float gscale, float* dc, float* dt, float* dtemp,
+                     void* stream);
+int leccr_dstl_fwd(const float* v, const float* c, const float* s, const float* t, float alpha, int64_t G,
+                   int64_t n, int64_t D, float* loss, float* ws, void* stream);
+int leccr_dstl_bwd(const float* v, const float* t, int64_t G, int64_t D, const float* ws, float gscale, float* dv,
+                   float* dt, void* stream);
+int leccr_cvpool_fwd(const void* x, float* pooled, float* inv_norm, int64_t b, int64_t L, int64_t d, int dtype,
+                     void* stream);
+int leccr_cvpool_bwd(const void* x, const float* inv_norm, const float* dpooled, void* dx, int64_t b, int64_t L,
+                     int64_t d, int dtype, void* stream);
+int leccr_capreg_fwd(const void* c, float* loss, int64_t b, int64_t n, int64_t d, int dtype, void* stream);
+int leccr_capreg_bwd(const void* c, float gscale, void* dc, int64_t b, int64_t n, int64_t d, int dtype,
+                     void* stream);
+
+/* ---- evaluation -------------------------------------------------------------------------------------------
+ * rank_of_gt: for each row r of scores [R,C] f32 and each of its ground-truth columns gt[r*per .. r*per+per-1]
+ * (int32, -1 = unused), rank = number of columns with a strictly larger score; out[r] = min over its gts.
+ * Equals np.where(np.argsort(row)[::-1] == gt) for tie-free rows (image_Retrieval_caption.py:265-292).
+ */
+int leccr_rank_of_gt(const float* scores, const int32_t* gt, int32_t* out, int64_t R, int64_t C, int64_t ldc,
+                     int64_t per, void* stream);
+
+/* ---- optimizer / parameter arena --------------------------------------------------------------------------
+ * adamw: decoupled weight decay AdamW exactly as transformers.AdamW (optim.py:1,58-63): p -= lr*wd*p after the
+ *   Adam update is NOT what HF does - HF applies  p += -step_size * m/denom  then  p += -lr*wd*p ; bias
+ *   correction on.  One launch over a flat f32 arena; `wd_mask` [n_seg] gives per-segment weight decay via
+ *   seg_end offsets (sorted, cumulative, in elements).
+ * cast_bf16: dst_bf16[i] = src_f32[i];  transpose_bf16: dst[c,r] = bf16(src[r,c]) for an [R,C] f32 matrix.
+ */
+int leccr_adamw(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end,
+                const float* seg_wd, int64_t n_seg, float lr, float beta1, float beta2, float eps, int64_t step,
+                float gscale, void* stream);
+int leccr_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int leccr_transpose_cast(const float* src, void* dst, int64_t R, int64_t C, int dtype, void* stream);
+int leccr_axpy(const void* x, void* y, float a, int64_t n, int dtype, void* stream);   /* y += a*x */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LECCR_HIP_H */

@@ -1,0 +1,152 @@
+"""ParamArena - flat HBM storage for parameters, gradients, optimizer state and low-precision compute copies.
+
+MI355X-first replacement for the reference's per-tensor parameter handling (605 separately allocated tensors, one
+optimizer kernel chain per tensor, DDP buckets re-flattened every step - image_Retrieval_caption.py:381-419):
+
+  * every nn.Parameter's .data is a view into ONE f32 buffer; .grad is a view into ONE f32 gradient buffer, so
+    zero_grad is one memset, gradient all-reduce is a handful of large RCCL calls over contiguous memory, and AdamW is
+    one kernel launch over the arena (leccr_adamw);
+  * in bf16 mode `refresh()` makes the compute copies once per step: one cast kernel over the whole arena plus one
+    transpose-cast per 2-D weight (K-contiguous [in,out] copies so the dX GEMMs run in the NT form the MFMA kernel
+    wants);
+  * parameters a module declares as a group (`_arena_groups()`) are laid out adjacently so they can also be addressed
+    as one packed matrix (BERT's separate query/key/value weights -> one [3d,d] QKV operand) without changing the
+    state_dict keys.
+
+state_dict keys, named_parameters() and load_state_dict() are untouched (load_state_dict copies into the views).
+"""
+import torch
+
+from . import kernels as K
+
+_ALIGN = 64  # elements; keeps every tensor 256-byte aligned in the f32 arena and 128-byte aligned in the bf16 copy
+
+
+class ParamArena:
+    def __init__(self, model, compute_dtype=torch.float32, device=None):
+        self.compute_dtype = compute_dtype
+        params, seen = [], set()
+
+        def add(p):
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+
+        groups = []
+        for m in model.modules():
+            if hasattr(m, '_arena_groups'):
+                for gname, plist in m._arena_groups():
+                    start = len(params)
+                    fresh = all(id(p) not in seen for p in plist)
+                    if fresh:
+                        for p in plist:
+                            assert p.numel() % _ALIGN == 0, 'packed group members must be multiples of 64 elements'
+                            add(p)
+                        groups.append((m, gname, plist, start))
+        for p in model.parameters():
+            add(p)
+        self.params = params
+        self.names = {id(p): n for n, p in model.named_parameters()}
+        device = device or params[0].device
+        self.offsets, off = [], 0
+        group_member = {id(p) for _, _, pl, _ in groups for p in pl[1:]}
+        for p in params:
+            if id(p) not in group_member:      # group members after the first follow immediately (no padding)
+                off = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+            self.offsets.append(off)
+            off += p.numel()
+        self.numel = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.data = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
+        self.lp = torch.zeros(self.numel, device=device, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
+        self._transposed = []
+        self.touched = [False] * len(params)
+        for i, (p, o) in enumerate(zip(params, self.offsets)):
+            view = self.data[o:o + p.numel()].view(p.shape)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            p._arena, p._aidx = self, i
+            p._g = p.grad
+            p._lp = self.lp[o:o + p.numel()].view(p.shape) if self.lp is not None else p.data
+            p._lpt = None
+        for m, gname, plist, start in groups:
+            o, n = self.offsets[start], sum(p.numel() for p in plist)
+            rows = sum(p.shape[0] for p in plist)
+            shape = (rows,) + tuple(plist[0].shape[1:])
+            pk = _Packed()
+            pk.members = plist
+            pk._g = self.grad[o:o + n].view(shape)
+            pk._lp = (self.lp if self.lp is not None else self.data)[o:o + n].view(shape)
+            pk._lpt = None
+            pk.data = self.data[o:o + n].view(shape)
+            setattr(m, gname, pk)
+        self.state_m = self.state_v = None
+        self._seg_key = None
+        self.step_count = 0
+
+    # ------------------------------------------------------------------ compute copies
+    def need_transposed(self, holder):
+        """Register a 2-D weight (Parameter or packed group) whose [in,out] compute copy the dX GEMM needs (bf16 mode)."""
+        if self.compute_dtype != torch.bfloat16 or holder._lpt is not None:
+            return
+        src = holder.data
+        assert src.dim() == 2
+        holder._lpt = torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=torch.bfloat16)
+        self._transposed.append(holder)
+
+    @torch.no_grad()
+    def refresh(self):
+        """Rebuild the low-precision compute copies from the f32 master weights (call once per optimizer step)."""
+        if self.lp is None:
+            return
+        K.cast_bf16(self.data, self.lp)
+        for h in self._transposed:
+            K.transpose_cast(h.data, h._lpt)
+
+    # ------------------------------------------------------------------ gradients
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def mark(self, holder):
+        """A kernel wrote (accumulated) this parameter's gradient in place."""
+        for p in (holder.members if isinstance(holder, _Packed) else (holder,)):
+            self.touched[p._aidx] = True
+
+    def mark_autograd_grads(self):
+        """Parameters updated through plain autograd (tiny ones: temp, queries) count as touched when non-zero."""
+        for i, p in enumerate(self.params):
+            if not self.touched[i] and p.requires_grad and p.numel() <= 1 << 16 and bool(p.grad.abs().sum() != 0):
+                self.touched[i] = True
+
+    # ------------------------------------------------------------------ optimizer (transformers.AdamW semantics)
+    def _segments(self, decay_of):
+        key = tuple(self.touched)
+        if self._seg_key != key:
+            ends, wds = [], []
+            for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+                nxt = self.offsets[i + 1] if i + 1 < len(self.params) else self.numel
+                ends.append(nxt)
+                # a parameter that never received a gradient is skipped by the reference optimizer (grad is None):
+                # wd < 0 tells the kernel to leave it untouched
+                wds.append(decay_of(self.names[id(p)], p) if (self.touched[i] and p.requires_grad) else -1.0)
+            dev = self.data.device
+            self._seg_end = torch.tensor(ends, dtype=torch.int64, device=dev)
+            self._seg_wd = torch.tensor(wds, dtype=torch.float32, device=dev)
+            self._seg_key = key
+        return self._seg_end, self._seg_wd
+
+    @torch.no_grad()
+    def adamw_step(self, lr, betas, eps, decay_of, gscale=1.0):
+        if self.state_m is None:
+            self.state_m = torch.zeros_like(self.data)
+            self.state_v = torch.zeros_like(self.data)
+        self.step_count += 1
+        seg_end, seg_wd = self._segments(decay_of)
+        K.adamw(self.data, self.grad, self.state_m, self.state_v, seg_end, seg_wd, lr, betas[0], betas[1], eps,
+                self.step_count, gscale)
+
+
+class _Packed:
+    """Several adjacent parameters addressed as one matrix (same attributes the kernels' callers use)."""
+    members = ()

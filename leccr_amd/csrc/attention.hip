@@ -1,0 +1,46 @@
+// attention.hip - C entry points for attention; picks the MFMA flash kernels (bf16, head size 64) or the generic
+// kernels (f32 parity path, other head sizes).
+#include "attention.h"
+
+namespace leccr {
+bool g_force_generic_attn = false;
+
+static int check_dims(const char* what, const AttnDims& D, int dtype) {
+    LECCR_REQUIRE(dtype == LECCR_F32 || dtype == LECCR_BF16, LECCR_EINVAL, "%s: bad dtype", what);
+    LECCR_REQUIRE(D.b >= 0 && D.heads > 0 && D.Lq >= 0 && D.Lk > 0 && D.hd > 0, LECCR_EINVAL, "%s: bad sizes", what);
+    LECCR_REQUIRE(D.ldq >= D.heads * D.hd && D.ldk >= D.heads * D.hd && D.ldv >= D.heads * D.hd &&
+                      D.ldo >= D.heads * D.hd,
+                  LECCR_EINVAL, "%s: row stride smaller than heads*hd", what);
+    return LECCR_OK;
+}
+}  // namespace leccr
+
+using namespace leccr;
+
+extern "C" int leccr_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+                              int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
+                              int64_t ldv, int64_t ldo, int dtype, void* stream) {
+    LECCR_REQUIRE(q && k && v && o && lse, LECCR_EINVAL, "attn_fwd: null pointer");
+    const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo};
+    if (int rc = check_dims("attn_fwd", D, dtype)) return rc;
+    if (b == 0 || Lq == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) return attn_mfma_fwd(q, k, v, o, lse, kmask, D, st);
+    return dtype == LECCR_F32 ? attn_generic_fwd<float>(q, k, v, o, lse, kmask, D, st)
+                              : attn_generic_fwd<bf16_t>(q, k, v, o, lse, kmask, D, st);
+}
+
+extern "C" int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                              const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
+                              int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
+                              int64_t ldv, int64_t ldo, int dtype, void* stream) {
+    LECCR_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && delta, LECCR_EINVAL, "attn_bwd: null pointer");
+    const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo};
+    if (int rc = check_dims("attn_bwd", D, dtype)) return rc;
+    if (b == 0 || Lq == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    if (!g_force_generic_attn && attn_mfma_supported(D, dtype))
+        return attn_mfma_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
+    return dtype == LECCR_F32 ? attn_generic_bwd<float>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st)
+                              : attn_generic_bwd<bf16_t>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
+}

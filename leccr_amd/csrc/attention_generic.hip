@@ -1,0 +1,218 @@
+// attention_generic.hip - reference-grade attention for any head size / dtype (f32 arithmetic, one wave per row).
+// Used by the f32 parity path and for head sizes the MFMA flash kernels (attention_mfma.hip) do not cover.
+//   fwd : o_i = softmax_j(scale * q_i.k_j + mask_j) v_j ; lse_i = logsumexp_j
+//   bwd : delta_i = dO_i.O_i ; dS_ij = p_ij (dO_i.v_j - delta_i) ; dq_i = scale sum_j dS_ij k_j ;
+//         dk_j = scale sum_i dS_ij q_i ; dv_j = sum_i p_ij dO_i        (p recomputed from lse, never stored)
+#include "attention.h"
+
+namespace leccr {
+
+// dynamic LDS per wave: hd floats (the row's q or k) + L floats (p) [+ L floats (dS)]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               const T* __restrict__ v, T* __restrict__ o,
+                                                               float* __restrict__ lse,
+                                                               const uint8_t* __restrict__ kmask, AttnDims D,
+                                                               float scale) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;  // over b*heads*Lq
+    if (row >= D.b * D.heads * D.Lq) return;
+    const int64_t i = row % D.Lq, h = (row / D.Lq) % D.heads, bb = row / (D.Lq * D.heads);
+    float* qs = sm + (size_t)wave * (D.hd + D.Lk);
+    float* ps = qs + D.hd;
+    const T* qp = q + (bb * D.Lq + i) * D.ldq + h * D.hd;
+    for (int d = lane; d < D.hd; d += 64) qs[d] = to_f32(qp[d]);
+    __builtin_amdgcn_wave_barrier();
+    float mx = -INFINITY;
+    for (int64_t j = lane; j < D.Lk; j += 64) {
+        float s = -INFINITY;
+        if (!kmask || !kmask[bb * D.Lk + j]) {
+            const T* kp = k + (bb * D.Lk + j) * D.ldk + h * D.hd;
+            float acc = 0.f;
+            for (int d = 0; d < D.hd; ++d) acc = fmaf(qs[d], to_f32(kp[d]), acc);
+            s = acc * scale;
+        }
+        ps[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wave_max(mx);
+    float l = 0.f;
+    for (int64_t j = lane; j < D.Lk; j += 64) {
+        const float p = mx == -INFINITY ? 0.f : __expf(ps[j] - mx);
+        ps[j] = p;
+        l += p;
+    }
+    l = wave_sum(l);
+    __builtin_amdgcn_wave_barrier();
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    if (lane == 0) lse[row] = l > 0.f ? mx + __logf(l) : INFINITY;
+    T* op = o + (bb * D.Lq + i) * D.ldo + h * D.hd;
+    for (int d = lane; d < D.hd; d += 64) {
+        float acc = 0.f;
+        const T* vp = v + bb * D.Lk * D.ldv + h * D.hd + d;
+        for (int64_t j = 0; j < D.Lk; ++j) acc = fmaf(ps[j], to_f32(vp[j * D.ldv]), acc);
+        op[d] = from_f32<T>(acc * inv);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+                                                         float* __restrict__ delta, AttnDims D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= D.b * D.heads * D.Lq) return;
+    const int64_t i = row % D.Lq, h = (row / D.Lq) % D.heads, bb = row / (D.Lq * D.heads);
+    const int64_t off = (bb * D.Lq + i) * D.ldo + h * D.hd;
+    float s = 0.f;
+    for (int d = lane; d < D.hd; d += 64) s += to_f32(o[off + d]) * to_f32(dout[off + d]);
+    s = wave_sum(s);
+    if (lane == 0) delta[row] = s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_generic_dq_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                              const T* __restrict__ v, const T* __restrict__ dout,
+                                                              const float* __restrict__ lse,
+                                                              const float* __restrict__ delta,
+                                                              const uint8_t* __restrict__ kmask, T* __restrict__ dq,
+                                                              AttnDims D, float scale) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    if (row >= D.b * D.heads * D.Lq) return;
+    const int64_t i = row % D.Lq, h = (row / D.Lq) % D.heads, bb = row / (D.Lq * D.heads);
+    float* qs = sm + (size_t)wave * (2 * D.hd + D.Lk);
+    float* dos = qs + D.hd;
+    float* ds = dos + D.hd;
+    const T* qp = q + (bb * D.Lq + i) * D.ldq + h * D.hd;
+    const T* dop = dout + (bb * D.Lq + i) * D.ldo + h * D.hd;
+    for (int d = lane; d < D.hd; d += 64) {
+        qs[d] = to_f32(qp[d]);
+        dos[d] = to_f32(dop[d]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float L = lse[row], dl = delta[row];
+    for (int64_t j = lane; j < D.Lk; j += 64) {
+        float dsv = 0.f;
+        if (!kmask || !kmask[bb * D.Lk + j]) {
+            const T* kp = k + (bb * D.Lk + j) * D.ldk + h * D.hd;
+            const T* vp = v + (bb * D.Lk + j) * D.ldv + h * D.hd;
+            float s = 0.f, dp = 0.f;
+            for (int d = 0; d < D.hd; ++d) {
+                s = fmaf(qs[d], to_f32(kp[d]), s);
+                dp = fmaf(dos[d], to_f32(vp[d]), dp);
+            }
+            const float p = __expf(s * scale - L);
+            dsv = p * (dp - dl);
+        }
+        ds[j] = dsv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    T* dqp = dq + (bb * D.Lq + i) * D.ldq + h * D.hd;
+    for (int d = lane; d < D.hd; d += 64) {
+        float acc = 0.f;
+        const T* kp = k + bb * D.Lk * D.ldk + h * D.hd + d;
+        for (int64_t j = 0; j < D.Lk; ++j) acc = fmaf(ds[j], to_f32(kp[j * D.ldk]), acc);
+        dqp[d] = from_f32<T>(acc * scale);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_generic_dkv_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                               const T* __restrict__ v, const T* __restrict__ dout,
+                                                               const float* __restrict__ lse,
+                                                               const float* __restrict__ delta,
+                                                               const uint8_t* __restrict__ kmask, T* __restrict__ dk,
+                                                               T* __restrict__ dv, AttnDims D, float scale) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * 4 + wave;  // over b*heads*Lk
+    if (row >= D.b * D.heads * D.Lk) return;
+    const int64_t j = row % D.Lk, h = (row / D.Lk) % D.heads, bb = row / (D.Lk * D.heads);
+    float* ks = sm + (size_t)wave * (2 * D.hd + 2 * D.Lq);
+    float* vs = ks + D.hd;
+    float* ps = vs + D.hd;
+    float* ds = ps + D.Lq;
+    const T* kp = k + (bb * D.Lk + j) * D.ldk + h * D.hd;
+    const T* vp = v + (bb * D.Lk + j) * D.ldv + h * D.hd;
+    for (int d = lane; d < D.hd; d += 64) {
+        ks[d] = to_f32(kp[d]);
+        vs[d] = to_f32(vp[d]);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool masked = kmask && kmask[bb * D.Lk + j];
+    for (int64_t i = lane; i < D.Lq; i += 64) {
+        float p = 0.f, dsv = 0.f;
+        if (!masked) {
+            const T* qp = q + (bb * D.Lq + i) * D.ldq + h * D.hd;
+            const T* dop = dout + (bb * D.Lq + i) * D.ldo + h * D.hd;
+            float s = 0.f, dp = 0.f;
+            for (int d = 0; d < D.hd; ++d) {
+                s = fmaf(ks[d], to_f32(qp[d]), s);
+                dp = fmaf(vs[d], to_f32(dop[d]), dp);
+            }
+            const int64_t r = (bb * D.heads + h) * D.Lq + i;
+            p = __expf(s * scale - lse[r]);
+            dsv = p * (dp - delta[r]);
+        }
+        ps[i] = p;
+        ds[i] = dsv;
+    }
+    __builtin_amdgcn_wave_barrier();
+    T* dkp = dk + (bb * D.Lk + j) * D.ldk + h * D.hd;
+    T* dvp = dv + (bb * D.Lk + j) * D.ldv + h * D.hd;
+    for (int d = lane; d < D.hd; d += 64) {
+        float ak = 0.f, av = 0.f;
+        const T* qp = q + bb * D.Lq * D.ldq + h * D.hd + d;
+        const T* dop = dout + bb * D.Lq * D.ldo + h * D.hd + d;
+        for (int64_t i = 0; i < D.Lq; ++i) {
+            ak = fmaf(ds[i], to_f32(qp[i * D.ldq]), ak);
+            av = fmaf(ps[i], to_f32(dop[i * D.ldo]), av);
+        }
+        dkp[d] = from_f32<T>(ak * scale);
+        dvp[d] = from_f32<T>(av);
+    }
+}
+
+template <typename T>
+int attn_generic_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+                     const AttnDims& D, hipStream_t st) {
+    const size_t shm = 4 * (size_t)(D.hd + D.Lk) * sizeof(float);
+    if (shm > 64 * 1024) {
+        set_error("attn_fwd(generic): Lk=%lld too long for the generic kernel", (long long)D.Lk);
+        return LECCR_EINVAL;
+    }
+    const float scale = 1.f / sqrtf((float)D.hd);
+    hipLaunchKernelGGL((attn_generic_fwd_kernel<T>), dim3((unsigned)cdiv(D.b * D.heads * D.Lq, 4)), dim3(256), shm, st,
+                       (const T*)q, (const T*)k, (const T*)v, (T*)o, lse, kmask, D, scale);
+    return check_launch("attn_generic_fwd");
+}
+
+template <typename T>
+int attn_generic_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                     const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D,
+                     hipStream_t st) {
+    const size_t shm1 = 4 * (size_t)(2 * D.hd + D.Lk) * sizeof(float);
+    const size_t shm2 = 4 * (size_t)(2 * D.hd + 2 * D.Lq) * sizeof(float);
+    if (shm1 > 64 * 1024 || shm2 > 64 * 1024) {
+        set_error("attn_bwd(generic): sequence too long for the generic kernel");
+        return LECCR_EINVAL;
+    }
+    const float scale = 1.f / sqrtf((float)D.hd);
+    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)cdiv(D.b * D.heads * D.Lq, 4)), dim3(256), 0, st,
+                       (const T*)o, (const T*)dout, delta, D);
+    hipLaunchKernelGGL((attn_generic_dq_kernel<T>), dim3((unsigned)cdiv(D.b * D.heads * D.Lq, 4)), dim3(256), shm1, st,
+                       (const T*)q, (const T*)k, (const T*)v, (const T*)dout, lse, delta, kmask, (T*)dq, D, scale);
+    hipLaunchKernelGGL((attn_generic_dkv_kernel<T>), dim3((unsigned)cdiv(D.b * D.heads * D.Lk, 4)), dim3(256), shm2, st,
+                       (const T*)q, (const T*)k, (const T*)v, (const T*)dout, lse, delta, kmask, (T*)dk, (T*)dv, D,
+                       scale);
+    return check_launch("attn_generic_bwd");
+}
+
+template int attn_generic_fwd<float>(const void*, const void*, const void*, void*, float*, const uint8_t*, const AttnDims&, hipStream_t);
+template int attn_generic_fwd<bf16_t>(const void*, const void*, const void*, void*, float*, const uint8_t*, const AttnDims&, hipStream_t);
+template int attn_generic_bwd<float>(const void*, const void*, const void*, const void*, const void*, const float*, const uint8_t*, void*, void*, void*, float*, const AttnDims&, hipStream_t);
+template int attn_generic_bwd<bf16_t>(const void*, const void*, const void*, const void*, const void*, const float*, const uint8_t*, void*, void*, void*, float*, const AttnDims&, hipStream_t);
+
+}  // namespace leccr

@@ -1,0 +1,131 @@
+// common.h - shared device helpers for the gfx950 kernels (wave64, bf16 <-> f32, reductions, error plumbing).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/leccr_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+namespace leccr {
+
+constexpr int kWave = 64;
+
+// host-side error text (thread local)
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+template <typename T> struct DT;
+template <> struct DT<float> { static constexpr int code = LECCR_F32; };
+template <> struct DT<bf16_t> { static constexpr int code = LECCR_BF16; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return static_cast<float>(v); }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return static_cast<bf16_t>(v); }
+
+// 4-wide vector load/store of T as f32 (pointer must be aligned to 4*sizeof(T))
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, f32x4 v) {
+    bf16x4 o = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `sh` needs >= 16 floats; every thread gets the result
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += sh[i];
+    return r;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < nw; ++i) r = fmaxf(r, sh[i]);
+    return r;
+}
+__device__ __forceinline__ float block_min(float v, float* sh) {
+    v = wave_min(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    float r = sh[0];
+    for (int i = 1; i < nw; ++i) r = fminf(r, sh[i]);
+    return r;
+}
+
+// activations (clip/model.py:166-168 QuickGELU; exact erf GELU) and their derivatives
+__device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float dquick_gelu(float x) {
+    const float s = 1.f / (1.f + __expf(-1.702f * x));
+    return s * (1.f + 1.702f * x * (1.f - s));
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+    return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+template <int EPI> __device__ __forceinline__ float apply_epi(float v, float aux) {
+    if constexpr (EPI == LECCR_EPI_QUICKGELU) return quick_gelu(v);
+    else if constexpr (EPI == LECCR_EPI_GELU) return gelu_erf(v);
+    else if constexpr (EPI == LECCR_EPI_DQUICKGELU) return v * dquick_gelu(aux);
+    else if constexpr (EPI == LECCR_EPI_DGELU) return v * dgelu_erf(aux);
+    else return v;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace leccr
+
+#define LECCR_REQUIRE(cond, code, ...)          \
+    do {                                        \
+        if (!(cond)) {                          \
+            leccr::set_error(__VA_ARGS__);      \
+            return (code);                      \
+        }                                       \
+    } while (0)

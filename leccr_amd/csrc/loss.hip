@@ -1,0 +1,586 @@
+// loss.hip - all-pairs similarity + contrastive / distillation losses of the LECCR step, forward and backward.
+// f32 features in, f32 losses out.  None of the G x G logits matrices of the contrastive losses is written to
+// HBM: a wave owns one row of the similarity matrix, lanes own columns, row statistics are wave-shuffle reductions;
+// the column direction is the same kernel with the operands swapped.  (Reference sequences: include/leccr_hip.h.)
+#include "common.h"
+
+namespace leccr {
+
+// dot(a_row, b_row) over D floats; a in LDS (broadcast), b from global (each lane its own row, L2 resident)
+__device__ __forceinline__ float dot_lds_glb(const float* __restrict__ a_lds, const float* __restrict__ b, int D) {
+    float acc = 0.f;
+    int d = 0;
+    for (; d + 3 < D; d += 4) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(b + d);
+        acc = fmaf(a_lds[d], bv[0], acc);
+        acc = fmaf(a_lds[d + 1], bv[1], acc);
+        acc = fmaf(a_lds[d + 2], bv[2], acc);
+        acc = fmaf(a_lds[d + 3], bv[3], acc);
+    }
+    for (; d < D; ++d) acc = fmaf(a_lds[d], b[d], acc);
+    return acc;
+}
+
+// ----------------------------------------------------------------------------------------------- sim_infonce
+// dir 0: rows of a vs all b ; dir 1: rows of b vs all a.   For row i: lse_i, pos_i = sum_j lab_ij logit_ij.
+// loss += scale * (lse_i - pos_i).   ws: [lse dir0 (G) | lse dir1 (G)]
+__global__ __launch_bounds__(256) void sim_rowlse_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const int64_t* __restrict__ idx, float inv_temp, int G, int D,
+                                                         float* __restrict__ loss, float* __restrict__ ws,
+                                                         float scale) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dir = blockIdx.y;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= G) return;
+    const float* A = dir == 0 ? a : b;
+    const float* B = dir == 0 ? b : a;
+    float* ar = sm + wave * D;
+    for (int d = lane; d < D; d += 64) ar[d] = A[(int64_t)i * D + d];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t my = idx ? idx[i] : 0;
+    float m = -INFINITY, l = 0.f, pos = 0.f, cnt = 0.f;
+    for (int j0 = 0; j0 < G; j0 += 64) {
+        const int j = j0 + lane;
+        float s = -INFINITY;
+        if (j < G) {
+            s = dot_lds_glb(ar, B + (int64_t)j * D, D) * inv_temp;
+            const bool match = idx ? (idx[j] == my) : (j == i);
+            if (match) {
+                pos += s;
+                cnt += 1.f;
+            }
+        }
+        const float mn = fmaxf(m, wave_max(s));
+        l = l * __expf(m - mn) + wave_sum(j < G ? __expf(s - mn) : 0.f);
+        m = mn;
+    }
+    pos = wave_sum(pos);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+        const float lse = m + __logf(l);
+        ws[dir * G + i] = lse;
+        atomicAdd(loss, scale * (lse - pos / cnt));
+    }
+}
+
+// Backward of both directions for the rows of one operand.
+//  side 0: da_i = sum_j g_ij b_j / temp   side 1: db_j = sum_i g_ij a_i / temp
+//  g_ij = gs * [ w_r (softmax_row(i,j) - lab_ij) + w_c (softmax_col(i,j) - lab_ij) ],   w_r = w_c = 1/(2G) (both
+//  dirs) or w_r = 1/G, w_c = 0 (single direction).  dtemp += -sum_ij g_ij logit_ij / temp   (side 0 only).
+__global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const int64_t* __restrict__ idx, float inv_temp, int G, int D,
+                                                      const float* __restrict__ ws, float w_r, float w_c,
+                                                      float* __restrict__ da, float* __restrict__ db,
+                                                      float* __restrict__ dtemp) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int side = blockIdx.y;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= G) return;
+    const float* A = side == 0 ? a : b;
+    const float* B = side == 0 ? b : a;
+    float* out = side == 0 ? da : db;
+    // row statistics for "my" row i and for the other operand's rows
+    const float* lse_mine = ws + side * G;        // side 0: row lse ; side 1: column lse
+    const float* lse_other = ws + (1 - side) * G;
+    const float w_mine = side == 0 ? w_r : w_c, w_oth = side == 0 ? w_c : w_r;
+    float* ar = sm + wave * (D + 64);
+    float* gbuf = ar + D;
+    for (int d = lane; d < D; d += 64) ar[d] = A[(int64_t)i * D + d];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t my = idx ? idx[i] : 0;
+    // label normaliser: cnt_i (the label matrix is symmetric: lab_ij = eq/cnt_i, lab_ji = eq/cnt_j, cnt_i == cnt_j on a match)
+    float cnt = 0.f;
+    for (int j = lane; j < G; j += 64) cnt += (idx ? (idx[j] == my) : (j == i)) ? 1.f : 0.f;
+    cnt = wave_sum(cnt);
+    const float li = w_mine != 0.f ? lse_mine[i] : 0.f;
+    float acc[8];  // D <= 512: lane owns columns lane, lane+64, ...
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    float dt = 0.f;
+    for (int j0 = 0; j0 < G; j0 += 64) {
+        const int j = j0 + lane;
+        float g = 0.f;
+        if (j < G) {
+            const float s = dot_lds_glb(ar, B + (int64_t)j * D, D) * inv_temp;
+            const float lab = (idx ? (idx[j] == my) : (j == i)) ? 1.f / cnt : 0.f;
+            if (w_mine != 0.f) g += w_mine * (__expf(s - li) - lab);
+            if (w_oth != 0.f) g += w_oth * (__expf(s - lse_other[j]) - lab);  // unused direction: statistics never written
+            dt -= g * s;
+        }
+        gbuf[lane] = g;
+        __builtin_amdgcn_wave_barrier();
+        const int jn = G - j0 < 64 ? G - j0 : 64;
+        for (int jj = 0; jj < jn; ++jj) {
+            const float gj = gbuf[jj];
+            const float* br = B + (int64_t)(j0 + jj) * D;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int d = lane + 64 * q;
+                if (d < D) acc[q] = fmaf(gj, br[d], acc[q]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int d = lane + 64 * q;
+        if (d < D) out[(int64_t)i * D + d] = acc[q] * inv_temp;
+    }
+    if (side == 0 && dtemp) {
+        dt = wave_sum(dt);
+        if (lane == 0) atomicAdd(dtemp, dt * inv_temp);
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- capsim
+// logits[i,j] = max_n <c[i,n,:], t[j,:]> / temp  (b x b, local batch).  ws: [logits b*b | lse_row b | lse_col b]
+__global__ __launch_bounds__(256) void capsim_logits_kernel(const float* __restrict__ c, const float* __restrict__ t,
+                                                            float inv_temp, int b, int n, int D,
+                                                            float* __restrict__ logits, int32_t* __restrict__ argmax) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= b) return;
+    float* cr = sm + wave * n * D;
+    for (int d = lane; d < n * D; d += 64) cr[d] = c[(int64_t)i * n * D + d];
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < b; j += 64) {
+        float best = -INFINITY;
+        int am = 0;
+        for (int q = 0; q < n; ++q) {
+            const float s = dot_lds_glb(cr + q * D, t + (int64_t)j * D, D);
+            if (s > best) {  // first maximum wins, as torch.max
+                best = s;
+                am = q;
+            }
+        }
+        logits[(int64_t)i * b + j] = best * inv_temp;
+        argmax[(int64_t)i * b + j] = am;
+    }
+}
+
+// row / column log-sum-exp of a stored [R,C] matrix + hard-label CE:  loss += scale * (lse_r - x[r, r])
+__global__ __launch_bounds__(256) void lse_ce_kernel(const float* __restrict__ x, int R, int C, int64_t rs, int64_t cs,
+                                                     float* __restrict__ lse_out, float* __restrict__ loss, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    float m = -INFINITY;
+    for (int j = lane; j < C; j += 64) m = fmaxf(m, x[r * rs + j * cs]);
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < C; j += 64) l += __expf(x[r * rs + j * cs] - m);
+    l = wave_sum(l);
+    if (lane == 0) {
+        const float lse = m + __logf(l);
+        lse_out[r] = lse;
+        if (loss) atomicAdd(loss, scale * (lse - x[r * rs + r * cs]));
+    }
+}
+
+// g_ij = gs/(2b) [ (softmax_row - delta_ij) + (softmax_col - delta_ij) ]
+__device__ __forceinline__ float capsim_g(const float* logits, const float* lse_r, const float* lse_c, int b, int i,
+                                          int j, float w) {
+    const float s = logits[(int64_t)i * b + j];
+    const float dl = i == j ? 1.f : 0.f;
+    return w * ((__expf(s - lse_r[i]) - dl) + (__expf(s - lse_c[j]) - dl));
+}
+
+// side 0: wave per i -> dc[i, n, :] ; side 1: wave per j -> dt[j, :].   D <= 512, n <= 8
+__global__ __launch_bounds__(256) void capsim_bwd_kernel(const float* __restrict__ c, const float* __restrict__ t,
+                                                         float inv_temp, int b, int n, int D,
+                                                         const int32_t* __restrict__ argmax,
+                                                         const float* __restrict__ ws, float w, float* __restrict__ dc,
+                                                         float* __restrict__ dt, float* __restrict__ dtemp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int side = blockIdx.y;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= b) return;
+    const float* logits = ws;
+    const float* lse_r = ws + (int64_t)b * b;
+    const float* lse_c = lse_r + b;
+    if (side == 0) {
+        for (int q = 0; q < n; ++q) {  // one pass per query keeps the accumulators in registers
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < b; ++j) {
+                if (argmax[(int64_t)r * b + j] != q) continue;  // wave-uniform
+                const float g = capsim_g(logits, lse_r, lse_c, b, r, j, w);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int d = lane + 64 * u;
+                    if (d < D) acc[u] = fmaf(g, t[(int64_t)j * D + d], acc[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = lane + 64 * u;
+                if (d < D) dc[((int64_t)r * n + q) * D + d] = acc[u] * inv_temp;
+            }
+        }
+        float dtl = 0.f;
+        for (int j = lane; j < b; j += 64) dtl -= capsim_g(logits, lse_r, lse_c, b, r, j, w) * logits[(int64_t)r * b + j];
+        dtl = wave_sum(dtl);
+        if (lane == 0 && dtemp) atomicAdd(dtemp, dtl * inv_temp);
+    } else {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < b; ++i) {
+            const float g = capsim_g(logits, lse_r, lse_c, b, i, r, w);
+            const float* cr = c + ((int64_t)i * n + argmax[(int64_t)i * b + r]) * D;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = lane + 64 * u;
+                if (d < D) acc[u] = fmaf(g, cr[d], acc[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int d = lane + 64 * u;
+            if (d < D) dt[(int64_t)r * D + d] = acc[u] * inv_temp;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- dstl
+// ws layout (floats): [tv G*G | lab G*G (sv, then labels) | sc G*G | minmax 4 (as ordered ints) | lse_tv G]
+__device__ __forceinline__ int f2ord(float f) {
+    int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+__global__ void dstl_init_kernel(int* mm) {
+    mm[0] = f2ord(INFINITY);   // min sv
+    mm[1] = f2ord(-INFINITY);  // max sv
+    mm[2] = f2ord(INFINITY);   // min sc
+    mm[3] = f2ord(-INFINITY);  // max sc
+}
+
+__global__ __launch_bounds__(256) void dstl_scores_kernel(const float* __restrict__ v, const float* __restrict__ c,
+                                                          const float* __restrict__ s, const float* __restrict__ t,
+                                                          int G, int n, int D, float* __restrict__ tv,
+                                                          float* __restrict__ sv, float* __restrict__ sc,
+                                                          int* __restrict__ mm) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= G) return;
+    float* tr = sm + wave * (2 + n) * D;  // t_i | s_i | c_i[0..n)
+    float* sr = tr + D;
+    float* cr = sr + D;
+    for (int d = lane; d < D; d += 64) {
+        tr[d] = t[(int64_t)i * D + d];
+        sr[d] = s[(int64_t)i * D + d];
+    }
+    for (int d = lane; d < n * D; d += 64) cr[d] = c[(int64_t)i * n * D + d];
+    __builtin_amdgcn_wave_barrier();
+    float mn_sv = INFINITY, mx_sv = -INFINITY, mn_sc = INFINITY, mx_sc = -INFINITY;
+    for (int j = lane; j < G; j += 64) {
+        const float a = dot_lds_glb(tr, v + (int64_t)j * D, D);   // logits_tv[i,j] = <t_i, v_j>
+        const float bsv = dot_lds_glb(sr, v + (int64_t)j * D, D); // logits_sv[i,j] = <s_i, v_j>
+        float best = -INFINITY;                                    // logits_sc[i,j] = max_n <c_i,n , s_j>
+        for (int q = 0; q < n; ++q) best = fmaxf(best, dot_lds_glb(cr + q * D, s + (int64_t)j * D, D));
+        tv[(int64_t)i * G + j] = a;
+        sv[(int64_t)i * G + j] = bsv;
+        sc[(int64_t)i * G + j] = best;
+        mn_sv = fminf(mn_sv, bsv);
+        mx_sv = fmaxf(mx_sv, bsv);
+        mn_sc = fminf(mn_sc, best);
+        mx_sc = fmaxf(mx_sc, best);
+    }
+    mn_sv = wave_min(mn_sv);
+    mx_sv = wave_max(mx_sv);
+    mn_sc = wave_min(mn_sc);
+    mx_sc = wave_max(mx_sc);
+    if (lane == 0) {
+        atomicMin(mm + 0, f2ord(mn_sv));
+        atomicMax(mm + 1, f2ord(mx_sv));
+        atomicMin(mm + 2, f2ord(mn_sc));
+        atomicMax(mm + 3, f2ord(mx_sc));
+    }
+}
+
+// per row: labels = softmax(alpha*norm(sv) + (1-alpha)*norm(sc)) (stored over sv), lse of tv, KL contribution
+__global__ __launch_bounds__(256) void dstl_kl_kernel(const float* __restrict__ tv, float* __restrict__ lab,
+                                                      const float* __restrict__ sc, const int* __restrict__ mm,
+                                                      float alpha, int G, float* __restrict__ lse_tv,
+                                                      float* __restrict__ loss) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= G) return;
+    const float mn_sv = ord2f(mm[0]), mx_sv = ord2f(mm[1]), mn_sc = ord2f(mm[2]), mx_sc = ord2f(mm[3]);
+    // norm_score: (x - min) / max(x - min)
+    const float k_sv = alpha / (mx_sv - mn_sv), k_sc = (1.f - alpha) / (mx_sc - mn_sc);
+    float m1 = -INFINITY, m2 = -INFINITY;
+    for (int j = lane; j < G; j += 64) {
+        const int64_t o = (int64_t)i * G + j;
+        const float x = (lab[o] - mn_sv) * k_sv + (sc[o] - mn_sc) * k_sc;
+        lab[o] = x;
+        m1 = fmaxf(m1, x);
+        m2 = fmaxf(m2, tv[o]);
+    }
+    m1 = wave_max(m1);
+    m2 = wave_max(m2);
+    float l1 = 0.f, l2 = 0.f;
+    for (int j = lane; j < G; j += 64) {
+        const int64_t o = (int64_t)i * G + j;
+        l1 += __expf(lab[o] - m1);
+        l2 += __expf(tv[o] - m2);
+    }
+    l1 = wave_sum(l1);
+    l2 = wave_sum(l2);
+    const float lse1 = m1 + __logf(l1), lse2 = m2 + __logf(l2);
+    float kl = 0.f;
+    for (int j = lane; j < G; j += 64) {
+        const int64_t o = (int64_t)i * G + j;
+        const float loglab = lab[o] - lse1, p = __expf(loglab);
+        lab[o] = p;
+        kl += p > 0.f ? p * (loglab - (tv[o] - lse2)) : 0.f;
+    }
+    kl = wave_sum(kl);
+    if (lane == 0) {
+        lse_tv[i] = lse2;
+        atomicAdd(loss, kl / G);
+    }
+}
+
+// g_ij = gs/G (softmax(tv)_ij - lab_ij);  side 0: dt_i = sum_j g_ij v_j ; side 1: dv_j = sum_i g_ij t_i
+__global__ __launch_bounds__(256) void dstl_bwd_kernel(const float* __restrict__ v, const float* __restrict__ t, int G,
+                                                       int D, const float* __restrict__ tv,
+                                                       const float* __restrict__ lab, const float* __restrict__ lse_tv,
+                                                       float w, float* __restrict__ dv, float* __restrict__ dt) {
+    const int lane = threadIdx.x & 63;
+    const int side = blockIdx.y;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= G) return;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < G; ++o) {
+        const int i = side == 0 ? r : o, j = side == 0 ? o : r;
+        const int64_t off = (int64_t)i * G + j;
+        const float g = w * (__expf(tv[off] - lse_tv[i]) - lab[off]);
+        const float* src = side == 0 ? v + (int64_t)j * D : t + (int64_t)i * D;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int d = lane + 64 * u;
+            if (d < D) acc[u] = fmaf(g, src[d], acc[u]);
+        }
+    }
+    float* out = side == 0 ? dt : dv;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int d = lane + 64 * u;
+        if (d < D) out[(int64_t)r * D + d] = acc[u];
+    }
+}
+
+// ----------------------------------------------------------------------------------------------- cvpool / capreg
+// x [b, L, d]: per (b, column): S = sum_l x, nrm = max(sqrt(sum_l x^2), 1e-12); pooled = S / (L nrm)
+template <typename T>
+__global__ __launch_bounds__(256) void cvpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ pooled,
+                                                         float* __restrict__ inv_norm, int L, int d) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t bi = blockIdx.y;
+    if (col >= d) return;
+    const T* p = x + bi * L * (int64_t)d + col;
+    float S = 0.f, Q = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float v = to_f32(p[(int64_t)l * d]);
+        S += v;
+        Q = fmaf(v, v, Q);
+    }
+    const float inv = 1.f / fmaxf(sqrtf(Q), 1e-12f);
+    inv_norm[bi * d + col] = inv;
+    pooled[bi * d + col] = S * inv / L;
+}
+
+// dx_l = dpooled/L * (inv - S x_l inv^3)      (the clamp branch has zero measure on the path)
+template <typename T>
+__global__ __launch_bounds__(256) void cvpool_bwd_kernel(const T* __restrict__ x, const float* __restrict__ inv_norm,
+                                                         const float* __restrict__ dpooled, T* __restrict__ dx, int L,
+                                                         int d) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t bi = blockIdx.y;
+    if (col >= d) return;
+    const T* p = x + bi * L * (int64_t)d + col;
+    T* o = dx + bi * L * (int64_t)d + col;
+    float S = 0.f;
+    for (int l = 0; l < L; ++l) S += to_f32(p[(int64_t)l * d]);
+    const float inv = inv_norm[bi * d + col], g = dpooled[bi * d + col] / L;
+    const float k = S * inv * inv * inv;
+    for (int l = 0; l < L; ++l) o[(int64_t)l * d] = from_f32<T>(g * (inv - k * to_f32(p[(int64_t)l * d])));
+}
+
+// caption_regularization: loss = (sum_b |sum_p c_hat[b,p]|^2 - b n) / (b n^2).  One wave per sample, d <= 4096, n <= 8.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void capreg_kernel(const T* __restrict__ c, float* __restrict__ loss,
+                                                     T* __restrict__ dc, float gscale, int b, int n, int d) {
+    const int lane = threadIdx.x & 63;
+    const int bi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bi >= b) return;
+    const float w = 1.f / ((float)b * n * n);
+    float inv[8];
+    for (int p = 0; p < n; ++p) {
+        float q = 0.f;
+        for (int e = lane; e < d; e += 64) {
+            const float v = to_f32(c[((int64_t)bi * n + p) * d + e]);
+            q = fmaf(v, v, q);
+        }
+        inv[p] = 1.f / fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    }
+    if constexpr (!BWD) {
+        float uu = 0.f;
+        for (int e = lane; e < d; e += 64) {
+            float u = 0.f;
+            for (int p = 0; p < n; ++p) u += to_f32(c[((int64_t)bi * n + p) * d + e]) * inv[p];
+            uu = fmaf(u, u, uu);
+        }
+        uu = wave_sum(uu);
+        if (lane == 0) atomicAdd(loss, (uu - n) * w);
+    } else {
+        // g_p = 2 w u ;  dc_p = inv_p (g - chat_p <g, chat_p>)
+        float gdot[8];
+        for (int p = 0; p < n; ++p) gdot[p] = 0.f;
+        for (int e = lane; e < d; e += 64) {
+            float u = 0.f;
+            for (int p = 0; p < n; ++p) u += to_f32(c[((int64_t)bi * n + p) * d + e]) * inv[p];
+            for (int p = 0; p < n; ++p) gdot[p] += u * to_f32(c[((int64_t)bi * n + p) * d + e]) * inv[p];
+        }
+        for (int p = 0; p < n; ++p) gdot[p] = wave_sum(gdot[p]);
+        const float k = 2.f * w * gscale;
+        for (int e = lane; e < d; e += 64) {
+            float u = 0.f;
+            for (int p = 0; p < n; ++p) u += to_f32(c[((int64_t)bi * n + p) * d + e]) * inv[p];
+            for (int p = 0; p < n; ++p) {
+                const float ch = to_f32(c[((int64_t)bi * n + p) * d + e]) * inv[p];
+                dc[((int64_t)bi * n + p) * d + e] = from_f32<T>(k * inv[p] * (u - ch * gdot[p]));
+            }
+        }
+    }
+}
+
+}  // namespace leccr
+
+using namespace leccr;
+
+extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
+                                     int both_dirs, float* loss, float* ws, void* stream) {
+    LECCR_REQUIRE(a && b && loss && ws && G > 0 && D > 0 && D <= 4096 && temp != 0.f, LECCR_EINVAL, "sim_infonce_fwd: bad argument");
+    LECCR_REQUIRE((D & 3) == 0, LECCR_EALIGN, "sim_infonce_fwd: D must be a multiple of 4");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("sim_infonce memset");
+    const float scale = both_dirs ? 0.5f / G : 1.f / G;
+    hipLaunchKernelGGL(sim_rowlse_kernel, dim3((unsigned)cdiv(G, 4), both_dirs ? 2 : 1), dim3(256), 4 * D * sizeof(float), st,
+                       a, b, idx, 1.f / temp, (int)G, (int)D, loss, ws, scale);
+    return check_launch("sim_infonce_fwd");
+}
+
+extern "C" int leccr_sim_infonce_bwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
+                                     int both_dirs, const float* ws, float gscale, float* da, float* db, float* dtemp,
+                                     void* stream) {
+    LECCR_REQUIRE(a && b && ws && da && db && G > 0 && D > 0 && D <= 512 && (D & 3) == 0, LECCR_EINVAL, "sim_infonce_bwd: bad argument (D <= 512)");
+    hipStream_t st = as_stream(stream);
+    const float w_r = gscale * (both_dirs ? 0.5f / G : 1.f / G), w_c = both_dirs ? w_r : 0.f;
+    hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(G, 4), 2), dim3(256), 4 * (D + 64) * sizeof(float), st, a, b, idx,
+                       1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp);
+    return check_launch("sim_infonce_bwd");
+}
+
+extern "C" int leccr_capsim_fwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D, float* loss,
+                                int32_t* argmax, float* ws, void* stream) {
+    LECCR_REQUIRE(c && t && loss && argmax && ws && b > 0 && n > 0 && n <= 8 && D > 0 && (D & 3) == 0 && n * D <= 3072, LECCR_EINVAL, "capsim_fwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("capsim memset");
+    float* logits = ws;
+    float* lse_r = ws + b * b;
+    float* lse_c = lse_r + b;
+    hipLaunchKernelGGL(capsim_logits_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 4 * n * D * sizeof(float), st, c, t,
+                       1.f / temp, (int)b, (int)n, (int)D, logits, argmax);
+    hipLaunchKernelGGL(lse_ce_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, logits, (int)b, (int)b, (int64_t)b, (int64_t)1, lse_r, loss, 0.5f / b);
+    hipLaunchKernelGGL(lse_ce_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, logits, (int)b, (int)b, (int64_t)1, (int64_t)b, lse_c, loss, 0.5f / b);
+    return check_launch("capsim_fwd");
+}
+
+extern "C" int leccr_capsim_bwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D,
+                                const int32_t* argmax, const float* ws, float gscale, float* dc, float* dt, float* dtemp,
+                                void* stream) {
+    LECCR_REQUIRE(c && t && argmax && ws && dc && dt && b > 0 && n > 0 && n <= 8 && D > 0 && D <= 512, LECCR_EINVAL, "capsim_bwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(capsim_bwd_kernel, dim3((unsigned)cdiv(b, 4), 2), dim3(256), 0, st, c, t, 1.f / temp, (int)b, (int)n,
+                       (int)D, argmax, ws, gscale * 0.5f / b, dc, dt, dtemp);
+    return check_launch("capsim_bwd");
+}
+
+extern "C" int leccr_dstl_fwd(const float* v, const float* c, const float* s, const float* t, float alpha, int64_t G,
+                              int64_t n, int64_t D, float* loss, float* ws, void* stream) {
+    LECCR_REQUIRE(v && c && s && t && loss && ws && G > 0 && n > 0 && n <= 8 && D > 0 && (D & 3) == 0 && (2 + n) * D <= 3072, LECCR_EINVAL, "dstl_fwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    float* tv = ws;
+    float* lab = ws + G * G;
+    float* sc = lab + G * G;
+    int* mm = reinterpret_cast<int*>(sc + G * G);
+    float* lse_tv = reinterpret_cast<float*>(mm + 4);
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("dstl memset");
+    hipLaunchKernelGGL(dstl_init_kernel, dim3(1), dim3(1), 0, st, mm);
+    hipLaunchKernelGGL(dstl_scores_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 4 * (2 + n) * D * sizeof(float), st, v, c, s, t,
+                       (int)G, (int)n, (int)D, tv, lab, sc, mm);
+    hipLaunchKernelGGL(dstl_kl_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, tv, lab, sc, mm, alpha, (int)G, lse_tv, loss);
+    return check_launch("dstl_fwd");
+}
+
+extern "C" int leccr_dstl_bwd(const float* v, const float* t, int64_t G, int64_t D, const float* ws, float gscale, float* dv,
+                              float* dt, void* stream) {
+    LECCR_REQUIRE(v && t && ws && dv && dt && G > 0 && D > 0 && D <= 512, LECCR_EINVAL, "dstl_bwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    const float* tv = ws;
+    const float* lab = ws + G * G;
+    const float* lse_tv = ws + 3 * G * G + 4;
+    hipLaunchKernelGGL(dstl_bwd_kernel, dim3((unsigned)cdiv(G, 4), 2), dim3(256), 0, st, v, t, (int)G, (int)D, tv, lab, lse_tv,
+                       gscale / G, dv, dt);
+    return check_launch("dstl_bwd");
+}
+
+extern "C" int leccr_cvpool_fwd(const void* x, float* pooled, float* inv_norm, int64_t b, int64_t L, int64_t d, int dtype,
+                                void* stream) {
+    LECCR_REQUIRE(x && pooled && inv_norm && L > 0 && d > 0, LECCR_EINVAL, "cvpool_fwd: bad argument");
+    if (b == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    dim3 grid((unsigned)cdiv(d, 256), (unsigned)b);
+    if (dtype == LECCR_F32) hipLaunchKernelGGL((cvpool_fwd_kernel<float>), grid, dim3(256), 0, st, (const float*)x, pooled, inv_norm, (int)L, (int)d);
+    else if (dtype == LECCR_BF16) hipLaunchKernelGGL((cvpool_fwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, pooled, inv_norm, (int)L, (int)d);
+    else { set_error("cvpool_fwd: bad dtype"); return LECCR_EINVAL; }
+    return check_launch("cvpool_fwd");
+}
+
+extern "C" int leccr_cvpool_bwd(const void* x, const float* inv_norm, const float* dpooled, void* dx, int64_t b, int64_t L,
+                                int64_t d, int dtype, void* stream) {
+    LECCR_REQUIRE(x && inv_norm && dpooled && dx && L > 0 && d > 0, LECCR_EINVAL, "cvpool_bwd: bad argument");
+    if (b == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    dim3 grid((unsigned)cdiv(d, 256), (unsigned)b);
+    if (dtype == LECCR_F32) hipLaunchKernelGGL((cvpool_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)x, inv_norm, dpooled, (float*)dx, (int)L, (int)d);
+    else if (dtype == LECCR_BF16) hipLaunchKernelGGL((cvpool_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)x, inv_norm, dpooled, (bf16_t*)dx, (int)L, (int)d);
+    else { set_error("cvpool_bwd: bad dtype"); return LECCR_EINVAL; }
+    return check_launch("cvpool_bwd");
+}
+
+extern "C" int leccr_capreg_fwd(const void* c, float* loss, int64_t b, int64_t n, int64_t d, int dtype, void* stream) {
+    LECCR_REQUIRE(c && loss && b > 0 && n > 0 && n <= 8 && d > 0, LECCR_EINVAL, "capreg_fwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("capreg memset");
+    dim3 grid((unsigned)cdiv(b, 4));
+    if (dtype == LECCR_F32) hipLaunchKernelGGL((capreg_kernel<float, false>), grid, dim3(256), 0, st, (const float*)c, loss, (float*)nullptr, 1.f, (int)b, (int)n, (int)d);
+    else if (dtype == LECCR_BF16) hipLaunchKernelGGL((capreg_kernel<bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)c, loss, (bf16_t*)nullptr, 1.f, (int)b, (int)n, (int)d);
+    else { set_error("capreg_fwd: bad dtype"); return LECCR_EINVAL; }
+    return check_launch("capreg_fwd");
+}
+
+extern "C" int leccr_capreg_bwd(const void* c, float gscale, void* dc, int64_t b, int64_t n, int64_t d, int dtype, void* stream) {
+    LECCR_REQUIRE(c && dc && b > 0 && n > 0 && n <= 8 && d > 0, LECCR_EINVAL, "capreg_bwd: bad argument");
+    hipStream_t st = as_stream(stream);
+    dim3 grid((unsigned)cdiv(b, 4));
+    if (dtype == LECCR_F32) hipLaunchKernelGGL((capreg_kernel<float, true>), grid, dim3(256), 0, st, (const float*)c, (float*)nullptr, (float*)dc, gscale, (int)b, (int)n, (int)d);
+    else if (dtype == LECCR_BF16) hipLaunchKernelGGL((capreg_kernel<bf16_t, true>), grid, dim3(256), 0, st, (const bf16_t*)c, (float*)nullptr, (bf16_t*)dc, gscale, (int)b, (int)n, (int)d);
+    else { set_error("capreg_bwd: bad dtype"); return LECCR_EINVAL; }
+    return check_launch("capreg_bwd");
+}

@@ -1,0 +1,296 @@
+// norm.hip - LayerNorm forward/backward, row L2-normalise forward/backward, column sums (bias gradients).
+// All HBM-bound: one wave64 per row, 16-byte (f32) / 8-byte (bf16) vector accesses, statistics in f32,
+// wave-shuffle reductions (no LDS for the row statistics).
+#include "common.h"
+
+namespace leccr {
+
+// A wave owns one row; lane l handles the 4-element chunks c = l, l+64, ... (NCH chunks per lane, d <= NCH*256).
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ add,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            T* __restrict__ sum_out, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int64_t rows, int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const T* xr = x + row * d;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            v[i] = load4(xr + c);
+            if (add) v[i] += load4(add + row * d + c);
+            if (sum_out) {
+                // normalise exactly what is stored (and later handed to the backward as x_in): round through T
+                store4(sum_out + row * d + c, v[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = to_f32(from_f32<T>(v[i][j]));
+            }
+            s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mu = wave_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            const f32x4 t = v[i] - mu;
+            q += t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3];
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / d + eps);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < d) {
+            const f32x4 g = load4(gamma + c), b = load4(beta + c);
+            store4(y + row * d + c, (v[i] - mu) * rs * g + b);
+        }
+    }
+}
+
+// Backward.  Grid-stride over rows so each wave accumulates its dgamma/dbeta partials in registers; one LDS reduce
+// per block and one f32 atomic per (block, column).
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xin,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                            T* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, int64_t rows, int d) {
+    __shared__ float red[NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 g[NCH], dg[NCH], db[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        g[i] = c < d ? load4(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NCH], gy[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+                const f32x4 dyv = load4(dy + row * d + c);
+                xh[i] = (load4(xin + row * d + c) - mu) * rs;
+                gy[i] = dyv * g[i];
+                dg[i] += dyv * xh[i];
+                db[i] += dyv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s1 += gy[i][j];
+                    s2 += gy[i][j] * xh[i][j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / d;
+        s2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+                f32x4 o = (gy[i] - s1 - xh[i] * s2) * rs;
+                if (dres) o += load4(dres + row * d + c);
+                store4(dx + row * d + c, o);
+            }
+        }
+    }
+    // reduce the 4 waves' partials through LDS (one wave at a time), then one f32 atomic per column
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int w = 0; w < 4; ++w) {
+            __syncthreads();
+            if (wave == w) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + 64 * i) * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float val = pass == 0 ? dg[i][j] : db[i][j];
+                        red[c + j] = w == 0 ? val : red[c + j] + val;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float* out = pass == 0 ? dgamma : dbeta;
+        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(out + c, red[c]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                         float* __restrict__ inv_norm, int64_t rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float v = to_f32(x[row * d + c]);
+        s += v * v;
+    }
+    const float inv = 1.f / fmaxf(sqrtf(wave_sum(s)), 1e-12f);  // F.normalize eps
+    if (lane == 0) inv_norm[row] = inv;
+    for (int c = lane; c < d; c += 64) y[row * d + c] = from_f32<T>(to_f32(x[row * d + c]) * inv);
+}
+
+// y = x * inv  ->  dx = inv * (dy - y * <dy, y>)
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                         const float* __restrict__ inv_norm, T* __restrict__ dx,
+                                                         int64_t rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s += to_f32(dy[row * d + c]) * to_f32(y[row * d + c]);
+    s = wave_sum(s);
+    const float inv = inv_norm[row];
+    for (int c = lane; c < d; c += 64)
+        dx[row * d + c] = from_f32<T>(inv * (to_f32(dy[row * d + c]) - to_f32(y[row * d + c]) * s));
+}
+
+// out[n] += sum_m x[m, n].  Block = 64 column-quads x 4 row phases; grid.y slices the rows.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t M,
+                                                     int64_t N, int64_t ldx, int rows_per_block) {
+    __shared__ float red[4][256 + 4];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t n = ((int64_t)blockIdx.x * 64 + tx) * 4;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (n + 3 < N) {
+        for (int64_t m = r0 + ty; m < r1; m += 4) acc += load4(x + m * ldx + n);
+    } else {
+        for (int64_t m = r0 + ty; m < r1; m += 4)
+            for (int j = 0; j < 4; ++j)
+                if (n + j < N) acc[j] += to_f32(x[m * ldx + n + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[ty][tx * 4 + j] = acc[j];
+    __syncthreads();
+    const int c = threadIdx.x;
+    const int64_t nn = (int64_t)blockIdx.x * 256 + c;
+    if (nn < N) atomicAdd(out + nn, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+}
+
+template <typename T>
+static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, const float* beta, void* y,
+                           void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
+                           hipStream_t st) {
+    dim3 grid((unsigned)cdiv(rows, 4));
+#define L(N)                                                                                                      \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, (const T*)add, gamma, beta, \
+                       (T*)y, (T*)sum_out, mean, rstd, rows, (int)d, eps)
+    if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
+    else if (d <= 2048) L(8); else L(16);
+#undef L
+    return check_launch("layernorm_fwd");
+}
+
+template <typename T>
+static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, const float* mean, const float* rstd,
+                           const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d,
+                           hipStream_t st) {
+    int64_t nb = cdiv(rows, 4);
+    if (nb > 1024) nb = 1024;
+    dim3 grid((unsigned)nb);
+#define L(N)                                                                                                     \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma, mean, \
+                       rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, (int)d)
+    if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
+    else if (d <= 2048) L(8); else L(16);
+#undef L
+    return check_launch("layernorm_bwd");
+}
+
+}  // namespace leccr
+
+using namespace leccr;
+
+#define DISPATCH_T(dtype, CALL_F32, CALL_BF16)                           \
+    do {                                                                 \
+        if ((dtype) == LECCR_F32) return CALL_F32;                       \
+        if ((dtype) == LECCR_BF16) return CALL_BF16;                     \
+        set_error("bad dtype %d", (int)(dtype));                         \
+        return LECCR_EINVAL;                                             \
+    } while (0)
+
+extern "C" int leccr_layernorm_fwd(const void* x, const void* add, const float* gamma, const float* beta, void* y,
+                                   void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
+                                   int dtype, void* stream) {
+    LECCR_REQUIRE(x && gamma && beta && y && mean && rstd, LECCR_EINVAL, "layernorm_fwd: null pointer");
+    LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_fwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
+    if (rows == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    DISPATCH_T(dtype, ln_fwd_dispatch<float>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, st),
+               ln_fwd_dispatch<bf16_t>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, st));
+}
+
+extern "C" int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, const float* mean,
+                                   const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                   int64_t rows, int64_t d, int dtype, void* stream) {
+    LECCR_REQUIRE(dy && x_in && gamma && mean && rstd && dx && dgamma && dbeta, LECCR_EINVAL, "layernorm_bwd: null pointer");
+    LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_bwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
+    if (rows == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st),
+               ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st));
+}
+
+template <typename T>
+static int l2f(const void* x, void* y, float* inv, int64_t rows, int64_t d, hipStream_t st) {
+    hipLaunchKernelGGL((l2norm_fwd_kernel<T>), dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, (const T*)x, (T*)y, inv, rows, (int)d);
+    return check_launch("l2norm_fwd");
+}
+template <typename T>
+static int l2b(const void* dy, const void* y, const float* inv, void* dx, int64_t rows, int64_t d, hipStream_t st) {
+    hipLaunchKernelGGL((l2norm_bwd_kernel<T>), dim3((unsigned)cdiv(rows, 4)), dim3(256), 0, st, (const T*)dy, (const T*)y, inv, (T*)dx, rows, (int)d);
+    return check_launch("l2norm_bwd");
+}
+
+extern "C" int leccr_l2norm_fwd(const void* x, void* y, float* inv_norm, int64_t rows, int64_t d, int dtype, void* stream) {
+    LECCR_REQUIRE(x && y && inv_norm && d > 0, LECCR_EINVAL, "l2norm_fwd: bad argument");
+    if (rows == 0) return LECCR_OK;
+    DISPATCH_T(dtype, l2f<float>(x, y, inv_norm, rows, d, as_stream(stream)), l2f<bf16_t>(x, y, inv_norm, rows, d, as_stream(stream)));
+}
+
+extern "C" int leccr_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void* dx, int64_t rows, int64_t d,
+                                int dtype, void* stream) {
+    LECCR_REQUIRE(dy && y && inv_norm && dx && d > 0, LECCR_EINVAL, "l2norm_bwd: bad argument");
+    if (rows == 0) return LECCR_OK;
+    DISPATCH_T(dtype, l2b<float>(dy, y, inv_norm, dx, rows, d, as_stream(stream)), l2b<bf16_t>(dy, y, inv_norm, dx, rows, d, as_stream(stream)));
+}
+
+template <typename T>
+static int cs(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, hipStream_t st) {
+    int rpb = 256;
+    while ((int64_t)cdiv(M, rpb) * cdiv(N, 256) > 4096) rpb *= 2;
+    dim3 grid((unsigned)cdiv(N, 256), (unsigned)cdiv(M, rpb));
+    hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, M, N, ldx, rpb);
+    return check_launch("colsum");
+}
+
+extern "C" int leccr_colsum(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, int dtype, void* stream) {
+    LECCR_REQUIRE(x && out && ldx >= N, LECCR_EINVAL, "colsum: bad argument");
+    LECCR_REQUIRE((ldx & 3) == 0 && ((uintptr_t)x & 15) == 0, LECCR_EALIGN, "colsum: x must be 16-byte aligned with ldx %% 4 == 0");
+    if (M == 0 || N == 0) return LECCR_OK;
+    DISPATCH_T(dtype, cs<float>(x, out, M, N, ldx, as_stream(stream)), cs<bf16_t>(x, out, M, N, ldx, as_stream(stream)));
+}

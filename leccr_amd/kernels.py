@@ -1,0 +1,318 @@
+"""Thin functional wrappers over the C ABI (one Python function per entry point, tensors in / tensors out).
+
+No autograd here (see ops.py) and no fallback: every function launches a HIP kernel from libleccr_hip.so on the
+current torch stream.  torch is used for allocation only.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from ._lib import (BF16, EPI_DGELU, EPI_DQUICKGELU, EPI_GELU, EPI_NONE, EPI_QUICKGELU, F32, check, dtype_code, lib,
+                   ptr, stream)
+
+
+def _rows2d(t):
+    """View [.., d] as (rows, d, ld) with a unit inner stride."""
+    assert t.stride(-1) == 1, 'inner dimension must be contiguous'
+    t2 = t.reshape(-1, t.shape[-1]) if t.is_contiguous() else t
+    assert t2.dim() == 2
+    return t2, t2.shape[0], t2.shape[1], t2.stride(0)
+
+
+def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
+         out=None, out_dtype=None, accumulate=False, alpha=1.0):
+    """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major."""
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
+    assert a.stride(1) == 1 and b.stride(1) == 1
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N, Kb = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+    if out is None:
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
+    assert out.shape == (M, N) and out.stride(1) == 1
+    p = L.GemmParams()
+    p.A, p.B, p.C = ptr(a), ptr(b), ptr(out)
+    p.M, p.N, p.K = M, N, K
+    p.lda, p.ldb, p.ldc = a.stride(0), b.stride(0), out.stride(0)
+    p.ab_dtype, p.c_dtype = dtype_code(a), dtype_code(out)
+    p.trans_a, p.trans_b = int(trans_a), int(trans_b)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
+    p.bias = ptr(bias)
+    p.epilogue, p.accumulate = epilogue, int(accumulate)
+    for t in (aux, aux_out, residual):
+        if t is not None:
+            assert t.dtype == out.dtype and t.shape == (M, N) and t.stride(1) == 1
+    p.aux, p.ldaux = ptr(aux), (aux.stride(0) if aux is not None else 0)
+    if aux_out is not None:
+        assert aux_out.stride(0) == out.stride(0)
+    p.aux_out = ptr(aux_out)
+    p.residual, p.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
+    p.alpha = alpha
+    check(lib().leccr_gemm(C.byref(p), stream()), 'leccr_gemm')
+    return out
+
+
+def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False):
+    x2, rows, d, ld = _rows2d(x)
+    assert ld == d
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    s = torch.empty_like(x2) if want_sum else None
+    if add is not None:
+        add = add.reshape(rows, d)
+        assert add.is_contiguous() and add.dtype == x.dtype
+    check(lib().leccr_layernorm_fwd(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd),
+                                    rows, d, eps, dtype_code(x), stream()), 'leccr_layernorm_fwd')
+    return y.view(x.shape), mean, rstd, (s.view(x.shape) if s is not None else None)
+
+
+def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None):
+    dy2, rows, d, ld = _rows2d(dy)
+    assert ld == d and x_in.is_contiguous()
+    dx = torch.empty_like(dy2)
+    if dres is not None:
+        assert dres.is_contiguous() and dres.dtype == dy.dtype
+    check(lib().leccr_layernorm_bwd(ptr(dy2), ptr(x_in), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                                    ptr(dgamma), ptr(dbeta), rows, d, dtype_code(dy), stream()), 'leccr_layernorm_bwd')
+    return dx.view(dy.shape)
+
+
+def _attn_args(q, k, v):
+    # q [b, Lq, heads*hd] possibly a strided view of a packed projection (row stride = ld, batch stride = Lq*ld)
+    for t, Lx in ((q, q.shape[1]), (k, k.shape[1]), (v, v.shape[1])):
+        assert t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == Lx * t.stride(1), (t.shape, t.stride())
+    return q.shape[0], q.shape[1], k.shape[1]
+
+
+def attn_fwd(q, k, v, heads, kmask=None):
+    b, Lq, Lk = _attn_args(q, k, v)
+    d = q.shape[2]
+    hd = d // heads
+    o = torch.empty(b, Lq, d, device=q.device, dtype=q.dtype)
+    lse = torch.empty(b, heads, Lq, device=q.device, dtype=torch.float32)
+    if kmask is not None:
+        assert kmask.dtype == torch.uint8 and kmask.shape == (b, Lk) and kmask.is_contiguous()
+    check(lib().leccr_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), b, heads, Lq, Lk, hd,
+                               q.stride(1), k.stride(1), v.stride(1), o.stride(1), dtype_code(q), stream()),
+          'leccr_attn_fwd')
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None):
+    b, Lq, Lk = _attn_args(q, k, v)
+    d = q.shape[2]
+    hd = d // heads
+    assert o.is_contiguous() and dout.is_contiguous() and dout.shape == o.shape
+    # gradients must have the strides of their inputs (the model passes views of one packed dqkv buffer)
+    dq = torch.empty_strided(q.shape, q.stride(), device=q.device, dtype=q.dtype) if dq is None else dq
+    dk = torch.empty_strided(k.shape, k.stride(), device=q.device, dtype=q.dtype) if dk is None else dk
+    dv = torch.empty_strided(v.shape, v.stride(), device=q.device, dtype=q.dtype) if dv is None else dv
+    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    delta = torch.empty_like(lse)
+    check(lib().leccr_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(kmask), ptr(dq), ptr(dk),
+                               ptr(dv), ptr(delta), b, heads, Lq, Lk, hd, q.stride(1), k.stride(1), v.stride(1),
+                               o.stride(1), dtype_code(q), stream()), 'leccr_attn_bwd')
+    return dq, dk, dv
+
+
+def colsum(x, out):
+    """out[n] += sum_m x[m, n]  (bias gradients)."""
+    x2, M, N, ld = _rows2d(x)
+    assert out.dtype == torch.float32 and out.numel() == N
+    check(lib().leccr_colsum(ptr(x2), ptr(out), M, N, ld, dtype_code(x), stream()), 'leccr_colsum')
+    return out
+
+
+def l2norm_fwd(x):
+    x2, rows, d, ld = _rows2d(x)
+    assert ld == d
+    y = torch.empty_like(x2)
+    inv = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib().leccr_l2norm_fwd(ptr(x2), ptr(y), ptr(inv), rows, d, dtype_code(x), stream()), 'leccr_l2norm_fwd')
+    return y.view(x.shape), inv
+
+
+def l2norm_bwd(dy, y, inv):
+    dy2, rows, d, ld = _rows2d(dy)
+    assert ld == d and y.is_contiguous()
+    dx = torch.empty_like(dy2)
+    check(lib().leccr_l2norm_bwd(ptr(dy2), ptr(y), ptr(inv), ptr(dx), rows, d, dtype_code(dy), stream()),
+          'leccr_l2norm_bwd')
+    return dx.view(dy.shape)
+
+
+# --------------------------------------------------------------------------------------- tower input stages
+def patchify(image, p, Kp, dtype):
+    b, c, R, _ = image.shape
+    assert c == 3 and image.dtype == torch.float32 and image.is_contiguous()
+    g = R // p
+    out = torch.empty(b * g * g, Kp, device=image.device, dtype=dtype)
+    check(lib().leccr_patchify(ptr(image), ptr(out), b, R, p, Kp, dtype_code(out), stream()), 'leccr_patchify')
+    return out
+
+
+def vit_assemble_fwd(patch_out, cls, pos, b):
+    N, d = pos.shape
+    tok = torch.empty(b, N, d, device=patch_out.device, dtype=patch_out.dtype)
+    check(lib().leccr_vit_assemble_fwd(ptr(patch_out), ptr(cls), ptr(pos), ptr(tok), b, N, d, dtype_code(tok),
+                                       stream()), 'leccr_vit_assemble_fwd')
+    return tok
+
+
+def vit_assemble_bwd(dtok, dcls, dpos):
+    b, N, d = dtok.shape
+    assert dtok.is_contiguous()
+    dpatch = torch.empty(b * (N - 1), d, device=dtok.device, dtype=dtok.dtype)
+    check(lib().leccr_vit_assemble_bwd(ptr(dtok), ptr(dpatch), ptr(dcls), ptr(dpos), b, N, d, dtype_code(dtok),
+                                       stream()), 'leccr_vit_assemble_bwd')
+    return dpatch
+
+
+def bert_embed_fwd(ids, word, pos, type0, dtype):
+    b, Lx = ids.shape
+    vocab, d = word.shape
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    emb = torch.empty(b, Lx, d, device=ids.device, dtype=dtype)
+    check(lib().leccr_bert_embed_fwd(ptr(ids), ptr(word), ptr(pos), ptr(type0), ptr(emb), b, Lx, d, vocab,
+                                     dtype_code(emb), stream()), 'leccr_bert_embed_fwd')
+    return emb
+
+
+def bert_embed_bwd(ids, demb, dword, dpos, dtype0, pad_id=0):
+    b, Lx, d = demb.shape
+    assert demb.is_contiguous()
+    check(lib().leccr_bert_embed_bwd(ptr(ids), ptr(demb), ptr(dword), ptr(dpos), ptr(dtype0), b, Lx, d,
+                                     dword.shape[0], pad_id, dtype_code(demb), stream()), 'leccr_bert_embed_bwd')
+
+
+# --------------------------------------------------------------------------------------- losses (f32)
+def _f32c(t):
+    assert t.dtype == torch.float32 and t.is_contiguous(), (t.dtype, t.stride())
+    return t
+
+
+def sim_infonce_fwd(a, b, idx, temp, both_dirs=True):
+    G, D = _f32c(a).shape
+    _f32c(b)
+    loss = torch.empty(1, device=a.device, dtype=torch.float32)
+    ws = torch.empty(2 * G, device=a.device, dtype=torch.float32)
+    check(lib().leccr_sim_infonce_fwd(ptr(a), ptr(b), ptr(idx), float(temp), G, D, int(both_dirs), ptr(loss),
+                                      ptr(ws), stream()), 'leccr_sim_infonce_fwd')
+    return loss, ws
+
+
+def sim_infonce_bwd(a, b, idx, temp, ws, gscale, both_dirs=True, dtemp=None):
+    G, D = a.shape
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    check(lib().leccr_sim_infonce_bwd(ptr(a), ptr(b), ptr(idx), float(temp), G, D, int(both_dirs), ptr(ws),
+                                      float(gscale), ptr(da), ptr(db), ptr(dtemp), stream()), 'leccr_sim_infonce_bwd')
+    return da, db
+
+
+def capsim_fwd(c, t, temp):
+    b, n, D = _f32c(c).shape
+    _f32c(t)
+    loss = torch.empty(1, device=c.device, dtype=torch.float32)
+    am = torch.empty(b, b, device=c.device, dtype=torch.int32)
+    ws = torch.empty(b * b + 2 * b, device=c.device, dtype=torch.float32)
+    check(lib().leccr_capsim_fwd(ptr(c), ptr(t), float(temp), b, n, D, ptr(loss), ptr(am), ptr(ws), stream()),
+          'leccr_capsim_fwd')
+    return loss, am, ws
+
+
+def capsim_bwd(c, t, temp, am, ws, gscale, dtemp=None):
+    b, n, D = c.shape
+    dc, dt = torch.empty_like(c), torch.empty_like(t)
+    check(lib().leccr_capsim_bwd(ptr(c), ptr(t), float(temp), b, n, D, ptr(am), ptr(ws), float(gscale), ptr(dc),
+                                 ptr(dt), ptr(dtemp), stream()), 'leccr_capsim_bwd')
+    return dc, dt
+
+
+def dstl_fwd(v, c, s, t, alpha):
+    G, n, D = _f32c(c).shape
+    for x in (v, s, t):
+        _f32c(x)
+    loss = torch.empty(1, device=v.device, dtype=torch.float32)
+    ws = torch.empty(3 * G * G + G + 8, device=v.device, dtype=torch.float32)
+    check(lib().leccr_dstl_fwd(ptr(v), ptr(c), ptr(s), ptr(t), float(alpha), G, n, D, ptr(loss), ptr(ws), stream()),
+          'leccr_dstl_fwd')
+    return loss, ws
+
+
+def dstl_bwd(v, t, ws, gscale):
+    G, D = v.shape
+    dv, dt = torch.empty_like(v), torch.empty_like(t)
+    check(lib().leccr_dstl_bwd(ptr(v), ptr(t), G, D, ptr(ws), float(gscale), ptr(dv), ptr(dt), stream()),
+          'leccr_dstl_bwd')
+    return dv, dt
+
+
+def cvpool_fwd(x):
+    b, Lx, d = x.shape
+    assert x.is_contiguous()
+    pooled = torch.empty(b, d, device=x.device, dtype=torch.float32)
+    inv = torch.empty_like(pooled)
+    check(lib().leccr_cvpool_fwd(ptr(x), ptr(pooled), ptr(inv), b, Lx, d, dtype_code(x), stream()), 'leccr_cvpool_fwd')
+    return pooled, inv
+
+
+def cvpool_bwd(x, inv, dpooled):
+    b, Lx, d = x.shape
+    dx = torch.empty_like(x)
+    check(lib().leccr_cvpool_bwd(ptr(x), ptr(inv), ptr(_f32c(dpooled)), ptr(dx), b, Lx, d, dtype_code(x), stream()),
+          'leccr_cvpool_bwd')
+    return dx
+
+
+def capreg_fwd(c):
+    b, n, d = c.shape
+    assert c.is_contiguous()
+    loss = torch.empty(1, device=c.device, dtype=torch.float32)
+    check(lib().leccr_capreg_fwd(ptr(c), ptr(loss), b, n, d, dtype_code(c), stream()), 'leccr_capreg_fwd')
+    return loss
+
+
+def capreg_bwd(c, gscale):
+    b, n, d = c.shape
+    dc = torch.empty_like(c)
+    check(lib().leccr_capreg_bwd(ptr(c), float(gscale), ptr(dc), b, n, d, dtype_code(c), stream()), 'leccr_capreg_bwd')
+    return dc
+
+
+# --------------------------------------------------------------------------------------- eval / optimizer
+def rank_of_gt(scores, gt):
+    """scores [R,C] f32; gt [R,per] int32 (-1 = unused) -> int32 [R] best rank of any ground truth."""
+    R, Cn = _f32c(scores).shape
+    assert gt.dtype == torch.int32 and gt.is_contiguous() and gt.shape[0] == R
+    out = torch.empty(R, device=scores.device, dtype=torch.int32)
+    check(lib().leccr_rank_of_gt(ptr(scores), ptr(gt), ptr(out), R, Cn, scores.stride(0), gt.shape[1], stream()),
+          'leccr_rank_of_gt')
+    return out
+
+
+def adamw(p, g, m, v, seg_end, seg_wd, lr, beta1, beta2, eps, step, gscale=1.0):
+    n = p.numel()
+    check(lib().leccr_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(seg_end), ptr(seg_wd), seg_end.numel(), float(lr),
+                            float(beta1), float(beta2), float(eps), int(step), float(gscale), stream()), 'leccr_adamw')
+
+
+def cast_bf16(src, dst):
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    check(lib().leccr_cast_bf16(ptr(src), ptr(dst), src.numel(), stream()), 'leccr_cast_bf16')
+    return dst
+
+
+def transpose_cast(src, dst):
+    R, Cn = src.shape
+    assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.numel() == R * Cn
+    check(lib().leccr_transpose_cast(ptr(src), ptr(dst), R, Cn, dtype_code(dst), stream()), 'leccr_transpose_cast')
+    return dst
+
+
+def axpy(x, y, a):
+    assert x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    check(lib().leccr_axpy(ptr(x), ptr(y), float(a), x.numel(), dtype_code(x), stream()), 'leccr_axpy')
+    return y

@@ -1,0 +1,402 @@
+"""Kernel-level parity on a real MI355X: every C-ABI entry point vs a plain PyTorch CPU reference (f64 math on the
+same - already rounded - inputs).  Tolerances: f32 path 1e-5 relative (summation order only); bf16 path: output
+rounding of bf16 (2^-8 relative) on top of exact-product f32 accumulation."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module')
+def K():
+    from leccr_amd import kernels
+    return kernels
+
+
+def _rand(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def _err(got, ref):
+    got, ref = got.detach().cpu().double(), ref.double()
+    return float((got - ref).abs().max()), float(ref.abs().max()) + 1e-12
+
+
+def _tol(dtype):
+    return 2e-5 if dtype == torch.float32 else 1.2e-2
+
+
+ACT = {0: lambda x: x, 1: lambda x: x * torch.sigmoid(1.702 * x),
+       2: lambda x: 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))}
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('M,N,K_', [(128, 128, 64), (256, 384, 128), (300, 260, 192), (577 * 2, 768, 768),
+                                    (37, 20, 50), (1154, 2304, 768)])
+def test_gemm_nt(K, dtype, M, N, K_):
+    a, b = _rand((M, K_), dtype, 1), _rand((N, K_), dtype, 2, 0.05)
+    bias = _rand((N,), torch.float32, 3)
+    out = K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV))
+    ref = a.double() @ b.double().t() + bias.double()
+    e, s = _err(out, ref)
+    assert e <= _tol(dtype) * s, (e, s)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('epi', [1, 2])
+def test_gemm_epilogues(K, dtype, epi):
+    M, N, K_ = 260, 256, 128
+    a, b = _rand((M, K_), dtype, 4), _rand((N, K_), dtype, 5, 0.1)
+    bias, res = _rand((N,), torch.float32, 6), _rand((M, N), dtype, 7)
+    pre = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), epilogue=epi, aux_out=pre, residual=res.to(DEV))
+    u = a.double() @ b.double().t() + bias.double()
+    e, s = _err(pre, u)
+    assert e <= _tol(dtype) * s
+    ref = ACT[epi](u) + res.double()
+    e, s = _err(out, ref)
+    assert e <= _tol(dtype) * s, (e, s)
+    # derivative epilogue: dX = (dY W) * act'(u)
+    dy, w = _rand((M, N), dtype, 8), _rand((N, K_), dtype, 9, 0.1)     # here N plays "out features"
+    u2 = _rand((M, K_), dtype, 10)
+    got = K.gemm(dy.to(DEV), w.t().contiguous().to(DEV), epilogue=epi + 2, aux=u2.to(DEV))
+    ud = u2.double().requires_grad_(True)
+    ACT[epi](ud).sum().backward()
+    ref = (dy.double() @ w.double()) * ud.grad
+    e, s = _err(got, ref)
+    assert e <= _tol(dtype) * s, (e, s)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('Kt,M,N', [(256, 128, 128), (577 * 3, 768, 256), (1000, 264, 136), (64 * 40, 768, 3072)])
+def test_gemm_tn_weight_grad(K, dtype, Kt, M, N):
+    """dW[M,N] += dY[Kt,M]^T X[Kt,N] (reduction-major operands, f32 accumulate into an existing buffer)."""
+    dy, x = _rand((Kt, M), dtype, 11), _rand((Kt, N), dtype, 12)
+    base = _rand((M, N), torch.float32, 13)
+    out = base.clone().to(DEV)
+    K.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True, out=out, accumulate=True)
+    ref = base.double() + dy.double().t() @ x.double()
+    e, s = _err(out, ref)
+    assert e <= 3e-5 * s * (1 if dtype == torch.float32 else 4), (e, s)   # f32 output: no bf16 rounding of C
+
+
+def test_gemm_strided_views(K):
+    """Packed-projection addressing: A/B/C as column slices of wider buffers (lda != K)."""
+    big_a = _rand((200, 512), torch.bfloat16, 14).to(DEV)
+    w = _rand((384, 256), torch.bfloat16, 15, 0.05).to(DEV)
+    big_c = torch.zeros(200, 1024, dtype=torch.bfloat16, device=DEV)
+    a = big_a[:, 128:384]
+    K.gemm(a, w, out=big_c[:, 256:640])
+    ref = a.cpu().double() @ w.cpu().double().t()
+    e, s = _err(big_c[:, 256:640], ref)
+    assert e <= 1.2e-2 * s
+    assert float(big_c[:, :256].abs().max()) == 0 and float(big_c[:, 640:].abs().max()) == 0
+
+
+def test_gemm_rejects_bad_arguments(K):
+    from leccr_amd._lib import LeccrHipError
+    a = torch.zeros(4, 8, device=DEV)
+    with pytest.raises(LeccrHipError):
+        K.gemm(a, a, out=torch.zeros(4, 4, device=DEV, dtype=torch.bfloat16), accumulate=True)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,d,eps', [(7, 64, 1e-5), (577 * 2, 768, 1e-5), (33, 512, 1e-5), (19, 768, 1e-12),
+                                        (5, 1024, 1e-5), (3, 4096, 1e-5)])
+def test_layernorm(K, dtype, rows, d, eps):
+    x, add = _rand((rows, d), dtype, 20), _rand((rows, d), dtype, 21)
+    g, b = 1 + 0.1 * _rand((d,), torch.float32, 22), _rand((d,), torch.float32, 23)
+    y, mean, rstd, s = K.layernorm_fwd(x.to(DEV), g.to(DEV), b.to(DEV), eps, add=add.to(DEV), want_sum=True)
+    xs = (x.double() + add.double())
+    e, sc = _err(s, xs)
+    assert e <= _tol(dtype) * sc
+    xin = s.cpu().double().requires_grad_(True)       # the kernel normalises the ROUNDED sum
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xin, (d,), gd, bd, eps)
+    e, sc = _err(y, ref)
+    assert e <= _tol(dtype) * sc, (e, sc)
+    dy, dres = _rand((rows, d), dtype, 24), _rand((rows, d), dtype, 25)
+    (ref * dy.double()).sum().backward()
+    dg = torch.zeros(d, device=DEV)
+    db = torch.zeros(d, device=DEV)
+    dx = K.layernorm_bwd(dy.to(DEV), s, g.to(DEV), mean, rstd, dg, db, dres=dres.to(DEV))
+    e, sc = _err(dx, xin.grad + dres.double())
+    assert e <= _tol(dtype) * sc, ('dx', e, sc)
+    e, sc = _err(dg, gd.grad)
+    assert e <= 1e-4 * sc + 1e-5, ('dgamma', e, sc)
+    e, sc = _err(db, bd.grad)
+    assert e <= 1e-4 * sc + 1e-5, ('dbeta', e, sc)
+
+
+def _ref_attn(q, k, v, heads, kmask):
+    b, Lq, d = q.shape
+    Lk, hd = k.shape[1], d // heads
+    qh = q.reshape(b, Lq, heads, hd).permute(0, 2, 1, 3)
+    kh = k.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    vh = v.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / math.sqrt(hd)
+    if kmask is not None:
+        s = s.masked_fill(kmask.bool()[:, None, None, :], float('-inf'))
+    o = torch.softmax(s, -1) @ vh
+    return o.permute(0, 2, 1, 3).reshape(b, Lq, d), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('b,heads,Lq,Lk,hd,masked', [(2, 2, 17, 17, 64, False), (3, 12, 9, 9, 64, True),
+                                                     (2, 8, 4, 70, 64, True), (2, 8, 150, 4, 64, False),
+                                                     (2, 4, 33, 33, 8, True), (1, 12, 577, 577, 64, False),
+                                                     (2, 8, 5, 5, 512, True)])
+def test_attention(K, dtype, b, heads, Lq, Lk, hd, masked):
+    d = heads * hd
+    # packed projection buffers: q|k|v side by side (strided views), as the model uses them
+    if Lq == Lk:
+        qkv = _rand((b, Lq, 3 * d), dtype, 30, 1.0 if hd <= 64 else 0.3)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        qkv_d = qkv.to(DEV)
+        qd, kd, vd = qkv_d[..., :d], qkv_d[..., d:2 * d], qkv_d[..., 2 * d:]
+    else:
+        q = _rand((b, Lq, d), dtype, 31)
+        kv = _rand((b, Lk, 2 * d), dtype, 32)
+        k, v = kv[..., :d], kv[..., d:]
+        qd, kv_d = q.to(DEV), kv.to(DEV)
+        kd, vd = kv_d[..., :d], kv_d[..., d:]
+    kmask = None
+    if masked:
+        lens = torch.randint(1, Lk + 1, (b,), generator=torch.Generator().manual_seed(33))
+        lens[0] = Lk
+        kmask = (torch.arange(Lk)[None, :] >= lens[:, None]).to(torch.uint8)
+    o, lse = K.attn_fwd(qd, kd, vd, heads, kmask.to(DEV) if masked else None)
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, ref_lse = _ref_attn(qr, kr, vr, heads, kmask)
+    e, s = _err(o, ref)
+    assert e <= _tol(dtype) * s, ('o', e, s)
+    e, s = _err(lse, ref_lse)
+    assert e <= 1e-4 * s + 1e-4, ('lse', e, s)
+    do = _rand((b, Lq, d), dtype, 34)
+    (ref * do.double()).sum().backward()
+    if Lq == Lk:        # gradients land in one packed dqkv buffer, as in the model
+        dqkv = torch.zeros_like(qkv_d)
+        gv = (dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:])
+    else:
+        dkv = torch.zeros_like(kv_d)
+        gv = (None, dkv[..., :d], dkv[..., d:])
+    dq, dk, dv = K.attn_bwd(qd, kd, vd, o, do.to(DEV), lse, heads, kmask.to(DEV) if masked else None,
+                            dq=gv[0], dk=gv[1], dv=gv[2])
+    for name, got, r in (('dq', dq, qr.grad), ('dk', dk, kr.grad), ('dv', dv, vr.grad)):
+        e, s = _err(got, r)
+        # bf16: o and p are rounded before the backward products -> a few bf16 ulps of the largest element
+        assert e <= (1e-4 if dtype == torch.float32 else 3e-2) * s, (name, e, s)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_colsum_and_l2norm(K, dtype):
+    x = _rand((1000, 772), dtype, 40)
+    out = torch.ones(772, device=DEV)
+    K.colsum(x.to(DEV), out)
+    e, s = _err(out, 1 + x.double().sum(0))
+    assert e <= 1e-5 * s + 1e-4
+    f = _rand((37, 256), dtype, 41)
+    y, inv = K.l2norm_fwd(f.to(DEV))
+    fr = f.double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(fr, dim=-1)
+    e, s = _err(y, ref)
+    assert e <= _tol(dtype) * s
+    dy = _rand((37, 256), dtype, 42)
+    (ref * dy.double()).sum().backward()
+    dx = K.l2norm_bwd(dy.to(DEV), y, inv)
+    e, s = _err(dx, fr.grad)
+    assert e <= (1e-5 if dtype == torch.float32 else 2e-2) * s
+
+
+# ------------------------------------------------------------------------------------------ tower input stages
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('R,p,Kp', [(64, 16, 768), (96, 32, 3072), (56, 14, 640)])
+def test_patchify_and_assemble(K, dtype, R, p, Kp):
+    b, d = 3, 64
+    img = _rand((b, 3, R, R), torch.float32, 50)
+    pat = K.patchify(img.to(DEV), p, Kp, dtype)
+    g = R // p
+    ref = img.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b * g * g, 3 * p * p)
+    ref = torch.cat([ref, torch.zeros(b * g * g, Kp - 3 * p * p)], 1).to(dtype)
+    assert torch.equal(pat.cpu(), ref)
+    N = g * g + 1
+    po, cls, pos = _rand((b * (N - 1), d), dtype, 51), _rand((d,), torch.float32, 52), _rand((N, d), torch.float32, 53)
+    tok = K.vit_assemble_fwd(po.to(DEV), cls.to(DEV), pos.to(DEV), b)
+    ref = torch.cat([cls.expand(b, 1, d).double(), po.double().reshape(b, N - 1, d)], 1) + pos.double()
+    e, s = _err(tok, ref)
+    assert e <= _tol(dtype) * s
+    dtok = _rand((b, N, d), dtype, 54)
+    dcls, dpos = torch.ones(d, device=DEV), torch.ones(N, d, device=DEV)
+    dpo = K.vit_assemble_bwd(dtok.to(DEV), dcls, dpos)
+    assert torch.equal(dpo.cpu(), dtok[:, 1:].reshape(-1, d))
+    e, s = _err(dpos, 1 + dtok.double().sum(0))
+    assert e <= 1e-5 * s
+    e, s = _err(dcls, 1 + dtok.double()[:, 0].sum(0))
+    assert e <= 1e-5 * s
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_bert_embed(K, dtype):
+    b, L, d, vocab = 5, 11, 128, 300
+    g = torch.Generator().manual_seed(60)
+    ids = torch.randint(0, vocab, (b, L), generator=g)
+    ids[:, -3:] = 0                                       # padding ids
+    ids[1, 2] = ids[3, 4] = 7                             # duplicates -> accumulation
+    word, pos, typ = _rand((vocab, d), torch.float32, 61), _rand((40, d), torch.float32, 62), _rand((2, d), torch.float32, 63)
+    emb = K.bert_embed_fwd(ids.to(DEV), word.to(DEV), pos.to(DEV), typ.to(DEV), dtype)
+    ref = word[ids].double() + pos[:L].double() + typ[0].double()
+    e, s = _err(emb, ref)
+    assert e <= _tol(dtype) * s
+    demb = _rand((b, L, d), dtype, 64)
+    dword, dpos, dtyp = torch.zeros(vocab, d, device=DEV), torch.zeros(40, d, device=DEV), torch.zeros(2, d, device=DEV)
+    K.bert_embed_bwd(ids.to(DEV), demb.to(DEV), dword, dpos, dtyp)
+    rw = torch.zeros(vocab, d, dtype=torch.float64)
+    rw.index_add_(0, ids.reshape(-1), demb.double().reshape(-1, d))
+    rw[0] = 0                                             # padding_idx row gets no gradient
+    e, s = _err(dword, rw)
+    assert e <= 1e-5 * s
+    e, s = _err(dpos[:L], demb.double().sum(0))
+    assert e <= 1e-5 * s and float(dpos[L:].abs().max()) == 0
+    e, s = _err(dtyp[0], demb.double().sum((0, 1)))
+    assert e <= 1e-5 * s and float(dtyp[1].abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------ losses
+def _unit(shape, seed):
+    return torch.nn.functional.normalize(_rand(shape, torch.float32, seed), dim=-1)
+
+
+@pytest.mark.parametrize('G,D,use_idx,both', [(6, 16, True, True), (70, 256, True, True), (256, 256, False, True),
+                                              (130, 512, True, False), (33, 64, False, False)])
+def test_sim_infonce(K, G, D, use_idx, both):
+    a, b = _unit((G, D), 70), _unit((G, D), 71)
+    idx = torch.arange(G)
+    idx[G // 2] = idx[0]
+    idx[G - 1] = idx[0]
+    temp = 0.07 if both else 1.0
+    ad, bd = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    td = torch.tensor(temp, dtype=torch.float64, requires_grad=True)
+    logits = ad @ bd.t() / td
+    if use_idx:
+        pos = (idx[:, None] == idx[None, :]).double()
+        lab = pos / pos.sum(1, keepdim=True)
+    else:
+        lab = torch.eye(G, dtype=torch.float64)
+    ref = -(torch.log_softmax(logits, 1) * lab).sum(1).mean()
+    if both:
+        ref = (ref - (torch.log_softmax(logits.t(), 1) * lab).sum(1).mean()) / 2
+    (ref * 1.7).backward()
+    ia = idx.to(DEV) if use_idx else None
+    loss, ws = K.sim_infonce_fwd(a.to(DEV), b.to(DEV), ia, temp, both)
+    assert abs(float(loss) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref))), (float(loss), float(ref))
+    dtemp = torch.zeros(1, device=DEV)
+    da, db = K.sim_infonce_bwd(a.to(DEV), b.to(DEV), ia, temp, ws, 1.7, both, dtemp)
+    for name, got, r in (('da', da, ad.grad), ('db', db, bd.grad), ('dtemp', dtemp[0], td.grad)):
+        e, s = _err(got, r)
+        assert e <= 1e-4 * s + 1e-7, (name, e, s)
+
+
+@pytest.mark.parametrize('b,n,D', [(6, 4, 16), (70, 4, 256), (256, 2, 256)])
+def test_capsim(K, b, n, D):
+    c, t = _rand((b, n, D), torch.float32, 72, 0.2), _unit((b, D), 73)
+    cd, tdd = c.double().requires_grad_(True), t.double().requires_grad_(True)
+    temp = torch.tensor(0.07, dtype=torch.float64, requires_grad=True)
+    logits = torch.einsum('ind,jd->nij', cd, tdd).max(0)[0] / temp
+    lab = torch.arange(b)
+    ref = (torch.nn.functional.cross_entropy(logits, lab) + torch.nn.functional.cross_entropy(logits.t(), lab)) / 2
+    (ref * 0.5).backward()
+    loss, am, ws = K.capsim_fwd(c.to(DEV), t.to(DEV), 0.07)
+    assert abs(float(loss) - float(ref)) <= 2e-5 * max(1.0, abs(float(ref)))
+    dtemp = torch.zeros(1, device=DEV)
+    dc, dt = K.capsim_bwd(c.to(DEV), t.to(DEV), 0.07, am, ws, 0.5, dtemp)
+    for name, got, r in (('dc', dc, cd.grad), ('dt', dt, tdd.grad), ('dtemp', dtemp[0], temp.grad)):
+        e, s = _err(got, r)
+        assert e <= 1e-4 * s + 1e-7, (name, e, s)
+
+
+@pytest.mark.parametrize('G,n,D', [(6, 4, 16), (70, 4, 256), (256, 4, 256)])
+def test_dstl(K, G, n, D):
+    v, s, t = _unit((G, D), 74), _unit((G, D), 75), _unit((G, D), 76)
+    c = _rand((G, n, D), torch.float32, 77, 0.2)
+    vd, tdd = v.double().requires_grad_(True), t.double().requires_grad_(True)
+    sd, cd = s.double(), c.double()
+    ns = lambda x: (x - x.min()) / (x - x.min()).max()
+    lab = torch.softmax(0.8 * ns(sd @ vd.detach().t()) + 0.2 * ns(torch.einsum('ind,jd->nij', cd, sd).max(0)[0]), 1)
+    ref = torch.nn.functional.kl_div(torch.log_softmax(tdd @ vd.t(), 1), lab, reduction='batchmean')
+    (ref * 0.3).backward()
+    loss, ws = K.dstl_fwd(v.to(DEV), c.to(DEV), s.to(DEV), t.to(DEV), 0.8)
+    assert abs(float(loss) - float(ref)) <= 5e-5 * max(1e-2, abs(float(ref))), (float(loss), float(ref))
+    dv, dt = K.dstl_bwd(v.to(DEV), t.to(DEV), ws, 0.3)
+    for name, got, r in (('dv', dv, vd.grad), ('dt', dt, tdd.grad)):
+        e, sc = _err(got, r)
+        assert e <= 2e-4 * sc + 1e-8, (name, e, sc)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_cvpool_capreg(K, dtype):
+    x = _rand((5, 37, 128), dtype, 78)
+    xd = x.double().requires_grad_(True)
+    ref = torch.nn.functional.normalize(xd, dim=1).mean(1)          # F.normalize default dim=1 = token axis
+    pooled, inv = K.cvpool_fwd(x.to(DEV))
+    e, s = _err(pooled, ref)
+    assert e <= 1e-5 * s
+    dp = _rand((5, 128), torch.float32, 79)
+    (ref * dp.double()).sum().backward()
+    dx = K.cvpool_bwd(x.to(DEV), inv, dp.to(DEV))
+    e, s = _err(dx, xd.grad)
+    assert e <= (1e-5 if dtype == torch.float32 else 1e-2) * s
+    c = _rand((9, 4, 512), dtype, 80)
+    cd = c.double().requires_grad_(True)
+    ch = torch.nn.functional.normalize(cd, dim=-1)
+    ref = (ch @ ch.transpose(1, 2) - torch.eye(4, dtype=torch.float64)).mean()
+    (ref * 2.5).backward()
+    loss = K.capreg_fwd(c.to(DEV))
+    assert abs(float(loss) - float(ref)) <= 1e-5 + 1e-4 * abs(float(ref))
+    dc = K.capreg_bwd(c.to(DEV), 2.5)
+    e, s = _err(dc, cd.grad)
+    assert e <= (1e-4 if dtype == torch.float32 else 1.5e-2) * s
+
+
+def test_rank_of_gt_and_optimizer(K):
+    import numpy as np
+    rng = np.random.default_rng(5)
+    s = rng.permutation(40 * 100).reshape(40, 100).astype(np.float32)
+    gt = np.stack([rng.choice(100, 5, replace=False) for _ in range(40)]).astype(np.int32)
+    gt[3, 2:] = -1
+    got = K.rank_of_gt(torch.from_numpy(s).to(DEV), torch.from_numpy(gt).to(DEV)).cpu().numpy()
+    for r in range(40):
+        inds = np.argsort(s[r])[::-1]
+        want = min(int(np.where(inds == g)[0][0]) for g in gt[r] if g >= 0)
+        assert got[r] == want
+    # AdamW vs a literal restatement of transformers.AdamW's update rule
+    n = 1000
+    p, g = _rand((n,), torch.float32, 81), _rand((n,), torch.float32, 82)
+    m, v = torch.zeros(n), torch.zeros(n)
+    seg_end = torch.tensor([400, 1000], dtype=torch.int64)
+    seg_wd = torch.tensor([0.01, 0.0])
+    pd, md, vd = p.to(DEV), m.to(DEV), v.to(DEV)
+    pr, mr, vr = p.double().clone(), m.double(), v.double()
+    lr, b1, b2, eps = 1e-3, 0.9, 0.98, 1e-8
+    for step in (1, 2, 3):
+        gs = g * step
+        K.adamw(pd, gs.to(DEV), md, vd, seg_end.to(DEV), seg_wd.to(DEV), lr, b1, b2, eps, step)
+        mr = b1 * mr + (1 - b1) * gs.double()
+        vr = b2 * vr + (1 - b2) * gs.double() ** 2
+        step_size = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        pr = pr - step_size * mr / (vr.sqrt() + eps)
+        wd = torch.cat([torch.full((400,), 0.01), torch.zeros(600)]).double()
+        pr = pr - lr * wd * pr
+    e, sc = _err(pd, pr)
+    assert e <= 1e-6 * sc
+    w = _rand((70, 130), torch.float32, 83)
+    wt = torch.empty(130, 70, dtype=torch.bfloat16, device=DEV)
+    K.transpose_cast(w.to(DEV), wt)
+    assert torch.equal(wt.cpu(), w.t().contiguous().to(torch.bfloat16))
+    wb = torch.empty(70 * 130, dtype=torch.bfloat16, device=DEV)
+    K.cast_bf16(w.to(DEV).reshape(-1), wb)
+    assert torch.equal(wb.cpu(), w.reshape(-1).to(torch.bfloat16))
