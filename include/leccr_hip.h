@@ -33,6 +33,11 @@ extern "C" {
 int leccr_version(void);                       /* ABI version, bumps on any signature change */
 const char* leccr_last_error(void);            /* text of the last error on this thread */
 int leccr_set_force_generic(int on);           /* 1: route every op through the simple f32-arithmetic kernels */
+/* Optional timing of the GEMM / attention launches with hipEvents recorded on the launch stream (bench.py's
+ * roofline leg).  read(): ms[5], work[5] (algorithmic FLOPs), launches[5] indexed
+ * {gemm_mfma_nt, gemm_mfma_tn, gemm_generic, attn_fwd, attn_bwd}; synchronises on the recorded events. */
+int leccr_prof_enable(int on);
+int leccr_prof_read(double* ms, double* work, int64_t* launches);
 
 /* ---- GEMM -------------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )      (+ C if accumulate)

@@ -44,7 +44,8 @@ class ParamArena:
                             add(p)
                         groups.append((m, gname, plist, start))
         for p in model.parameters():
-            add(p)
+            if not getattr(p, '_leccr_unused', False):      # inert state_dict-only parameters stay outside the arena
+                add(p)
         self.params = params
         self.names = {id(p): n for n, p in model.named_parameters()}
         device = device or params[0].device
@@ -107,11 +108,6 @@ class ParamArena:
     # ------------------------------------------------------------------ gradients
     def zero_grad(self):
         self.grad.zero_()
-
-    def mark(self, holder):
-        """A kernel wrote (accumulated) this parameter's gradient in place."""
-        for p in (holder.members if isinstance(holder, _Packed) else (holder,)):
-            self.touched[p._aidx] = True
 
     def mark_autograd_grads(self):
         """Parameters updated through plain autograd (tiny ones: temp, queries) count as touched when non-zero."""

@@ -25,6 +25,7 @@ extern "C" int leccr_attn_fwd(const void* q, const void* k, const void* v, void*
     if (int rc = check_dims("attn_fwd", D, dtype)) return rc;
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
+    ProfScope prof(PROF_ATTN_FWD, 4.0 * (double)b * heads * Lq * Lk * hd, st);
     if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) return attn_mfma_fwd(q, k, v, o, lse, kmask, D, st);
     return dtype == LECCR_F32 ? attn_generic_fwd<float>(q, k, v, o, lse, kmask, D, st)
                               : attn_generic_fwd<bf16_t>(q, k, v, o, lse, kmask, D, st);
@@ -39,6 +40,7 @@ extern "C" int leccr_attn_bwd(const void* q, const void* k, const void* v, const
     if (int rc = check_dims("attn_bwd", D, dtype)) return rc;
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
+    ProfScope prof(PROF_ATTN_BWD, 10.0 * (double)b * heads * Lq * Lk * hd, st);
     if (!g_force_generic_attn && attn_mfma_supported(D, dtype))
         return attn_mfma_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
     return dtype == LECCR_F32 ? attn_generic_bwd<float>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st)

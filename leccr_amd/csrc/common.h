@@ -28,6 +28,15 @@ int check_launch(const char* what);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Optional in-library timing (leccr_prof_*): brackets a launch with hipEvents on the launch stream.
+enum ProfKind { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD = 3, PROF_ATTN_BWD = 4, PROF_KINDS = 5 };
+struct ProfScope {
+    int slot;
+    hipStream_t st;
+    ProfScope(int kind, double work, hipStream_t stream);
+    ~ProfScope();
+};
+
 template <typename T> struct DT;
 template <> struct DT<float> { static constexpr int code = LECCR_F32; };
 template <> struct DT<bf16_t> { static constexpr int code = LECCR_BF16; };

@@ -366,11 +366,14 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
         LECCR_REQUIRE(p.aux != nullptr, LECCR_EINVAL, "gemm: derivative epilogue needs aux");
     if (p.M == 0 || p.N == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
+    const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
     if (mfma_ok(p)) {
+        ProfScope prof(p.trans_a == 0 ? PROF_GEMM_NT : PROF_GEMM_TN, flops, st);
         if (p.trans_a == 0)
             return p.c_dtype == LECCR_F32 ? launch_mfma<0, float>(p, st) : launch_mfma<0, bf16_t>(p, st);
         return p.c_dtype == LECCR_F32 ? launch_mfma<1, float>(p, st) : launch_mfma<1, bf16_t>(p, st);
     }
+    ProfScope prof(PROF_GEMM_GENERIC, flops, st);
     if (p.ab_dtype == LECCR_F32) {
         LECCR_REQUIRE(p.c_dtype == LECCR_F32, LECCR_EINVAL, "gemm: f32 operands need an f32 C");
         return launch_generic<float, float>(p, st);

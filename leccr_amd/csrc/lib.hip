@@ -1,5 +1,6 @@
 // lib.hip - library plumbing: version, thread-local error text, launch check.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -21,7 +22,54 @@ int check_launch(const char* what) {
     }
     return LECCR_OK;
 }
+
+// ---- profiling: event pairs around selected launches, summed per kind on read ---------------------------------
+static bool g_prof_on = false;
+static constexpr int kProfCap = 1 << 15;
+struct ProfRec { hipEvent_t a, b; int kind; double work; };
+static ProfRec* g_prof = nullptr;
+static int g_prof_n = 0;
+
+ProfScope::ProfScope(int kind, double work, hipStream_t stream) : slot(-1), st(stream) {
+    if (!g_prof_on || g_prof_n >= kProfCap) return;
+    slot = g_prof_n++;
+    ProfRec& r = g_prof[slot];
+    if (!r.a) {
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+    }
+    r.kind = kind;
+    r.work = work;
+    (void)hipEventRecord(r.a, st);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof[slot].b, st);
+}
 }  // namespace leccr
+
+extern "C" int leccr_prof_enable(int on) {
+    using namespace leccr;
+    if (on && !g_prof) g_prof = static_cast<ProfRec*>(calloc(kProfCap, sizeof(ProfRec)));
+    g_prof_on = on != 0;
+    if (on) g_prof_n = 0;
+    return LECCR_OK;
+}
+
+// ms[k], work[k] (FLOPs), launches[k] for k < 5 (gemm_nt, gemm_tn, gemm_generic, attn_fwd, attn_bwd). Synchronises.
+extern "C" int leccr_prof_read(double* ms, double* work, int64_t* launches) {
+    using namespace leccr;
+    for (int k = 0; k < PROF_KINDS; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    for (int i = 0; i < g_prof_n; ++i) {
+        ProfRec& r = g_prof[i];
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
+        ms[r.kind] += t;
+        work[r.kind] += r.work;
+        launches[r.kind] += 1;
+    }
+    return LECCR_OK;
+}
 
 extern "C" int leccr_version(void) { return 1; }
 extern "C" const char* leccr_last_error(void) { return leccr::g_err; }

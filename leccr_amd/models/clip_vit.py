@@ -1,0 +1,143 @@
+"""CLIP vision tower with the reference's module tree (clip/model.py:171-240, 246-346) over the HIP ops.
+
+Only the ViT image path is live.  The CLIP text tower that the reference allocates and never uses
+(clip_encoder.transformer.*, token_embedding, ...) is kept as inert parameters so checkpoints load key for key.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .layers import LayerNormParams, Linear, mark_unused
+
+
+class _MHAParams(nn.Module):
+    """nn.MultiheadAttention's parameter names: in_proj_weight [3d,d], in_proj_bias, out_proj.{weight,bias}."""
+
+    def __init__(self, d, xavier=True):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _MLP(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.c_fc = Linear(d, 4 * d)
+        self.c_proj = Linear(4 * d, d)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d, heads):
+        super().__init__()
+        self.heads = heads
+        self.attn = _MHAParams(d)
+        self.ln_1 = LayerNormParams(d, 1e-5)
+        self.mlp = _MLP(d)
+        self.ln_2 = LayerNormParams(d, 1e-5)
+
+    def _params(self):
+        return (self.ln_1.weight, self.ln_1.bias, self.attn.in_proj_weight, self.attn.in_proj_bias,
+                self.attn.out_proj.weight, self.attn.out_proj.bias, self.ln_2.weight, self.ln_2.bias,
+                self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight, self.mlp.c_proj.bias)
+
+    def forward(self, x):
+        return ops.ViTBlockFn.apply(x, self, *self._params())
+
+
+class Transformer(nn.Module):
+    def __init__(self, width, layers, heads):
+        super().__init__()
+        self.width, self.layers = width, layers
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads) for _ in range(layers)])
+
+    def forward(self, x):
+        return self.resblocks(x)
+
+
+class VisionTransformer(nn.Module):
+    def __init__(self, input_resolution, patch_size, width, layers, heads, output_dim):
+        super().__init__()
+        self.input_resolution, self.patch_size, self.output_dim = input_resolution, patch_size, output_dim
+        self.conv1 = nn.Conv2d(3, width, patch_size, patch_size, bias=False)      # parameter holder (weight [d,3,p,p])
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = LayerNormParams(width, 1e-5)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = LayerNormParams(width, 1e-5)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+
+    def forward(self, image, dtype):
+        """-> transformer trunk output [b, N, width] (batch-major; clip/model.py:223-240)."""
+        tok = ops.PatchEmbedFn.apply(image, self.conv1.weight, self.class_embedding, self.positional_embedding, dtype)
+        x = self.ln_pre(tok)
+        return self.transformer(x)
+
+
+class CLIP(nn.Module):
+    """Constructor signature of the reference's CLIP (clip/model.py:246-297), ViT vision towers only."""
+
+    def __init__(self, embed_dim, image_resolution, vision_layers, vision_width, vision_patch_size, context_length,
+                 vocab_size, transformer_width, transformer_heads, transformer_layers, text_tower=True):
+        super().__init__()
+        assert not isinstance(vision_layers, (tuple, list)), 'ModifiedResNet towers are outside the LECCR path'
+        self.visual = VisionTransformer(image_resolution, vision_patch_size, vision_width, vision_layers,
+                                        vision_width // 64, embed_dim)
+        self.context_length = context_length
+        if text_tower:      # allocated by the reference, never used by LECCR: inert parameters
+            self.transformer = mark_unused(Transformer(transformer_width, transformer_layers, transformer_heads))
+            self.token_embedding = mark_unused(nn.Embedding(vocab_size, transformer_width))
+            self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width))
+            self.ln_final = mark_unused(LayerNormParams(transformer_width, 1e-5))
+            self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+            self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+            for p in (self.positional_embedding, self.text_projection, self.logit_scale):
+                p._leccr_unused = True
+            nn.init.normal_(self.token_embedding.weight, std=0.02)
+            nn.init.normal_(self.positional_embedding, std=0.01)
+            nn.init.normal_(self.text_projection, std=transformer_width ** -0.5)
+            self._init_blocks(self.transformer)
+        self._init_blocks(self.visual.transformer)
+        self.compute_dtype = torch.float32
+
+    @staticmethod
+    def _init_blocks(tr):
+        """initialize_parameters (clip/model.py:299-326)."""
+        proj_std = (tr.width ** -0.5) * ((2 * tr.layers) ** -0.5)
+        attn_std = tr.width ** -0.5
+        fc_std = (2 * tr.width) ** -0.5
+        for blk in tr.resblocks:
+            nn.init.normal_(blk.attn.in_proj_weight, std=attn_std)
+            nn.init.normal_(blk.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(blk.mlp.c_fc.weight, std=fc_std)
+            nn.init.normal_(blk.mlp.c_proj.weight, std=proj_std)
+
+    def float(self):
+        return self
+
+    def encode_image(self, image, return_hidden=False):
+        """clip/model.py:340-346: ln_post on ALL tokens then @ proj; returns (cls, hidden) when return_hidden."""
+        v = self.visual
+        x = v(image, self.compute_dtype)
+        hidden = ops.LnProjFn.apply(x, v.ln_post.weight, v.ln_post.bias, v.proj)
+        cls = hidden[:, 0, :]
+        if return_hidden:
+            return cls.contiguous(), hidden
+        return cls.contiguous()
+
+
+# name -> (width, layers, patch, embed_dim) for the ViT entries of clip.clip._MODELS (clip/clip.py:30-40)
+VIT_GEOMETRY = {'ViT-B/32': (768, 12, 32, 512), 'ViT-B/16': (768, 12, 16, 512), 'ViT-L/14': (1024, 24, 14, 768)}
+
+
+def build_clip(name='ViT-B/32', image_resolution=384, text_tower=True, geometry=None):
+    """Random-init CLIP of the named geometry at the reference's hard-coded 384 resolution (clip/model.py:414).
+    `geometry` (dict of CLIP constructor arguments) overrides the name - used by the tiny parity fixtures."""
+    if geometry is not None:
+        return CLIP(text_tower=text_tower, **geometry)
+    width, layers, patch, embed = VIT_GEOMETRY[name]
+    return CLIP(embed, image_resolution, layers, width, patch, 77, 49408, 512, 8, 12, text_tower=text_tower)

@@ -1,0 +1,193 @@
+"""XVLMBase + AllGather with the reference's API (models/xvlm.py:50-70,150-292), computed by the HIP ops.
+
+Extensions (all optional, defaults reproduce the reference's hard-coded choices):
+  config['clip_name']      'ViT-B/32' (reference default, xvlm.py:85) | 'ViT-B/16' | 'ViT-L/14'
+  config['text_config']    dict of BERT geometry overrides (default: bert-base-multilingual-cased geometry)
+  config['clip_geometry']  dict of CLIP constructor arguments overriding clip_name (tiny parity fixtures)
+  config['compute_dtype']  'fp32' (reference precision, parity path) | 'bf16' (MFMA path)
+  config['clip_text_tower'] keep the unused CLIP text tower's parameters for state_dict compatibility (default True)
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from .. import ops
+from ..arena import ParamArena
+from .bert import BertModel
+from .clip_vit import VIT_GEOMETRY, build_clip
+from .layers import Linear, mark_unused
+
+
+class AllGather(torch.autograd.Function):
+    """models/xvlm.py:50-70: forward all_gather + cat(dim 0); backward returns ONLY the local row slice of the
+    incoming gradient (no reduce-scatter).  Over RCCL (backend 'nccl' on ROCm) / xGMI."""
+
+    @staticmethod
+    def forward(ctx, tensor, rank, world_size):
+        tensor = tensor.contiguous()
+        out = torch.empty((world_size,) + tuple(tensor.shape), device=tensor.device, dtype=tensor.dtype)
+        dist.all_gather_into_tensor(out.view(-1), tensor.view(-1)) if tensor.is_cuda else \
+            dist.all_gather(list(out.unbind(0)), tensor)
+        ctx.rank, ctx.batch_size = rank, tensor.shape[0]
+        return out.view((world_size * tensor.shape[0],) + tuple(tensor.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return grad_output[ctx.batch_size * ctx.rank: ctx.batch_size * (ctx.rank + 1)], None, None
+
+
+allgather = AllGather.apply
+
+
+def _dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def gather_rows(t):
+    rank, world = _dist_info()
+    return t if world == 1 else allgather(t, rank, world)
+
+
+def build_mlp(input_dim, output_dim):
+    """xvlm.py:74-80 (itm_head: allocated by the reference, never used on the LECCR path)."""
+    return nn.Sequential(nn.Linear(input_dim, input_dim * 2), nn.LayerNorm(input_dim * 2), nn.GELU(),
+                         nn.Linear(input_dim * 2, output_dim))
+
+
+def build_clip_encoder(config):
+    """xvlm.py:83-88 hard-codes 'ViT-B/32' + pretrained weights; here: any ViT geometry, seeded random init
+    (no network on this pipeline), overridable through config['clip_name']."""
+    config = config or {}
+    name = config.get('clip_name', 'ViT-B/32')
+    geometry = config.get('clip_geometry')
+    clip = build_clip(name, image_resolution=config.get('clip_image_res', 384),
+                      text_tower=config.get('clip_text_tower', True), geometry=geometry)
+    return clip, (geometry['embed_dim'] if geometry else VIT_GEOMETRY[name][3])
+
+
+def build_text_encoder(config):
+    """xvlm.py:91-103: bert-base-multilingual-cased geometry (random init here), dropout 0.1 in the reference."""
+    enc = BertModel((config or {}).get('text_config'))
+    return enc, enc.config.hidden_size
+
+
+_UNUSED_MARKERS = ('.norm1.', 'itm_head.', '.pooler.')
+
+
+def is_unused_parameter(name):
+    """Parameters the reference allocates but that never receive a gradient."""
+    if name.startswith('clip_encoder.') and not name.startswith('clip_encoder.visual.'):
+        return True
+    return any(m in name for m in _UNUSED_MARKERS)
+
+
+class XVLMBase(nn.Module):
+    def __init__(self, config=None, load_vision_params=False, load_text_params=False, use_contrastive_loss=False,
+                 use_matching_loss=False, use_mlm_loss=False, use_bbox_loss=False, config_text=None):
+        super().__init__()
+        self.allgather = allgather
+        self.init_params = []
+        self.config = config
+        self.clip_encoder, vision_width = build_clip_encoder(config)
+        self.text_encoder, text_width = build_text_encoder(config)
+        self.vision_width, self.text_width = vision_width, text_width
+        if use_contrastive_loss:
+            self.embed_dim = config['embed_dim']
+            self.text_proj = Linear(self.text_width, self.embed_dim)
+            self.init_params.extend(['text_proj.' + n for n, _ in self.text_proj.named_parameters()])
+            if config['use_one_cl_proj_only']:
+                assert self.vision_width == self.text_width
+                self.vision_proj = None
+            else:
+                self.vision_proj = Linear(self.vision_width, self.embed_dim)
+                self.init_params.extend(['vision_proj.' + n for n, _ in self.vision_proj.named_parameters()])
+            self.temp = nn.Parameter(torch.ones([]) * config['temp'])
+            self.init_params.extend(['temp'])
+        if use_matching_loss:
+            self.itm_head = mark_unused(build_mlp(input_dim=self.text_width, output_dim=2))
+            self.init_params.extend(['itm_head.' + n for n, _ in self.itm_head.named_parameters()])
+        dt = (config or {}).get('compute_dtype', 'fp32')
+        self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[dt]
+        self.arena = None
+
+    # ------------------------------------------------------------------ runtime (arena + compute copies)
+    def _ensure_runtime(self):
+        """Build the ParamArena on first use (after init_caption_encoder() and .to(device), as the reference's
+        main() orders them - image_Retrieval_caption.py:370-381)."""
+        if self.arena is not None:
+            return self.arena
+        dev = next(self.parameters()).device
+        if dev.type != 'cuda':
+            raise RuntimeError('leccr_amd models run on an MI355X only: move the model to the GPU first '
+                               '(there is no CPU fallback)')
+        for n, p in self.named_parameters():
+            p._leccr_unused = is_unused_parameter(n)
+        self.arena = ParamArena(self, self.compute_dtype, dev)
+        self.clip_encoder.compute_dtype = self.compute_dtype
+        self.text_encoder.compute_dtype = self.compute_dtype
+        a = self.arena
+        vis = self.clip_encoder.visual
+        cw = vis.conv1.weight
+        cw._lp2d, cw._g2d = cw._lp.view(cw.shape[0], -1), cw._g.view(cw.shape[0], -1)
+        assert cw._lp2d.shape[1] % 64 == 0 or self.compute_dtype == torch.float32, \
+            'patch size whose 3*p*p is not a multiple of 64 needs K padding (ViT-L/14): not wired yet'
+        a.need_transposed(vis.proj)
+        for name, p in self.named_parameters():
+            if p.dim() == 2 and not getattr(p, '_leccr_unused', False) and 'embeddings' not in name \
+                    and name != 'clip_encoder.visual.positional_embedding' and p is not vis.proj:
+                a.need_transposed(p)
+        for layer in self.text_encoder.encoder.layer:
+            a.need_transposed(layer._qkv_w)
+        a.refresh()
+        return a
+
+    def refresh_weights(self):
+        """Re-derive the low-precision compute copies after the master weights changed (optimizer step / load)."""
+        if self.arena is not None:
+            self.arena.refresh()
+
+    def load_state_dict(self, *args, **kw):
+        r = super().load_state_dict(*args, **kw)
+        self.refresh_weights()
+        return r
+
+    # ------------------------------------------------------------------ reference API
+    def get_vision_embeds(self, image, image_atts=None, idx_to_group_img=None, return_hidden=True):
+        """xvlm.py:203-210 -> (image_embeds [b,N,vw], image_atts [b,N] ones)."""
+        assert idx_to_group_img is None, 'grouped-image branch is outside the LECCR path'
+        self._ensure_runtime()
+        _, image_embeds = self.clip_encoder.encode_image(image, return_hidden=True)
+        image_atts = torch.ones(image_embeds.size()[:-1], dtype=torch.long, device=image.device)
+        return image_embeds, image_atts
+
+    def get_text_embeds(self, text_ids, text_atts):
+        """xvlm.py:237-238."""
+        self._ensure_runtime()
+        return self.text_encoder(text_ids, attention_mask=text_atts, return_dict=True).last_hidden_state
+
+    def _feat(self, proj, cls_rows):
+        return ops.l2_normalize(proj(cls_rows, out_f32=True))
+
+    def get_features(self, image_embeds=None, text_embeds=None, vis_pooling='cls'):
+        """xvlm.py:241-256: CLS -> Linear -> F.normalize (f32 features)."""
+        vision_proj = self.text_proj if self.vision_proj is None else self.vision_proj
+        assert vis_pooling == 'cls'
+        if image_embeds is None:
+            return self._feat(self.text_proj, text_embeds[:, 0, :])
+        if text_embeds is None:
+            return self._feat(vision_proj, image_embeds[:, 0, :])
+        return self._feat(vision_proj, image_embeds[:, 0, :]), self._feat(self.text_proj, text_embeds[:, 0, :])
+
+    def get_contrastive_loss(self, image_feat, text_feat, idx=None, tval=None):
+        """xvlm.py:260-292: all-gather both feature sets (+ idx), all-pairs logits / temp, soft-label InfoNCE both
+        directions.  The G x G logits are never materialised (leccr_sim_infonce_*)."""
+        assert image_feat.size(-1) == self.embed_dim and text_feat.size(-1) == self.embed_dim
+        a, b = gather_rows(image_feat.float()), gather_rows(text_feat.float())
+        idx_all = None
+        if idx is not None:
+            idx = idx.view(-1, 1)
+            assert idx.size(0) == image_feat.size(0)
+            idx_all = gather_rows(idx).view(-1).contiguous()
+        return ops.SimInfoNCEFn.apply(a, b, self.temp, idx_all, True, tval)

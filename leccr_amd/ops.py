@@ -1,0 +1,470 @@
+"""Autograd layer over the HIP kernels: one torch.autograd.Function per transformer layer / stage / loss.
+
+Design (MI355X-first, not a translation of the reference's op-by-op eager graph):
+  * a Function covers a whole layer, with a hand-written backward that fuses what eager autograd cannot: residual
+    gradients ride in LayerNorm-backward / GEMM epilogues, activation derivatives ride in the dX GEMM epilogue
+    (LECCR_EPI_D*), packed QKV projections are addressed in place by the attention kernels;
+  * parameter gradients are accumulated by the kernels straight into the ParamArena's flat gradient buffer
+    (backward returns None for parameters), so there is no per-parameter AccumulateGrad traffic;
+  * activations are batch-major [b, L, d] in the model's compute dtype (f32 or bf16); statistics and losses are f32.
+
+Every tensor op here is a launch from libleccr_hip.so (kernels.py); torch supplies allocation, views and the autograd
+graph only.
+"""
+import torch
+
+from . import kernels as K
+from ._lib import EPI_DGELU, EPI_DQUICKGELU, EPI_GELU, EPI_NONE, EPI_QUICKGELU
+
+_DACT = {EPI_QUICKGELU: EPI_DQUICKGELU, EPI_GELU: EPI_DGELU}
+
+
+# --------------------------------------------------------------------------------------- raw linear helpers
+def _bias(b):
+    return None if b is None else b.data.reshape(-1)
+
+
+def lin_fwd(x2, w, b=None, **kw):
+    """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free)."""
+    return K.gemm(x2, w._lp, bias=_bias(b), **kw)
+
+
+def lin_dx(dy2, w, **kw):
+    """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N]."""
+    if w._lpt is not None:
+        return K.gemm(dy2, w._lpt, **kw)
+    return K.gemm(dy2, w._lp, trans_b=True, **kw)
+
+
+def lin_dw(dy2, x2, w, b=None, scale=1.0):
+    """dW += scale * dY^T X (f32, into the gradient arena) and db += scale * colsum(dY)."""
+    K.gemm(dy2, x2, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale)
+    _mark(w)
+    if b is not None:
+        if scale == 1.0:
+            K.colsum(dy2, b._g.reshape(-1))
+        else:
+            tmp = torch.zeros(b._g.numel(), device=dy2.device, dtype=torch.float32)
+            K.colsum(dy2, tmp)
+            K.axpy(tmp, b._g.reshape(-1), scale)
+        _mark(b)
+
+
+def _mark(p):
+    """Record that a kernel accumulated into this parameter's gradient (drives the optimizer's skip list)."""
+    for m in (getattr(p, 'members', None) or (p,)):
+        m._arena.touched[m._aidx] = True
+
+
+def _rows(x):
+    return x.reshape(-1, x.shape[-1])
+
+
+class _Slice:
+    """Row range [r0, r1) of a 2-D weight/bias holder (packed in_proj: q rows, kv rows)."""
+
+    def __init__(self, h, r0, r1, cols_of_t=None):
+        self._lp = h._lp[r0:r1]
+        self._g = h._g[r0:r1]
+        self.data = h.data[r0:r1]
+        self._lpt = h._lpt[:, r0:r1] if getattr(h, '_lpt', None) is not None and h._lpt.dim() == 2 else None
+        self._base = h
+
+    @property
+    def members(self):
+        return getattr(self._base, 'members', (self._base,))
+
+
+# --------------------------------------------------------------------------------------- Linear / LayerNorm / L2
+class LinearFn(torch.autograd.Function):
+    """nn.Linear on the last axis.  x may be a strided row view (e.g. the [CLS] rows x[:, 0, :])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wgrad_scale, out_f32):
+        x2 = x if x.dim() == 2 else _rows(x)
+        y = lin_fwd(x2, weight, bias, out_dtype=torch.float32 if out_f32 else None)
+        ctx.save_for_backward(x2)
+        ctx.w, ctx.b, ctx.shape, ctx.scale = weight, bias, x.shape, wgrad_scale
+        return y.view(*x.shape[:-1], y.shape[-1])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        dy2 = _rows(dy.contiguous())
+        if dy2.dtype != x2.dtype:               # f32 head output: the GEMM operands share the compute dtype
+            dy2 = dy2.to(x2.dtype)
+        dx = lin_dx(dy2, ctx.w).view(ctx.shape) if ctx.needs_input_grad[0] else None
+        lin_dw(dy2, x2, ctx.w, ctx.b, ctx.scale)
+        return dx, None, None, None, None
+
+
+def linear(x, weight, bias=None, wgrad_scale=1.0, out_f32=False):
+    """out_f32: write the result in f32 even when the operands are bf16 (projection heads feeding the f32 losses)."""
+    return LinearFn.apply(x, weight, bias, wgrad_scale, out_f32)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        y, mean, rstd, _ = K.layernorm_fwd(x, weight.data, bias.data, eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.w, ctx.b = weight, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        dx = K.layernorm_bwd(dy.contiguous(), x, ctx.w.data, mean, rstd, ctx.w._g, ctx.b._g)
+        _mark(ctx.w)
+        _mark(ctx.b)
+        return dx, None, None, None
+
+
+def layer_norm(x, weight, bias, eps):
+    return LayerNormFn.apply(x, weight, bias, eps)
+
+
+class L2NormFn(torch.autograd.Function):
+    """F.normalize(x, dim=-1) (models/xvlm.py:245-256)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y, inv = K.l2norm_fwd(x.contiguous())
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        return K.l2norm_bwd(dy.contiguous(), y, inv)
+
+
+def l2_normalize(x):
+    return L2NormFn.apply(x)
+
+
+# --------------------------------------------------------------------------------------- CLIP ViT
+class PatchEmbedFn(torch.autograd.Function):
+    """conv1 (stride == kernel) as patchify + GEMM, then [CLS] + positional embedding (clip/model.py:224-228)."""
+
+    @staticmethod
+    def forward(ctx, image, conv_w, cls, pos, dtype):
+        b, _, R, _ = image.shape
+        d, _, p, _ = conv_w.shape
+        Kp = conv_w._lp2d.shape[1]
+        patches = K.patchify(image.contiguous(), p, Kp, dtype)
+        po = K.gemm(patches, conv_w._lp2d)
+        tok = K.vit_assemble_fwd(po, cls.data, pos.data, b)
+        ctx.save_for_backward(patches)
+        ctx.p = (conv_w, cls, pos)
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        (patches,) = ctx.saved_tensors
+        conv_w, cls, pos = ctx.p
+        dpo = K.vit_assemble_bwd(dtok.contiguous(), cls._g, pos._g)
+        _mark(cls)
+        _mark(pos)
+        K.gemm(dpo, patches, trans_a=True, trans_b=True, out=conv_w._g2d, accumulate=True)
+        _mark(conv_w)
+        return None, None, None, None, None
+
+
+class ViTBlockFn(torch.autograd.Function):
+    """ResidualAttentionBlock (clip/model.py:171-192): x + MHA(ln_1(x)); then + c_proj(QuickGELU(c_fc(ln_2(.))))."""
+
+    @staticmethod
+    def forward(ctx, x, blk, *params):
+        b, N, d = x.shape
+        M = b * N
+        h1, mean1, rstd1, _ = K.layernorm_fwd(x, blk.ln_1.weight.data, blk.ln_1.bias.data, 1e-5)
+        qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias).view(b, N, 3 * d)
+        o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
+        x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=_rows(x)).view(b, N, d)
+        h2, mean2, rstd2, _ = K.layernorm_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5)
+        pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
+        act = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, epilogue=EPI_QUICKGELU, aux_out=pre)
+        x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=_rows(x1)).view(b, N, d)
+        ctx.save_for_backward(x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act)
+        ctx.blk = blk
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act = ctx.saved_tensors
+        blk = ctx.blk
+        b, N, d = x.shape
+        dx2 = dx2.contiguous()
+        g2 = _rows(dx2)
+        dpre = lin_dx(g2, blk.mlp.c_proj.weight, epilogue=EPI_DQUICKGELU, aux=pre)
+        lin_dw(g2, act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+        dh2 = lin_dx(dpre, blk.mlp.c_fc.weight)
+        lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
+        dx1 = K.layernorm_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g,
+                              blk.ln_2.bias._g, dres=dx2)
+        g1 = _rows(dx1)
+        do = lin_dx(g1, blk.attn.out_proj.weight).view(b, N, d)
+        lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias)
+        dqkv = torch.empty_like(qkv)
+        K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+        dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight)
+        lin_dw(_rows(dqkv), _rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias)
+        dx = K.layernorm_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g,
+                             blk.ln_1.bias._g, dres=dx1)
+        for p in (blk.ln_1.weight, blk.ln_1.bias, blk.ln_2.weight, blk.ln_2.bias):
+            _mark(p)
+        return (dx, None) + (None,) * 12
+
+
+class LnProjFn(torch.autograd.Function):
+    """hidden = ln_post(x) @ proj on ALL tokens (clip/model.py:340-346); proj is [d, vw] (no bias)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, proj):
+        b, N, d = x.shape
+        h, mean, rstd, _ = K.layernorm_fwd(x, ln_w.data, ln_b.data, 1e-5)
+        # proj [d, vw]: B(n, k) = proj[k, n]  -> the [vw, d] K-contiguous copy is proj._lpt
+        y = K.gemm(_rows(h), proj._lpt) if proj._lpt is not None else K.gemm(_rows(h), proj._lp, trans_b=True)
+        ctx.save_for_backward(x, h, mean, rstd)
+        ctx.p = (ln_w, ln_b, proj)
+        return y.view(b, N, -1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, mean, rstd = ctx.saved_tensors
+        ln_w, ln_b, proj = ctx.p
+        b, N, d = x.shape
+        dy2 = _rows(dy.contiguous())
+        dh = K.gemm(dy2, proj._lp)                                    # dH = dY @ proj^T : B(n=d, k=vw) = proj[n, k]
+        K.gemm(_rows(h), dy2, trans_a=True, trans_b=True, out=proj._g, accumulate=True)   # dproj[d,vw] = H^T dY
+        _mark(proj)
+        dx = K.layernorm_bwd(dh.view(b, N, d), x, ln_w.data, mean, rstd, ln_w._g, ln_b._g)
+        _mark(ln_w)
+        _mark(ln_b)
+        return dx, None, None, None
+
+
+# --------------------------------------------------------------------------------------- BERT
+class BertEmbedFn(torch.autograd.Function):
+    """BertEmbeddings: word + position + token_type(0) -> LayerNorm(1e-12) (HF BertModel, called at xvlm.py:238)."""
+
+    @staticmethod
+    def forward(ctx, ids, emb, dtype, *params):
+        e = K.bert_embed_fwd(ids.contiguous(), emb.word_embeddings.weight.data, emb.position_embeddings.weight.data,
+                             emb.token_type_embeddings.weight.data, dtype)
+        y, mean, rstd, _ = K.layernorm_fwd(e, emb.LayerNorm.weight.data, emb.LayerNorm.bias.data, emb.eps)
+        ctx.save_for_backward(ids, e, mean, rstd)
+        ctx.emb = emb
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        ids, e, mean, rstd = ctx.saved_tensors
+        emb = ctx.emb
+        de = K.layernorm_bwd(dy.contiguous(), e, emb.LayerNorm.weight.data, mean, rstd, emb.LayerNorm.weight._g,
+                             emb.LayerNorm.bias._g)
+        K.bert_embed_bwd(ids, de, emb.word_embeddings.weight._g, emb.position_embeddings.weight._g,
+                         emb.token_type_embeddings.weight._g, emb.pad_id)
+        for p in (emb.LayerNorm.weight, emb.LayerNorm.bias, emb.word_embeddings.weight,
+                  emb.position_embeddings.weight, emb.token_type_embeddings.weight):
+            _mark(p)
+        return (None, None, None) + (None,) * 5
+
+
+class BertLayerFn(torch.autograd.Function):
+    """One post-LN BERT layer: packed QKV GEMM -> masked attention -> dense + residual -> LN -> GELU FFN + residual -> LN."""
+
+    @staticmethod
+    def forward(ctx, x, kmask, layer, *params):
+        b, L, d = x.shape
+        qkv = lin_fwd(_rows(x), layer._qkv_w, layer._qkv_b).view(b, L, 3 * d)
+        o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask)
+        ao = layer.attention.output
+        s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, residual=_rows(x)).view(b, L, d)
+        x1, mean1, rstd1, _ = K.layernorm_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps)
+        pre = torch.empty(b * L, layer.intermediate.dense.weight.shape[0], device=x.device, dtype=x.dtype)
+        h = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, epilogue=EPI_GELU,
+                    aux_out=pre)
+        s2 = lin_fwd(h, layer.output.dense.weight, layer.output.dense.bias, residual=_rows(x1)).view(b, L, d)
+        x2, mean2, rstd2, _ = K.layernorm_fwd(s2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data,
+                                              layer.eps)
+        ctx.save_for_backward(x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2)
+        ctx.layer = layer
+        return x2
+
+    @staticmethod
+    def backward(ctx, dx2):
+        x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2 = ctx.saved_tensors
+        layer = ctx.layer
+        ao, out = layer.attention.output, layer.output
+        b, L, d = x.shape
+        ds2 = K.layernorm_bwd(dx2.contiguous(), s2, out.LayerNorm.weight.data, mean2, rstd2, out.LayerNorm.weight._g,
+                              out.LayerNorm.bias._g)
+        g2 = _rows(ds2)
+        dpre = lin_dx(g2, out.dense.weight, epilogue=EPI_DGELU, aux=pre)
+        lin_dw(g2, h, out.dense.weight, out.dense.bias)
+        dx1 = lin_dx(dpre, layer.intermediate.dense.weight, residual=g2)          # + residual path of s2 = .. + x1
+        lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
+        ds1 = K.layernorm_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
+                              ao.LayerNorm.bias._g)
+        g1 = _rows(ds1)
+        do = lin_dx(g1, ao.dense.weight).view(b, L, d)
+        lin_dw(g1, _rows(o), ao.dense.weight, ao.dense.bias)
+        dqkv = torch.empty_like(qkv)
+        K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, layer.heads, kmask,
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+        dx = lin_dx(_rows(dqkv), layer._qkv_w, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
+        lin_dw(_rows(dqkv), _rows(x), layer._qkv_w, layer._qkv_b)
+        for p in (out.LayerNorm.weight, out.LayerNorm.bias, ao.LayerNorm.weight, ao.LayerNorm.bias):
+            _mark(p)
+        return (dx, None, None) + (None,) * len(ctx.needs_input_grad[3:])
+
+
+# --------------------------------------------------------------------------------------- caption interaction
+class CrossAttnLayerFn(torch.autograd.Function):
+    """CrossAttentionLayer / SelfAttentionLayer (models/attention.py:24-128), batch-major:
+    a = MHA(tgt, memory, key_padding_mask); y = norm2(tgt + linear2(gelu(linear1(a)))).   (norm1 unused, a NOT
+    residual-added before the FFN - attention.py:47-54.)"""
+
+    @staticmethod
+    def forward(ctx, tgt, memory, kmask, layer, *params):
+        b, Lq, d = tgt.shape
+        Lk = memory.shape[1]
+        mha = layer.multihead_attn
+        wq, wkv = _Slice(mha.in_proj_weight, 0, d), _Slice(mha.in_proj_weight, d, 3 * d)
+        bq, bkv = _Slice(mha.in_proj_bias, 0, d), _Slice(mha.in_proj_bias, d, 3 * d)
+        q = lin_fwd(_rows(tgt), wq, bq).view(b, Lq, d)
+        kv = lin_fwd(_rows(memory), wkv, bkv).view(b, Lk, 2 * d)
+        o, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], layer.heads, kmask)
+        a = lin_fwd(_rows(o), mha.out_proj.weight, mha.out_proj.bias)
+        pre = torch.empty_like(a)
+        h = lin_fwd(a, layer.linear1.weight, layer.linear1.bias, epilogue=EPI_GELU, aux_out=pre)
+        s = lin_fwd(h, layer.linear2.weight, layer.linear2.bias, residual=_rows(tgt)).view(b, Lq, d)
+        y, mean, rstd, _ = K.layernorm_fwd(s, layer.norm2.weight.data, layer.norm2.bias.data, 1e-5)
+        ctx.save_for_backward(tgt, memory, kmask, q, kv, o, lse, a, pre, h, s, mean, rstd)
+        ctx.layer = layer
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        tgt, memory, kmask, q, kv, o, lse, a, pre, h, s, mean, rstd = ctx.saved_tensors
+        layer = ctx.layer
+        mha = layer.multihead_attn
+        b, Lq, d = tgt.shape
+        Lk = memory.shape[1]
+        wq, wkv = _Slice(mha.in_proj_weight, 0, d), _Slice(mha.in_proj_weight, d, 3 * d)
+        bq, bkv = _Slice(mha.in_proj_bias, 0, d), _Slice(mha.in_proj_bias, d, 3 * d)
+        ds = K.layernorm_bwd(dy.contiguous(), s, layer.norm2.weight.data, mean, rstd, layer.norm2.weight._g,
+                             layer.norm2.bias._g)
+        _mark(layer.norm2.weight)
+        _mark(layer.norm2.bias)
+        gs = _rows(ds)
+        dpre = lin_dx(gs, layer.linear2.weight, epilogue=EPI_DGELU, aux=pre)
+        lin_dw(gs, h, layer.linear2.weight, layer.linear2.bias)
+        da = lin_dx(dpre, layer.linear1.weight)
+        lin_dw(dpre, a, layer.linear1.weight, layer.linear1.bias)
+        do = lin_dx(da, mha.out_proj.weight).view(b, Lq, d)
+        lin_dw(da, _rows(o), mha.out_proj.weight, mha.out_proj.bias)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        K.attn_bwd(q, kv[..., :d], kv[..., d:], o, do, lse, layer.heads, kmask, dq=dq, dk=dkv[..., :d],
+                   dv=dkv[..., d:])
+        dtgt = lin_dx(_rows(dq), wq, residual=gs).view(b, Lq, d) if ctx.needs_input_grad[0] else None
+        lin_dw(_rows(dq), _rows(tgt), wq, bq)
+        dmem = lin_dx(_rows(dkv), wkv).view(b, Lk, d) if ctx.needs_input_grad[1] else None
+        lin_dw(_rows(dkv), _rows(memory), wkv, bkv)
+        return (dtgt, dmem, None, None) + (None,) * len(ctx.needs_input_grad[4:])
+
+
+# --------------------------------------------------------------------------------------- losses
+class SimInfoNCEFn(torch.autograd.Function):
+    """get_contrastive_loss's compute (models/xvlm.py:273-292) on already gathered f32 features."""
+
+    @staticmethod
+    def forward(ctx, a, b, temp, idx, both_dirs, tval=None):
+        a, b = a.contiguous(), b.contiguous()
+        if tval is None:
+            tval = float(temp) if temp is not None else 1.0
+        loss, ws = K.sim_infonce_fwd(a, b, idx, tval, both_dirs)
+        ctx.save_for_backward(a, b, ws)
+        ctx.meta = (tval, idx, both_dirs, temp is not None)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b, ws = ctx.saved_tensors
+        tval, idx, both_dirs, has_temp = ctx.meta
+        dtemp = torch.zeros(1, device=a.device, dtype=torch.float32) if has_temp else None
+        da, db = K.sim_infonce_bwd(a, b, idx, tval, ws, float(g), both_dirs, dtemp)
+        return da, db, (dtemp[0] if has_temp else None), None, None, None
+
+
+class CapSimFn(torch.autograd.Function):
+    """get_caption_contrastive_loss (model_retrieval_caption.py:145-152); c [b,n,D] batch-major, t [b,D]."""
+
+    @staticmethod
+    def forward(ctx, c, t, temp, tval=None):
+        c, t = c.contiguous(), t.contiguous()
+        tval = float(temp) if tval is None else tval
+        loss, am, ws = K.capsim_fwd(c, t, tval)
+        ctx.save_for_backward(c, t, am, ws)
+        ctx.tval = tval
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        c, t, am, ws = ctx.saved_tensors
+        dtemp = torch.zeros(1, device=c.device, dtype=torch.float32)
+        dc, dt = K.capsim_bwd(c, t, ctx.tval, am, ws, float(g), dtemp)
+        return dc, dt, dtemp[0], None
+
+
+class DstlFn(torch.autograd.Function):
+    """dstl_loss's compute (model_retrieval_caption.py:100-116) on gathered f32 features; grads to v and t only."""
+
+    @staticmethod
+    def forward(ctx, v, c, s, t, alpha):
+        v, c, s, t = v.contiguous(), c.contiguous(), s.contiguous(), t.contiguous()
+        loss, ws = K.dstl_fwd(v, c, s, t, alpha)
+        ctx.save_for_backward(v, t, ws)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        v, t, ws = ctx.saved_tensors
+        dv, dt = K.dstl_bwd(v, t, ws, float(g))
+        return dv, None, None, dt, None
+
+
+class CvPoolFn(torch.autograd.Function):
+    """mean over tokens of F.normalize(x, dim=1) (the token axis!) - caption_vision_loss in pooled form."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        pooled, inv = K.cvpool_fwd(x)
+        ctx.save_for_backward(x, inv)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dp):
+        x, inv = ctx.saved_tensors
+        return K.cvpool_bwd(x, inv, dp.contiguous())
+
+
+class CapRegFn(torch.autograd.Function):
+    """caption_regularization (model_retrieval_caption.py:65-73); c [b,n,d] batch-major."""
+
+    @staticmethod
+    def forward(ctx, c):
+        c = c.contiguous()
+        ctx.save_for_backward(c)
+        return K.capreg_fwd(c)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (c,) = ctx.saved_tensors
+        return K.capreg_bwd(c, float(g))
