@@ -1,16 +1,446 @@
-// attention_mfma.hip - bf16 / head-size-64 flash attention on MFMA (placeholder until the kernels land:
-// attn_mfma_supported() returns false so every call takes the generic kernels).
+// attention_mfma.hip - bf16, head size 64 flash attention for gfx950 (forward + backward), v_mfma_f32_16x16x32_bf16.
+//
+// Forward  (block = 64 queries of one (batch, head), 4 waves x 16 queries; K/V tiles of 64 keys stream through a
+//           double-buffered LDS image filled by global_load_lds_dwordx4):
+//     S^T = K Q^T      A-role = K rows from LDS (ds_read_b128), B-role = Q fragments held in registers
+//     softmax          the accumulator has the QUERY on the lane (col) and keys in registers + the 4 lane groups, so
+//                      row statistics are 15 in-lane ops + 2 shuffles and every per-query scalar is lane-local
+//     O^T += V^T P^T   A-role = V^T via ds_read_b64_tr_b16 of the row-major V tile, B-role = P straight from the S^T
+//                      accumulator registers (an accumulator tile is the next MFMA's operand when the next product sums
+//                      over its ROW index - no LDS round trip, no lane movement)
+// Backward (deterministic, no atomics; P is recomputed from the saved log-sum-exp):
+//     dkdv kernel: block = 64 keys (wave = 16 keys, dK^T/dV^T in accumulators), sweeps query tiles:
+//                  S = Q K^T, dP = dO V^T (query rows in registers, key on the lane), P, dS, then
+//                  dV^T += dO^T P, dK^T += Q^T dS with dO^T / Q^T by transposed LDS reads of the same tiles
+//     dq kernel:   block = 64 queries, sweeps key tiles: S^T, dP^T, dS^T, dQ^T += K^T dS^T
+// One LDS image per tile serves both the row reads and the transposed reads: 128-byte rows, 16-byte chunk index XOR
+// (row & 7) - conflict-free for ds_read_b128 and ds_read_b64_tr_b16 alike.
+//
+// Replaces nn.MultiheadAttention / BertSelfAttention cores (see include/leccr_hip.h, leccr_attn_*).
 #include "attention.h"
 
 namespace leccr {
-bool attn_mfma_supported(const AttnDims&, int) { return false; }
-int attn_mfma_fwd(const void*, const void*, const void*, void*, float*, const uint8_t*, const AttnDims&, hipStream_t) {
-    set_error("attn_mfma_fwd: not built");
-    return LECCR_EINVAL;
+
+namespace {
+
+constexpr int HD = 64;     // head size
+constexpr int BT = 64;     // rows per tile (queries per block, keys per tile)
+constexpr int TILE_BYTES = BT * HD * 2;   // 8 KiB
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct FP {
+    const bf16_t *q, *k, *v, *o, *dout;
+    bf16_t *out, *dq, *dk, *dv;
+    float* lse;          // fwd: written; bwd: read
+    const float* delta;  // bwd
+    const uint8_t* kmask;
+    int64_t heads, Lq, Lk, ldq, ldk, ldv, ldo;
+    float scale;
+};
+
+// Stage a [64 rows][64 bf16] tile (rows clamped to n_rows-1) from `base` (row stride ld elements) into LDS.
+// LDS image: row r at byte r*128, physical 16-byte chunk = logical chunk ^ (r & 7)  (swizzle on the SOURCE address).
+__device__ __forceinline__ void stage_tile64(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t n_rows,
+                                             unsigned char* lds) {
+    const int tid = threadIdx.x, wave_base = tid & ~63;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int slot = i * 256 + tid;
+        const int row = slot >> 3, pc = slot & 7, lc = pc ^ (row & 7);
+        int64_t r = row0 + row;
+        r = r < n_rows ? r : n_rows - 1;
+        const bf16_t* src = base + r * ld + lc * 8;
+        unsigned char* dst = lds + (size_t)(i * 256 + wave_base) * 16;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
+    }
 }
-int attn_mfma_bwd(const void*, const void*, const void*, const void*, const void*, const float*, const uint8_t*, void*,
-                  void*, void*, float*, const AttnDims&, hipStream_t) {
-    set_error("attn_mfma_bwd: not built");
-    return LECCR_EINVAL;
+
+// Row fragment (A-role or B-role with the row on lane&15): X[row0 + (lane&15)][32*ks + 8*(lane>>4) + 0..7]
+__device__ __forceinline__ bf16x8 frag_rows(const unsigned char* tile, int row0, int ks, int lane) {
+    const int row = row0 + (lane & 15);
+    const int lc = ks * 4 + (lane >> 4);
+    return *reinterpret_cast<const bf16x8*>(tile + row * 128 + ((lc ^ (row & 7)) << 4));
 }
+
+// Transposed fragment: element j of lane (i = lane&15, h = lane>>4) = X[row(h,j)][col0 + i],
+// row(h,j) = 32*ks + 16*(j>>2) + 4*h + (j&3)  - the k order of an accumulator tile used as the other operand.
+__device__ __forceinline__ bf16x8 frag_tr(const unsigned char* tile, int col0, int ks, int lane) {
+    const int i = lane & 15, h = lane >> 4;
+    const int rowA = 32 * ks + 4 * h + (i >> 2);
+    const int rowB = rowA + 16;
+    const int col = col0 + 4 * (i & 3);           // first of the 4 columns this lane addresses
+    const int chunk = col >> 3, inb = (col & 7) * 2;
+    const int offA = rowA * 128 + ((chunk ^ (rowA & 7)) << 4) + inb;
+    const int offB = rowB * 128 + ((chunk ^ (rowB & 7)) << 4) + inb;
+    short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(tile + offA));
+    short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)(tile + offB));
+    short8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// Fragment straight from global memory: X[row][32*ks + 8*(lane>>4) + 0..7] with row = row0 + (lane&15), clamped.
+__device__ __forceinline__ bf16x8 frag_global(const bf16_t* base, int64_t ld, int64_t row0, int64_t n_rows, int ks,
+                                              int lane) {
+    int64_t r = row0 + (lane & 15);
+    r = r < n_rows ? r : n_rows - 1;
+    return *reinterpret_cast<const bf16x8*>(base + r * ld + 32 * ks + 8 * (lane >> 4));
+}
+
+__device__ __forceinline__ bf16x8 pack2(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+    r[0] = (bf16_t)a[0]; r[1] = (bf16_t)a[1]; r[2] = (bf16_t)a[2]; r[3] = (bf16_t)a[3];
+    r[4] = (bf16_t)b[0]; r[5] = (bf16_t)b[1]; r[6] = (bf16_t)b[2]; r[7] = (bf16_t)b[3];
+    return r;
+}
+
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
+
+// --------------------------------------------------------------------------------------------------- forward
+// LDS per stage: K tile | V tile | bias[64] f32
+constexpr int FWD_STAGE = 2 * TILE_BYTES + 256;
+
+__global__ __launch_bounds__(256) void flash_fwd_kernel(FP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
+    const int64_t nqb = (p.Lq + BT - 1) / BT;
+    const int64_t bh = blockIdx.x / nqb, b = bh / p.heads, head = bh % p.heads;
+    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BT;
+    const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
+    const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
+    const bf16_t* Vp = p.v + b * p.Lk * p.ldv + head * HD;
+    const uint8_t* km = p.kmask ? p.kmask + b * p.Lk : nullptr;
+    const float c = p.scale * kLog2e;
+
+    bf16x8 qf[2];
+    qf[0] = frag_global(Q, p.ldq, q0 + wave * 16, p.Lq, 0, lane);
+    qf[1] = frag_global(Q, p.ldq, q0 + wave * 16, p.Lq, 1, lane);
+
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+
+    const int ntiles = (int)((p.Lk + BT - 1) / BT);
+    auto stage = [&](int t) {
+        unsigned char* st = smem + (t & 1) * FWD_STAGE;
+        stage_tile64(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
+        stage_tile64(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
+        if (tid < BT) {
+            const int64_t key = (int64_t)t * BT + tid;
+            const bool ok = key < p.Lk && !(km && km[key]);
+            reinterpret_cast<float*>(st + 2 * TILE_BYTES)[tid] = ok ? 0.f : -INFINITY;
+        }
+    };
+    stage(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* st = smem + (t & 1) * FWD_STAGE;
+        __syncthreads();
+        if (t + 1 < ntiles) stage(t + 1);
+        const unsigned char* kt = st;
+        const unsigned char* vt = st + TILE_BYTES;
+        const float* bias = reinterpret_cast<const float*>(st + 2 * TILE_BYTES);
+        f32x4 s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[j] = MFMA16(frag_rows(kt, j * 16, 0, lane), qf[0], s[j]);
+            s[j] = MFMA16(frag_rows(kt, j * 16, 1, lane), qf[1], s[j]);
+        }
+        // s[j][r] = <k[key = 16j + 4*h4 + r], q[query = lane&15]>
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 bj = *reinterpret_cast<const f32x4*>(bias + j * 16 + 4 * h4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[j][r] = s[j][r] * c + bj[r];
+                mx = fmaxf(mx, s[j][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float msafe = mn == -INFINITY ? 0.f : mn;       // every key so far masked: keep exp2 arguments finite
+        const float alpha = exp2_fast(m - msafe);              // m = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[j][r] = exp2_fast(s[j][r] - msafe);
+                rs += s[j][r];
+            }
+        rs += __shfl_xor(rs, 16, 64);
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] *= alpha;
+        const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            o[nd] = MFMA16(frag_tr(vt, nd * 16, 0, lane), pf0, o[nd]);
+            o[nd] = MFMA16(frag_tr(vt, nd * 16, 1, lane), pf1, o[nd]);
+        }
+    }
+    // o[nd][r] = O^T[d = 16 nd + 4 h4 + r][query = lane&15]
+    const int64_t qi = q0 + wave * 16 + (lane & 15);
+    if (qi < p.Lq) {
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        bf16_t* op = p.out + (b * p.Lq + qi) * p.ldo + head * HD;
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) store4(op + nd * 16 + 4 * h4, o[nd] * inv);
+        if (h4 == 0) p.lse[(b * p.heads + head) * p.Lq + qi] = l > 0.f ? (m + __log2f(l)) * kLn2 : INFINITY;
+    }
+}
+
+// --------------------------------------------------------------------------------------------------- backward: dK, dV
+// LDS per stage: Q tile | dO tile | lse2[64] | delta[64]
+constexpr int DKV_STAGE = 2 * TILE_BYTES + 512;
+
+__global__ __launch_bounds__(256) void flash_dkdv_kernel(FP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
+    const int64_t nkb = (p.Lk + BT - 1) / BT;
+    const int64_t bh = blockIdx.x / nkb, b = bh / p.heads, head = bh % p.heads;
+    const int64_t k0 = (int64_t)(blockIdx.x % nkb) * BT + wave * 16;      // this wave's 16 keys
+    const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
+    const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
+    const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
+    const bf16_t* Vp = p.v + b * p.Lk * p.ldv + head * HD;
+    const float* lse = p.lse + (b * p.heads + head) * p.Lq;
+    const float* dl = p.delta + (b * p.heads + head) * p.Lq;
+    const float c = p.scale * kLog2e;
+
+    bf16x8 kf[2], vf[2];
+    kf[0] = frag_global(Kp, p.ldk, k0, p.Lk, 0, lane);
+    kf[1] = frag_global(Kp, p.ldk, k0, p.Lk, 1, lane);
+    vf[0] = frag_global(Vp, p.ldv, k0, p.Lk, 0, lane);
+    vf[1] = frag_global(Vp, p.ldv, k0, p.Lk, 1, lane);
+    const int64_t key = k0 + (lane & 15);
+    const float kbias = (key < p.Lk && !(p.kmask && p.kmask[b * p.Lk + key])) ? 0.f : -INFINITY;
+
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int ntiles = (int)((p.Lq + BT - 1) / BT);
+    auto stage = [&](int t) {
+        unsigned char* st = smem + (t & 1) * DKV_STAGE;
+        stage_tile64(Q, p.ldq, (int64_t)t * BT, p.Lq, st);
+        stage_tile64(DO, p.ldo, (int64_t)t * BT, p.Lq, st + TILE_BYTES);
+        if (tid < BT) {
+            const int64_t qi = (int64_t)t * BT + tid;
+            float* f = reinterpret_cast<float*>(st + 2 * TILE_BYTES);
+            f[tid] = qi < p.Lq ? lse[qi] * kLog2e : INFINITY;      // +inf -> P = 0 for rows past Lq
+            f[64 + tid] = qi < p.Lq ? dl[qi] : 0.f;
+        }
+    };
+    stage(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* st = smem + (t & 1) * DKV_STAGE;
+        __syncthreads();
+        if (t + 1 < ntiles) stage(t + 1);
+        const unsigned char* qt = st;
+        const unsigned char* dot = st + TILE_BYTES;
+        const float* l2 = reinterpret_cast<const float*>(st + 2 * TILE_BYTES);
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[j] = MFMA16(frag_rows(qt, j * 16, 0, lane), kf[0], s[j]);
+            s[j] = MFMA16(frag_rows(qt, j * 16, 1, lane), kf[1], s[j]);
+            dp[j] = MFMA16(frag_rows(dot, j * 16, 0, lane), vf[0], dp[j]);
+            dp[j] = MFMA16(frag_rows(dot, j * 16, 1, lane), vf[1], dp[j]);
+        }
+        // s[j][r]: query = 16 j + 4 h4 + r, key = lane&15
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 lj = *reinterpret_cast<const f32x4*>(l2 + j * 16 + 4 * h4);
+            const f32x4 dj = *reinterpret_cast<const f32x4*>(l2 + 64 + j * 16 + 4 * h4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = exp2_fast(s[j][r] * c + kbias - lj[r]);
+                s[j][r] = pr;
+                dp[j][r] = pr * (dp[j][r] - dj[r]);
+            }
+        }
+        const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
+        const bf16x8 df0 = pack2(dp[0], dp[1]), df1 = pack2(dp[2], dp[3]);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            dv[nd] = MFMA16(frag_tr(dot, nd * 16, 0, lane), pf0, dv[nd]);
+            dv[nd] = MFMA16(frag_tr(dot, nd * 16, 1, lane), pf1, dv[nd]);
+            dk[nd] = MFMA16(frag_tr(qt, nd * 16, 0, lane), df0, dk[nd]);
+            dk[nd] = MFMA16(frag_tr(qt, nd * 16, 1, lane), df1, dk[nd]);
+        }
+    }
+    if (key < p.Lk) {
+        bf16_t* dkp = p.dk + (b * p.Lk + key) * p.ldk + head * HD;
+        bf16_t* dvp = p.dv + (b * p.Lk + key) * p.ldv + head * HD;
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            store4(dkp + nd * 16 + 4 * h4, dk[nd] * p.scale);
+            store4(dvp + nd * 16 + 4 * h4, dv[nd]);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------- backward: dQ
+__global__ __launch_bounds__(256) void flash_dq_kernel(FP p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
+    const int64_t nqb = (p.Lq + BT - 1) / BT;
+    const int64_t bh = blockIdx.x / nqb, b = bh / p.heads, head = bh % p.heads;
+    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BT + wave * 16;
+    const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
+    const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
+    const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
+    const bf16_t* Vp = p.v + b * p.Lk * p.ldv + head * HD;
+    const uint8_t* km = p.kmask ? p.kmask + b * p.Lk : nullptr;
+    const float c = p.scale * kLog2e;
+
+    bf16x8 qf[2], dof[2];
+    qf[0] = frag_global(Q, p.ldq, q0, p.Lq, 0, lane);
+    qf[1] = frag_global(Q, p.ldq, q0, p.Lq, 1, lane);
+    dof[0] = frag_global(DO, p.ldo, q0, p.Lq, 0, lane);
+    dof[1] = frag_global(DO, p.ldo, q0, p.Lq, 1, lane);
+    const int64_t qi = q0 + (lane & 15);
+    const int64_t qc = qi < p.Lq ? qi : p.Lq - 1;
+    const float lse2 = qi < p.Lq ? p.lse[(b * p.heads + head) * p.Lq + qc] * kLog2e : INFINITY;
+    const float dlt = p.delta[(b * p.heads + head) * p.Lq + qc];
+
+    f32x4 dq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ntiles = (int)((p.Lk + BT - 1) / BT);
+    auto stage = [&](int t) {
+        unsigned char* st = smem + (t & 1) * FWD_STAGE;
+        stage_tile64(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
+        stage_tile64(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
+        if (tid < BT) {
+            const int64_t key = (int64_t)t * BT + tid;
+            const bool ok = key < p.Lk && !(km && km[key]);
+            reinterpret_cast<float*>(st + 2 * TILE_BYTES)[tid] = ok ? 0.f : -INFINITY;
+        }
+    };
+    stage(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const unsigned char* st = smem + (t & 1) * FWD_STAGE;
+        __syncthreads();
+        if (t + 1 < ntiles) stage(t + 1);
+        const unsigned char* kt = st;
+        const unsigned char* vt = st + TILE_BYTES;
+        const float* bias = reinterpret_cast<const float*>(st + 2 * TILE_BYTES);
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            s[j] = MFMA16(frag_rows(kt, j * 16, 0, lane), qf[0], s[j]);
+            s[j] = MFMA16(frag_rows(kt, j * 16, 1, lane), qf[1], s[j]);
+            dp[j] = MFMA16(frag_rows(vt, j * 16, 0, lane), dof[0], dp[j]);
+            dp[j] = MFMA16(frag_rows(vt, j * 16, 1, lane), dof[1], dp[j]);
+        }
+        // s[j][r]: key = 16 j + 4 h4 + r, query = lane&15
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 bj = *reinterpret_cast<const f32x4*>(bias + j * 16 + 4 * h4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pr = exp2_fast(s[j][r] * c + bj[r] - lse2);
+                dp[j][r] = pr * (dp[j][r] - dlt);
+            }
+        }
+        const bf16x8 df0 = pack2(dp[0], dp[1]), df1 = pack2(dp[2], dp[3]);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            dq[nd] = MFMA16(frag_tr(kt, nd * 16, 0, lane), df0, dq[nd]);
+            dq[nd] = MFMA16(frag_tr(kt, nd * 16, 1, lane), df1, dq[nd]);
+        }
+    }
+    if (qi < p.Lq) {
+        bf16_t* dqp = p.dq + (b * p.Lq + qi) * p.ldq + head * HD;
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) store4(dqp + nd * 16 + 4 * h4, dq[nd] * p.scale);
+    }
+}
+
+// delta[b, h, q] = sum_d dO * O
+__global__ __launch_bounds__(256) void flash_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                          float* __restrict__ delta, int64_t heads, int64_t Lq,
+                                                          int64_t ldo, int64_t total) {
+    // 16 lanes per (b, h, q) row: 4 elements each
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    float s = 0.f;
+    if (row < total) {
+        const int64_t qi = row % Lq, head = (row / Lq) % heads, b = row / (Lq * heads);
+        const int64_t off = (b * Lq + qi) * ldo + head * HD + sub * 4;
+        const f32x4 a = load4(o + off), g = load4(dout + off);
+        s = a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+    }
+#pragma unroll
+    for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
+    if (row < total && sub == 0) delta[row] = s;
+}
+
+template <typename KFn>
+static void set_smem(KFn k, int bytes) {
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+bool attn_mfma_supported(const AttnDims& D, int dtype) {
+    return dtype == LECCR_BF16 && D.hd == HD && (D.ldq % 8) == 0 && (D.ldk % 8) == 0 && (D.ldv % 8) == 0 &&
+           (D.ldo % 8) == 0 && D.b * D.heads * cdiv(D.Lq > D.Lk ? D.Lq : D.Lk, BT) < (1ll << 31);
+}
+
+int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+                  const AttnDims& D, hipStream_t st) {
+    if (!(al16(q) && al16(k) && al16(v) && al16(o))) {
+        set_error("attn_fwd(mfma): q/k/v/o must be 16-byte aligned");
+        return LECCR_EALIGN;
+    }
+    FP p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)o; p.lse = lse;
+    p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk; p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv;
+    p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD);
+    static bool once = (set_smem(flash_fwd_kernel, 2 * FWD_STAGE), true);
+    (void)once;
+    dim3 grid((unsigned)(cdiv(D.Lq, BT) * D.b * D.heads));
+    hipLaunchKernelGGL(flash_fwd_kernel, grid, dim3(256), 2 * FWD_STAGE, st, p);
+    return check_launch("flash_fwd");
+}
+
+int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                  const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st) {
+    if (!(al16(q) && al16(k) && al16(v) && al16(o) && al16(dout) && al16(dq) && al16(dk) && al16(dv))) {
+        set_error("attn_bwd(mfma): tensors must be 16-byte aligned");
+        return LECCR_EALIGN;
+    }
+    FP p{};
+    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)o;
+    p.dout = (const bf16_t*)dout; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
+    p.lse = const_cast<float*>(lse); p.delta = delta; p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk;
+    p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv; p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD);
+    static bool once = (set_smem(flash_dkdv_kernel, 2 * DKV_STAGE), set_smem(flash_dq_kernel, 2 * FWD_STAGE), true);
+    (void)once;
+    const int64_t rows = D.b * D.heads * D.Lq;
+    hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, (const bf16_t*)o,
+                       (const bf16_t*)dout, delta, D.heads, D.Lq, D.ldo, rows);
+    hipLaunchKernelGGL(flash_dkdv_kernel, dim3((unsigned)(cdiv(D.Lk, BT) * D.b * D.heads)), dim3(256), 2 * DKV_STAGE, st, p);
+    hipLaunchKernelGGL(flash_dq_kernel, dim3((unsigned)(cdiv(D.Lq, BT) * D.b * D.heads)), dim3(256), 2 * FWD_STAGE, st, p);
+    return check_launch("flash_bwd");
+}
+
 }  // namespace leccr

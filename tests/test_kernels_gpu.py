@@ -150,7 +150,8 @@ def _ref_attn(q, k, v, heads, kmask):
 @pytest.mark.parametrize('b,heads,Lq,Lk,hd,masked', [(2, 2, 17, 17, 64, False), (3, 12, 9, 9, 64, True),
                                                      (2, 8, 4, 70, 64, True), (2, 8, 150, 4, 64, False),
                                                      (2, 4, 33, 33, 8, True), (1, 12, 577, 577, 64, False),
-                                                     (2, 8, 5, 5, 512, True)])
+                                                     (2, 8, 5, 5, 512, True), (2, 12, 200, 200, 64, True),
+                                                     (3, 8, 130, 70, 64, True), (2, 8, 4, 577, 64, False)])
 def test_attention(K, dtype, b, heads, Lq, Lk, hd, masked):
     d = heads * hd
     # packed projection buffers: q|k|v side by side (strided views), as the model uses them
