@@ -67,6 +67,7 @@ def cpu_baseline(args, cfg):
     from leccr_amd.models import RetrievalModel
     from leccr_amd.synthetic import make_batch
     from oracle import leccr_oracle as O
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))      # the GPU box's CPU share for one GPU
     torch.manual_seed(1234)
     c = dict(cfg)
     c['compute_dtype'] = 'fp32'

@@ -43,7 +43,9 @@ struct FP {
 // LDS image: row r at byte r*128, physical 16-byte chunk = logical chunk ^ (r & 7)  (swizzle on the SOURCE address).
 __device__ __forceinline__ void stage_tile64(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t n_rows,
                                              unsigned char* lds) {
-    const int tid = threadIdx.x, wave_base = tid & ~63;
+    const int tid = threadIdx.x;
+    // wave-uniform in an SGPR: otherwise hipcc wraps every global_load_lds in a waterfall loop (M0 must be uniform)
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int slot = i * 256 + tid;

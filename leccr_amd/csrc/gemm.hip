@@ -111,7 +111,8 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ A, const b
                                            unsigned char* lds_stage, int64_t m0, int64_t n0, int64_t k0, int64_t M,
                                            int64_t N, int64_t K, int64_t lda, int64_t ldb) {
     const int tid = threadIdx.x;
-    const int wave_base = tid & ~63;
+    // wave-uniform in an SGPR: otherwise hipcc wraps every global_load_lds in a waterfall loop (M0 must be uniform)
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     unsigned char* ldsA = lds_stage;
     unsigned char* ldsB = lds_stage + BM * BK * 2;
 #pragma unroll
@@ -344,7 +345,18 @@ static bool mfma_ok(const leccr_gemm_params& p) {
 
 using namespace leccr;
 
-namespace leccr { extern bool g_force_generic_attn; }
+namespace leccr {
+extern bool g_force_generic_attn;
+bool gemm256_wanted(const leccr_gemm_params& p);
+bool gemm256_legal(const leccr_gemm_params& p);
+int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
+static int g_gemm_variant = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel where legal
+}
+
+extern "C" int leccr_set_gemm_variant(int v) {
+    g_gemm_variant = v;
+    return LECCR_OK;
+}
 
 extern "C" int leccr_set_force_generic(int on) {
     g_force_generic = on != 0;
@@ -369,6 +381,8 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
     if (mfma_ok(p)) {
         ProfScope prof(p.trans_a == 0 ? PROF_GEMM_NT : PROF_GEMM_TN, flops, st);
+        if ((g_gemm_variant == 2 && gemm256_legal(p)) || (g_gemm_variant == 0 && gemm256_wanted(p)))
+            return gemm256_launch(p, st);
         if (p.trans_a == 0)
             return p.c_dtype == LECCR_F32 ? launch_mfma<0, float>(p, st) : launch_mfma<0, bf16_t>(p, st);
         return p.c_dtype == LECCR_F32 ? launch_mfma<1, float>(p, st) : launch_mfma<1, bf16_t>(p, st);

@@ -1,0 +1,536 @@
+// gemm256.hip - the large-shape bf16 GEMM of the LECCR step: 256x256x64 block tile, 8 waves, persistent, ping-pong.
+//
+// Why (measured on MI355X, random data): the 128x128 kernel in gemm.hip reaches ~940 TFLOP/s at 4096^3 but only
+// ~600 on the step's dominant shapes (M = 147712 tokens, K = 768) and 350-550 on the weight-gradient products: at
+// 64 FLOP per L2->LDS byte and one prologue + epilogue per 12 K-tiles it is fill/drain- and L2-traffic bound.
+// This kernel doubles the tile (128 FLOP/B), keeps a continuous operand stream across output tiles (persistent
+// blocks, the next tile's first K-tiles are in flight during the epilogue) and schedules the two waves that share a
+// SIMD in opposite phases.
+//
+// Structure
+//   * 512 threads = 8 waves = 2 (M) x 4 (N); wave tile 128 x 64 = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16
+//     (128 accumulator VGPRs), issued with swapped roles so a lane ends with 4 consecutive N of one row.
+//   * LDS 128 KiB = 2 slots x {A0, A1, B0, B1} half-tiles of 16 KiB (128 rows x 64 k), filled by
+//     global_load_lds_dwordx4 with the XOR swizzle applied to the SOURCE address (gemm.hip's images).
+//   * A K-tile is 4 quadrant steps per wave: LOAD (ds_reads of the quadrant's fragments + a share of the prefetch)
+//     then COMPUTE (16 MFMAs).  Waves 0-3 (M row 0) and 4-7 (M row 1) pair up on the 4 SIMDs and run ONE SEGMENT
+//     APART: while one wave of a SIMD computes, its partner loads.  Every segment ends in a raw s_barrier.
+//   * Rolling prefetch with counted waits: B half-tiles one K-tile ahead, A half-tiles two K-tiles ahead (an A half is
+//     read by one wave row only and is free after that row's third LOAD), ONE `s_waitcnt vmcnt(4)` per K-tile,
+//     never 0 in the loop.  Timeline (global segments of K-tile t; group 1 runs one segment late):
+//         A0(t) last read seg 4, A1(t) seg 5, B(t) seg 7; B(t+1) issued segs 0-3, A(t+2) issued segs 6-7;
+//         every wave waits vmcnt(4) at the end of its 4th LOAD (segs 6/7) -> A(t+1), B(t+1) landed; the barrier
+//         closing seg 7 publishes them; first reads of t+1 at segs 8/9.
+//   * The K-tile stream runs across the block's output tiles ("items"), so the epilogue of one item overlaps the
+//     partner wave's last COMPUTE and the loads of the next item.
+//
+// TRANS = 0: C = A[M,K] B[N,K]^T (forward and dX).   TRANS = 1: C += A[K,M]^T B[K,N] (weight gradients, split-K with
+// f32 atomics).  Same epilogues as gemm.hip.
+#include "common.h"
+
+namespace leccr {
+namespace g256 {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int HALF = 16384;            // bytes per half-tile
+constexpr int SLOT = 4 * HALF;         // A0 A1 B0 B1
+constexpr int NTHREADS = 512;
+
+struct Args {
+    const bf16_t* A;
+    const bf16_t* B;
+    void* C;
+    int64_t M, N, K, lda, ldb, ldc;
+    const float* bias;
+    const void* aux;
+    int64_t ldaux;
+    void* aux_out;
+    const void* residual;
+    int64_t ldr;
+    float alpha;
+    int accumulate;
+    int tiles_m, tiles_n, splits, nkt;   // nkt = K-tiles per item (uniform; reduction tail reads zeros)
+    int n_items;
+};
+
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page256[512];
+
+__device__ __forceinline__ int tn_swz(int k) { return (k & 3) | (((k >> 3) & 1) << 2); }
+
+// Position of one K-tile of this block's stream.  Everything is wave-uniform (SGPRs).  The four half-tile source
+// pointers are advanced incrementally (one 64-bit add per half per K-tile); integer divisions happen once per item.
+struct Cursor {
+    int j, kt;                 // item ordinal within this block's list, K-tile within the item
+    int split;
+    int64_t m0, n0, k0;        // k0 = first reduction index of this K-tile
+    const bf16_t* p[4];        // source of half A0, A1, B0, B1 at this K-tile (row 0 / column 0 of the half)
+    bool in[4];                // the half is interior in M/N (no row/column tail)
+};
+
+template <int TRANS>
+__device__ __forceinline__ void decode(const Args& a, int first_item, int stride, Cursor& c) {
+    const int item = first_item + c.j * stride;
+    const int tiles = a.tiles_m * a.tiles_n;
+    c.split = item / tiles;
+    const int tile = item - c.split * tiles;
+    const int tm = tile / a.tiles_n;
+    c.m0 = (int64_t)tm * BM;
+    c.n0 = (int64_t)(tile - tm * a.tiles_n) * BN;
+    c.k0 = (int64_t)c.split * a.nkt * BK + (int64_t)c.kt * BK;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const bool isA = w < 2;
+        const int64_t r0 = (isA ? c.m0 : c.n0) + (w & 1) * 128;
+        const int64_t ld = isA ? a.lda : a.ldb;
+        const bf16_t* base = isA ? a.A : a.B;
+        c.in[w] = r0 + 128 <= (isA ? a.M : a.N);
+        c.p[w] = TRANS == 0 ? base + r0 * ld + c.k0 : base + c.k0 * ld + r0;
+    }
+}
+
+// next K-tile of the stream; at the end it stays on the last one (harmless reloads keep the vmcnt counts uniform).
+// FIRST/LAST select which half pointers this cursor actually uses (A prefetch: 0-1, B prefetch: 2-3).
+template <int TRANS, int FIRST, int LAST>
+__device__ __forceinline__ void advance(const Args& a, int first_item, int stride, int n_mine, Cursor& c) {
+    if (c.kt + 1 < a.nkt) {
+        ++c.kt;
+        c.k0 += BK;
+#pragma unroll
+        for (int w = FIRST; w <= LAST; ++w) c.p[w] += TRANS == 0 ? (int64_t)BK : (int64_t)BK * (w < 2 ? a.lda : a.ldb);
+    } else if (c.j + 1 < n_mine) {
+        ++c.j;
+        c.kt = 0;
+        decode<TRANS>(a, first_item, stride, c);
+    }
+}
+
+// Per-thread, loop-invariant parts of the staging addresses (byte offsets inside a half-tile's source window).
+struct StageOff {
+    uint32_t a[2], b[2];     // byte offset of this thread's 16-byte chunk i = 0,1 for the A / B operand
+    int row[2];              // NT: row inside the half (for the M/N tail clamp);  TN: k inside the K-tile
+    int col8[2];             // element column of the chunk (NT: k offset; TN: column inside the half)
+};
+
+template <int TRANS>
+__device__ __forceinline__ StageOff make_stage_off(const Args& a) {
+    StageOff o;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = i * NTHREADS + (int)threadIdx.x;
+        if constexpr (TRANS == 0) {
+            const int row = s >> 3, pc = s & 7, lc = pc ^ (row & 7);
+            o.row[i] = row;
+            o.col8[i] = lc * 8;
+            o.a[i] = (uint32_t)(row * a.lda + lc * 8) * 2u;
+            o.b[i] = (uint32_t)(row * a.ldb + lc * 8) * 2u;
+        } else {
+            const int k = s >> 4, pc = s & 15;
+            const int lc = (((pc >> 1) ^ tn_swz(k)) << 1) | (pc & 1);
+            o.row[i] = k;
+            o.col8[i] = lc * 8;
+            o.a[i] = (uint32_t)(k * a.lda + lc * 8) * 2u;
+            o.b[i] = (uint32_t)(k * a.ldb + lc * 8) * 2u;
+        }
+    }
+    return o;
+}
+
+// Issue one half-tile (2 x 16 B per thread).  which: 0 = A rows/cols 0-127, 1 = A 128-255, 2 = B 0-127, 3 = B 128-255.
+// Interior halves (the common case): uniform 64-bit base (SGPR pair) + 32-bit per-thread byte offset, nothing else.
+template <int TRANS, int WHICH>
+__device__ __forceinline__ void issue_half(const Args& a, const StageOff& so, const Cursor& c, uint32_t lds_slot_off,
+                                           uint32_t wave_off) {
+    constexpr bool isA = WHICH < 2;
+    const bool interior = c.in[WHICH] && (TRANS == 0 || c.k0 + BK <= a.K);
+    const char* ub = reinterpret_cast<const char*>(c.p[WHICH]);
+    const uint32_t dst0 = lds_slot_off + WHICH * HALF + wave_off;       // uniform; the hardware adds lane*16
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const void* src;
+        if (interior) {
+            src = ub + (isA ? so.a[i] : so.b[i]);
+        } else {
+            const bf16_t* base = isA ? a.A : a.B;
+            const int64_t ld = isA ? a.lda : a.ldb;
+            const int64_t rmax = isA ? a.M : a.N;
+            const int64_t r0 = (isA ? c.m0 : c.n0) + (WHICH & 1) * 128;
+            if constexpr (TRANS == 0) {
+                int64_t r = r0 + so.row[i];
+                r = r < rmax ? r : rmax - 1;
+                src = base + r * ld + c.k0 + so.col8[i];
+            } else {
+                const int64_t kk = c.k0 + so.row[i], col = r0 + so.col8[i];
+                src = (kk < a.K && col < rmax) ? (const void*)(base + kk * ld + col) : (const void*)g_zero_page256;
+            }
+        }
+        __builtin_amdgcn_global_load_lds(GLB_PTR(src), (__attribute__((address_space(3))) void*)(size_t)(dst0 + i * NTHREADS * 16),
+                                         16, 0, 0);
+    }
+}
+
+// ---- LDS fragment reads through inline asm.
+// hipcc cannot prove that a ds_read does not alias an in-flight global_load_lds, so a C++ LDS load anywhere in the loop
+// makes SIInsertWaitcnts put `s_waitcnt vmcnt(0)` at the loop head - draining the prefetch every K-tile (seen in the
+// .s).  Reads issued from asm are invisible to that pass; their completion is the explicit WAIT_LDS() before the
+// segment barrier, and SEG_BARRIER's sched_barrier keeps the MFMAs behind it.
+typedef __attribute__((ext_vector_type(4))) int int4_t;
+typedef __attribute__((ext_vector_type(2))) int int2_t;
+
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
+    int4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_tr16x2(uint32_t addr) {      // rows k..k+3 (offset IMM) and k+4..k+7 (IMM + 1024)
+    int2_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(IMM));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(IMM + 1024));
+    int4_t v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// Per-lane address pieces.  NT: va[ks] = row*128 + ((4ks + h) ^ (row & 7))*16 with row = lane & 15 (fragment rows are
+// multiples of 16 apart, so row & 7 == lane & 7 and the fragment row is a pure immediate: + row0*128).
+// TN: base = k*256 + 8*(i & 3), k = 8h + (i >> 2); x = tn_swz(k)*32; a fragment whose 16 columns start at 16*cb is read
+// at ((32*cb) ^ x) + base (+1024: k+4, +8192: k-step 1).
+struct LaneAddr {
+    uint32_t nt[2];
+    uint32_t tbase, tx;
+};
+
+__device__ __forceinline__ LaneAddr make_lane_addr(int lane) {
+    LaneAddr la;
+    const int r = lane & 15, h = lane >> 4;
+    la.nt[0] = r * 128 + (((0 + h) ^ (r & 7)) << 4);
+    la.nt[1] = r * 128 + (((4 + h) ^ (r & 7)) << 4);
+    const int k = 8 * h + (r >> 2);
+    la.tbase = k * 256 + 8 * (r & 3);
+    la.tx = tn_swz(k) * 32;
+    return la;
+}
+
+// fragment (k-step KS) of the 16 rows/columns starting at ROW0 (compile time) of the half-tile at LDS byte `hoff`
+// (uniform) [+ runtime, wave-uniform extra rows folded in by the caller]
+template <int TRANS, int ROW0, int KS>
+__device__ __forceinline__ bf16x8 rd(const LaneAddr& la, uint32_t nt_base0, uint32_t nt_base1, uint32_t t_base,
+                                     uint32_t t_x) {
+    if constexpr (TRANS == 0) {
+        return lds_b128<ROW0 * 128>(KS == 0 ? nt_base0 : nt_base1);
+    } else {
+        const uint32_t addr = ((uint32_t)((ROW0 >> 4) * 32) ^ t_x) + t_base;
+        return lds_tr16x2<KS * 8192>(addr);
+    }
+}
+
+#define SEG_BARRIER()                          \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+#define WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+// FLAGS (compile-time epilogue shape, so the per-item epilogue carries no runtime branches):
+constexpr int F_ATOMIC = 1, F_RES = 2, F_AUXOUT = 4, F_ACCUM = 8;
+
+template <int TRANS, typename TC, int EPI, int FLAGS>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
+    constexpr bool ATOMIC = (FLAGS & F_ATOMIC) != 0;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;          // wr doubles as the ping-pong group
+
+    // persistent item assignment: XCD x (= block id % 8, a speed-only assumption) owns a contiguous range of items
+    const int G = gridDim.x, bid = blockIdx.x;
+    int first_item, stride, n_mine;
+    if ((G & 7) == 0) {
+        const int gx = G >> 3, x = bid & 7, j = bid >> 3;
+        const int q = a.n_items >> 3, r = a.n_items & 7;
+        const int beg = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int cnt = x < r ? q + 1 : q;
+        first_item = beg + j;
+        stride = gx;
+        n_mine = j < cnt ? (cnt - j + gx - 1) / gx : 0;
+    } else {
+        first_item = bid;
+        stride = G;
+        n_mine = bid < a.n_items ? (a.n_items - bid + G - 1) / G : 0;
+    }
+    if (n_mine == 0) return;                           // whole block exits together: no barrier imbalance
+
+    const StageOff so = make_stage_off<TRANS>(a);
+    const uint32_t smem_off = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // wave-uniform LDS destination of this wave's DMA pieces (M0): must be an SGPR or hipcc emits a waterfall loop
+    const uint32_t wave_off = smem_off + (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63) * 16u;
+    Cursor cB, cA;                                     // stream positions t+1 (B prefetch) and t+2 (A prefetch)
+    Cursor cur;
+    cur.j = 0; cur.kt = 0;
+    decode<TRANS>(a, first_item, stride, cur);
+    cB = cur;
+    advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);
+    cA = cB;
+
+    // prologue: A(0), B(0), A(1) then vmcnt(4) (A(1) stays in flight), publish
+    issue_half<TRANS, 0>(a, so, cur, 0, wave_off);
+    issue_half<TRANS, 1>(a, so, cur, 0, wave_off);
+    issue_half<TRANS, 2>(a, so, cur, 0, wave_off);
+    issue_half<TRANS, 3>(a, so, cur, 0, wave_off);
+    issue_half<TRANS, 0>(a, so, cA, SLOT, wave_off);
+    issue_half<TRANS, 1>(a, so, cA, SLOT, wave_off);
+    advance<TRANS, 0, 1>(a, first_item, stride, n_mine, cA);        // cA -> t+2
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    SEG_BARRIER();
+    if (wr == 1) SEG_BARRIER();                        // group 1 runs one segment behind group 0
+
+    const LaneAddr la = make_lane_addr(lane);
+    // wave-uniform pieces of the fragment addresses: this wave's A half, its B half and its 64-row window inside it
+    const uint32_t offA = smem_off + wr * HALF;
+    const uint32_t offB = smem_off + (2 + (wc >> 1)) * HALF;
+    const uint32_t bwin_nt = (wc & 1) * 64 * 128;          // NT: + 64 rows of 128 B
+    const uint32_t bx = la.tx ^ ((wc & 1) * 4 * 32);        // TN: the window is 4 column blocks of 32 B
+    int t = 0;                                         // global K-tile counter of this block's stream (slot parity)
+    for (int j = 0; j < n_mine; ++j) {
+        f32x4 acc[4][8];                               // [ni][mi]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bf16x8 af[4][2], bfv[2][2];
+
+        for (int kt = 0; kt < a.nkt; ++kt, ++t) {
+            const uint32_t so_ = (t & 1) * SLOT;                 // this K-tile's slot; the other one is SLOT - so_
+            const uint32_t a0 = la.nt[0] + offA + so_, a1 = la.nt[1] + offA + so_, at = la.tbase + offA + so_;
+            const uint32_t b0 = la.nt[0] + offB + so_ + bwin_nt, b1 = la.nt[1] + offB + so_ + bwin_nt;
+            const uint32_t bt = la.tbase + offB + so_;
+#define RD_A(ROW0, KS) rd<TRANS, ROW0, KS>(la, a0, a1, at, la.tx)
+#define RD_B(ROW0, KS) rd<TRANS, ROW0, KS>(la, b0, b1, bt, bx)
+
+            // ---- quadrant (mh=0, nh=0): LOAD A rows 0-63 + B rows 0-31 of this wave, issue B0(t+1)
+            bfv[0][0] = RD_B(0, 0); bfv[0][1] = RD_B(0, 1); bfv[1][0] = RD_B(16, 0); bfv[1][1] = RD_B(16, 1);
+            af[0][0] = RD_A(0, 0); af[0][1] = RD_A(0, 1); af[1][0] = RD_A(16, 0); af[1][1] = RD_A(16, 1);
+            af[2][0] = RD_A(32, 0); af[2][1] = RD_A(32, 1); af[3][0] = RD_A(48, 0); af[3][1] = RD_A(48, 1);
+            issue_half<TRANS, 2>(a, so, cB, SLOT - so_, wave_off);
+            WAIT_LDS();
+            SEG_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[ni][ks], af[mi][ks], acc[ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            SEG_BARRIER();
+
+            // ---- quadrant (0, 1): LOAD B rows 32-63, issue B1(t+1)
+            bfv[0][0] = RD_B(32, 0); bfv[0][1] = RD_B(32, 1); bfv[1][0] = RD_B(48, 0); bfv[1][1] = RD_B(48, 1);
+            issue_half<TRANS, 3>(a, so, cB, SLOT - so_, wave_off);
+            WAIT_LDS();
+            SEG_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[2 + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[ni][ks], af[mi][ks], acc[2 + ni][mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            SEG_BARRIER();
+
+            // ---- quadrant (1, 1): LOAD A rows 64-127 (last read of this wave row's A half)
+            af[0][0] = RD_A(64, 0); af[0][1] = RD_A(64, 1); af[1][0] = RD_A(80, 0); af[1][1] = RD_A(80, 1);
+            af[2][0] = RD_A(96, 0); af[2][1] = RD_A(96, 1); af[3][0] = RD_A(112, 0); af[3][1] = RD_A(112, 1);
+            WAIT_LDS();
+            SEG_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[2 + ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[ni][ks], af[mi][ks], acc[2 + ni][4 + mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            SEG_BARRIER();
+
+            // ---- quadrant (1, 0): LOAD B rows 0-31 again, issue A0(t+2), A1(t+2) into THIS slot, the K-tile's one wait
+            bfv[0][0] = RD_B(0, 0); bfv[0][1] = RD_B(0, 1); bfv[1][0] = RD_B(16, 0); bfv[1][1] = RD_B(16, 1);
+            issue_half<TRANS, 0>(a, so, cA, so_, wave_off);
+            issue_half<TRANS, 1>(a, so, cA, so_, wave_off);
+            advance<TRANS, 2, 3>(a, first_item, stride, n_mine, cB);
+            advance<TRANS, 0, 1>(a, first_item, stride, n_mine, cA);
+            WAIT_LDS();
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // retires A(t+1) and B(t+1); A(t+2) stays in flight
+            SEG_BARRIER();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[ni][ks], af[mi][ks], acc[ni][4 + mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            SEG_BARRIER();
+        }
+
+        // ---- epilogue segment of this item (the partner wave is in its last COMPUTE / first LOAD meanwhile)
+        {
+            const int64_t m0 = cur.m0, n0 = cur.n0;
+            const bool interior = m0 + BM <= a.M && n0 + BN <= a.N;
+            const int64_t nb = n0 + wc * 64 + (lane >> 4) * 4;           // this lane's first column; tiles at +16*ni
+            const bool has_bias = a.bias != nullptr && (!ATOMIC || cur.split == 0);
+            // bias is consumed unconditionally right here: a load whose only uses sit behind the tail-tile branches would
+            // stay "pending" in hipcc's scoreboard across the loop back edge and cost a vmcnt(0) in the K loop
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 bvn = {0.f, 0.f, 0.f, 0.f};
+                if (has_bias) {                      // uniform branch; tail columns read a clamped (valid) address
+                    const int64_t nc = nb + ni * 16 < a.N ? nb + ni * 16 : a.N - 4;
+                    bvn = load4(a.bias + nc);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = acc[ni][mi] * a.alpha + bvn;
+            }
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const int64_t m = m0 + wr * 128 + mi * 16 + (lane & 15);
+                if (!interior && m >= a.M) continue;
+                TC* crow = reinterpret_cast<TC*>(a.C) + m * a.ldc + nb;
+                const TC* rrow = reinterpret_cast<const TC*>(a.residual) + m * a.ldr + nb;
+                const TC* xrow = reinterpret_cast<const TC*>(a.aux) + m * a.ldaux + nb;
+                TC* orow = reinterpret_cast<TC*>(a.aux_out) + m * a.ldc + nb;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    if (!interior && nb + ni * 16 >= a.N) continue;
+                    f32x4 v = acc[ni][mi];
+                    if constexpr (ATOMIC) {
+                        float* cp = reinterpret_cast<float*>(crow) + ni * 16;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
+                    } else {
+                        if constexpr ((FLAGS & F_AUXOUT) != 0) store4(orow + ni * 16, v);
+                        if constexpr (EPI != LECCR_EPI_NONE) {
+                            f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+                            if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) ax = load4(xrow + ni * 16);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = apply_epi<EPI>(v[r], ax[r]);
+                        }
+                        if constexpr ((FLAGS & F_RES) != 0) v += load4(rrow + ni * 16);
+                        if constexpr ((FLAGS & F_ACCUM) != 0) v += load4(crow + ni * 16);
+                        store4(crow + ni * 16, v);
+                    }
+                }
+            }
+            // a compiler-visible wait: every ordinary load of the epilogue is retired for hipcc's scoreboard, so the K
+            // loop carries no conservative vmcnt(0) (costs the in-flight A(t+2), once per item, long landed by now)
+            __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) expcnt(7) lgkmcnt(15)
+            SEG_BARRIER();
+        }
+        // move `cur` to the next item
+        if (j + 1 < n_mine) {
+            cur.j = j + 1;
+            cur.kt = 0;
+            decode<TRANS>(a, first_item, stride, cur);
+        }
+    }
+    if (wr == 0) SEG_BARRIER();                        // group 0 waits out group 1's trailing segment
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches still target this block's LDS
+}
+
+}  // namespace g256
+
+// ---------------------------------------------------------------------------------------------------- launch
+// epilogue shapes compiled for the 256 kernel (everything else stays on gemm.hip's 128x128 kernel)
+static int flags_of(const leccr_gemm_params& p) {
+    using namespace g256;
+    return (p.residual ? F_RES : 0) | (p.aux_out ? F_AUXOUT : 0) | (p.accumulate ? F_ACCUM : 0);
+}
+
+static bool shape_compiled(const leccr_gemm_params& p) {
+    using namespace g256;
+    const int f = flags_of(p);
+    if (p.trans_a == 1) return p.c_dtype == LECCR_F32 && p.epilogue == LECCR_EPI_NONE && (f == F_ACCUM);
+    if (p.c_dtype == LECCR_F32) return p.epilogue == LECCR_EPI_NONE && f == 0;
+    switch (p.epilogue) {
+        case LECCR_EPI_NONE: return f == 0 || f == F_RES;
+        case LECCR_EPI_QUICKGELU:
+        case LECCR_EPI_GELU: return f == F_AUXOUT;
+        case LECCR_EPI_DQUICKGELU:
+        case LECCR_EPI_DGELU: return f == 0;
+    }
+    return false;
+}
+
+bool gemm256_legal(const leccr_gemm_params& p) {
+    return p.M >= 256 && p.N >= 256 && p.lda < (1 << 24) && p.ldb < (1 << 24) && shape_compiled(p);
+}
+
+bool gemm256_wanted(const leccr_gemm_params& p) {
+    const int64_t tm = cdiv(p.M, g256::BM), tn = cdiv(p.N, g256::BN);
+    if (!gemm256_legal(p)) return false;
+    if (p.trans_a == 0) return tm * tn >= 192 && p.K >= 128;        // enough tiles to fill 256 CUs
+    return p.K >= 4096;                                                // weight gradients: deep reduction, split-K
+}
+
+template <int TRANS, typename TC, int EPI, int FLAGS>
+static void launch_inst(const g256::Args& a, int grid, hipStream_t st) {
+    using namespace g256;
+    auto kfn = gemm256_kernel<TRANS, TC, EPI, FLAGS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTHREADS), 2 * SLOT, st, a);
+}
+
+int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
+    using namespace g256;
+    Args a{};
+    a.A = (const bf16_t*)p.A; a.B = (const bf16_t*)p.B; a.C = p.C;
+    a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc;
+    a.bias = p.bias; a.aux = p.aux; a.ldaux = p.ldaux; a.aux_out = p.aux_out; a.residual = p.residual; a.ldr = p.ldr;
+    a.alpha = p.alpha; a.accumulate = p.accumulate;
+    a.tiles_m = (int)cdiv(p.M, BM); a.tiles_n = (int)cdiv(p.N, BN);
+    const int64_t ktiles = cdiv(p.K, BK);
+    const int tiles = a.tiles_m * a.tiles_n;
+    int splits = 1;
+    if (p.trans_a == 1) {
+        splits = (int)((256 + tiles - 1) / tiles);                     // about one item per CU
+        if (splits > ktiles / 8) splits = (int)(ktiles / 8);
+        if (splits < 1) splits = 1;
+    }
+    a.splits = splits;
+    a.nkt = (int)cdiv(ktiles, splits);
+    a.n_items = tiles * splits;
+    int grid = a.n_items < 256 ? a.n_items : 256;
+    if (grid >= 8) grid &= ~7;                                         // multiple of 8: the XCD-contiguous item ranges
+    const int f = flags_of(p);
+    if (p.trans_a == 1) {
+        if (splits > 1) launch_inst<1, float, LECCR_EPI_NONE, F_ATOMIC>(a, grid, st);
+        else launch_inst<1, float, LECCR_EPI_NONE, F_ACCUM>(a, grid, st);
+    } else if (p.c_dtype == LECCR_F32) {
+        launch_inst<0, float, LECCR_EPI_NONE, 0>(a, grid, st);
+    } else {
+        switch (p.epilogue) {
+            case LECCR_EPI_NONE:
+                if (f == F_RES) launch_inst<0, bf16_t, LECCR_EPI_NONE, F_RES>(a, grid, st);
+                else launch_inst<0, bf16_t, LECCR_EPI_NONE, 0>(a, grid, st);
+                break;
+            case LECCR_EPI_QUICKGELU: launch_inst<0, bf16_t, LECCR_EPI_QUICKGELU, F_AUXOUT>(a, grid, st); break;
+            case LECCR_EPI_GELU: launch_inst<0, bf16_t, LECCR_EPI_GELU, F_AUXOUT>(a, grid, st); break;
+            case LECCR_EPI_DQUICKGELU: launch_inst<0, bf16_t, LECCR_EPI_DQUICKGELU, 0>(a, grid, st); break;
+            case LECCR_EPI_DGELU: launch_inst<0, bf16_t, LECCR_EPI_DGELU, 0>(a, grid, st); break;
+            default: set_error("gemm256: bad epilogue %d", p.epilogue); return LECCR_EINVAL;
+        }
+    }
+    return check_launch("gemm256");
+}
+
+}  // namespace leccr

@@ -1,0 +1,33 @@
+"""GEMM micro-benchmark on MI355X: TFLOP/s of leccr_gemm on the step's main shapes (random data)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from leccr_amd import kernels as K
+
+dev = 'cuda'
+M = 256 * 577
+SH = [('qkv', 0, M, 2304, 768), ('out', 0, M, 768, 768), ('fc1', 0, M, 3072, 768), ('fc2', 0, M, 768, 3072),
+      ('dW qkv', 1, 2304, 768, M), ('dW out', 1, 768, 768, M), ('dW fc1', 1, 3072, 768, M), ('dW fc2', 1, 768, 3072, M),
+      ('bert qkv', 0, 16384, 2304, 768), ('bert fc1', 0, 16384, 3072, 768), ('bert fc2', 0, 16384, 768, 3072),
+      ('bert dW fc1', 1, 3072, 768, 16384), ('sq 4096', 0, 4096, 4096, 4096), ('sq 8192', 0, 8192, 8192, 8192)]
+reps = int(os.environ.get('REPS', 5))
+from leccr_amd import _lib
+_lib.lib().leccr_set_gemm_variant(int(os.environ.get('VARIANT', 0)))
+print('variant', os.environ.get('VARIANT', 0))
+for name, tn, m, n, k in SH:
+    if tn:
+        a = torch.randn(k, m, device=dev).bfloat16(); b = torch.randn(k, n, device=dev).bfloat16()
+        out = torch.zeros(m, n, device=dev)
+        f = lambda: K.gemm(a, b, trans_a=True, trans_b=True, out=out, accumulate=True)
+    else:
+        a = torch.randn(m, k, device=dev).bfloat16(); b = torch.randn(n, k, device=dev).bfloat16()
+        out = torch.empty(m, n, device=dev, dtype=torch.bfloat16)
+        f = lambda: K.gemm(a, b, out=out)
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    print(f'{name:12s} M={m:6d} N={n:5d} K={k:6d}  {ms*1e3:9.1f} us  {2*m*n*k/ms/1e9:8.1f} TFLOP/s', flush=True)

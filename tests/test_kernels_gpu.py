@@ -401,3 +401,52 @@ def test_rank_of_gt_and_optimizer(K):
     wb = torch.empty(70 * 130, dtype=torch.bfloat16, device=DEV)
     K.cast_bf16(w.to(DEV).reshape(-1), wb)
     assert torch.equal(wb.cpu(), w.reshape(-1).to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------------------------------ 256x256 persistent GEMM
+@pytest.fixture
+def force256():
+    from leccr_amd import _lib
+    _lib.lib().leccr_set_gemm_variant(2)
+    yield
+    _lib.lib().leccr_set_gemm_variant(0)
+
+
+@pytest.mark.parametrize('M,N,K_', [(512, 512, 128), (1154, 768, 768), (2000, 1024, 256), (256 * 40, 2304, 768),
+                                    (300, 260, 64), (256 * 70, 768, 192)])
+@pytest.mark.parametrize('epi', [0, 1])
+def test_gemm256_nt(K, force256, M, N, K_, epi):
+    a, b = _rand((M, K_), torch.bfloat16, 90), _rand((N, K_), torch.bfloat16, 91, 0.05)
+    bias, res = _rand((N,), torch.float32, 92), _rand((M, N), torch.bfloat16, 93)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV) if epi else None
+    out = K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), epilogue=epi, aux_out=pre, residual=res.to(DEV))
+    u = a.double() @ b.double().t() + bias.double()
+    ref = ACT[epi](u) + res.double()
+    e, s = _err(out, ref)
+    assert e <= 1.2e-2 * s, (e, s)
+    if epi:
+        e, s = _err(pre, u)
+        assert e <= 1.2e-2 * s
+
+
+@pytest.mark.parametrize('Kt,M,N', [(577 * 3, 768, 256), (20000, 768, 768), (64 * 300, 256, 512), (5000, 264, 520)])
+def test_gemm256_tn(K, force256, Kt, M, N):
+    dy, x = _rand((Kt, M), torch.bfloat16, 94), _rand((Kt, N), torch.bfloat16, 95)
+    base = _rand((M, N), torch.float32, 96)
+    out = base.clone().to(DEV)
+    K.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True, out=out, accumulate=True)
+    ref = base.double() + dy.double().t() @ x.double()
+    e, s = _err(out, ref)
+    assert e <= 1e-4 * s, (e, s)
+
+
+def test_gemm256_matches_128_bitwise_inputs(K):
+    """Same bf16 inputs through both kernels: results agree to f32 summation-order noise (bf16 output: <= 1 ulp)."""
+    from leccr_amd import _lib
+    a, b = _rand((256 * 9, 384), torch.bfloat16, 97).to(DEV), _rand((768, 384), torch.bfloat16, 98, 0.05).to(DEV)
+    _lib.lib().leccr_set_gemm_variant(1)
+    o1 = K.gemm(a, b, out_dtype=torch.float32)
+    _lib.lib().leccr_set_gemm_variant(2)
+    o2 = K.gemm(a, b, out_dtype=torch.float32)
+    _lib.lib().leccr_set_gemm_variant(0)
+    assert float((o1 - o2).abs().max()) <= 1e-4 * float(o1.abs().max())
