@@ -353,6 +353,12 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
 static int g_gemm_variant = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel where legal
 }
 
+namespace leccr { void gemm256_set_stamps(void* p); }
+extern "C" int leccr_debug_set_stamps(void* p) {      // diagnostic builds (-DLECCR_G256_STAMPS) only
+    leccr::gemm256_set_stamps(p);
+    return LECCR_OK;
+}
+
 extern "C" int leccr_set_gemm_variant(int v) {
     g_gemm_variant = v;
     return LECCR_OK;

@@ -15,12 +15,15 @@
 //   * A K-tile is 4 quadrant steps per wave: LOAD (ds_reads of the quadrant's fragments + a share of the prefetch)
 //     then COMPUTE (16 MFMAs).  Waves 0-3 (M row 0) and 4-7 (M row 1) pair up on the 4 SIMDs and run ONE SEGMENT
 //     APART: while one wave of a SIMD computes, its partner loads.  Every segment ends in a raw s_barrier.
-//   * Rolling prefetch with counted waits: B half-tiles one K-tile ahead, A half-tiles two K-tiles ahead (an A half is
-//     read by one wave row only and is free after that row's third LOAD), ONE `s_waitcnt vmcnt(4)` per K-tile,
-//     never 0 in the loop.  Timeline (global segments of K-tile t; group 1 runs one segment late):
-//         A0(t) last read seg 4, A1(t) seg 5, B(t) seg 7; B(t+1) issued segs 0-3, A(t+2) issued segs 6-7;
-//         every wave waits vmcnt(4) at the end of its 4th LOAD (segs 6/7) -> A(t+1), B(t+1) landed; the barrier
-//         closing seg 7 publishes them; first reads of t+1 at segs 8/9.
+//   * Rolling prefetch TWO K-tiles ahead with counted waits: a wave's LOAD segments read 12 / 4 / 8 / 0 fragments
+//     (the first B fragments stay in registers for the fourth quadrant), so B(t) is free after LOAD 2 and A(t) after
+//     LOAD 3; B(t+2) is issued in LOAD 3 and A(t+2) in LOAD 4 into the slot K-tile t is vacating; ONE
+//     `s_waitcnt vmcnt(8)` per K-tile (end of LOAD 4) retires K-tile t+1, never 0 in the loop.  Timeline (global
+//     segments of K-tile t; group 1 runs one segment late): B(t) last read segs 2/3, A(t) segs 4/5; B(t+2) issued
+//     segs 4/5, A(t+2) segs 6/7; the barrier closing seg 7 publishes t+1; first reads of t+1 at segs 8/9.
+//     (Measured alternative, in-kernel stamps: one DMA piece per segment instead of 4 per LOAD 3/4 was 3 % slower -
+//     a piece issued ahead of a COMPUTE segment's MFMAs delays them; the L1/TA path, ~16-28 B/clk/CU, is what bounds
+//     the K-tile at ~4400 cycles either way.)
 //   * The K-tile stream runs across the block's output tiles ("items"), so the epilogue of one item overlaps the
 //     partner wave's last COMPUTE and the loads of the next item.
 //
@@ -51,6 +54,7 @@ struct Args {
     int accumulate;
     int tiles_m, tiles_n, splits, nkt;   // nkt = K-tiles per item (uniform; reduction tail reads zeros)
     int n_items;
+    unsigned long long* stamps;          // diagnostic builds only (LECCR_G256_STAMPS): per-segment cycle sums
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page256[512];
@@ -137,7 +141,7 @@ __device__ __forceinline__ StageOff make_stage_off(const Args& a) {
 
 // Issue one half-tile (2 x 16 B per thread).  which: 0 = A rows/cols 0-127, 1 = A 128-255, 2 = B 0-127, 3 = B 128-255.
 // Interior halves (the common case): uniform 64-bit base (SGPR pair) + 32-bit per-thread byte offset, nothing else.
-template <int TRANS, int WHICH>
+template <int TRANS, int WHICH, int I0 = 0, int I1 = 2>
 __device__ __forceinline__ void issue_half(const Args& a, const StageOff& so, const Cursor& c, uint32_t lds_slot_off,
                                            uint32_t wave_off) {
     constexpr bool isA = WHICH < 2;
@@ -145,7 +149,7 @@ __device__ __forceinline__ void issue_half(const Args& a, const StageOff& so, co
     const char* ub = reinterpret_cast<const char*>(c.p[WHICH]);
     const uint32_t dst0 = lds_slot_off + WHICH * HALF + wave_off;       // uniform; the hardware adds lane*16
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = I0; i < I1; ++i) {
         const void* src;
         if (interior) {
             src = ub + (isA ? so.a[i] : so.b[i]);
@@ -231,6 +235,18 @@ __device__ __forceinline__ bf16x8 rd(const LaneAddr& la, uint32_t nt_base0, uint
         __builtin_amdgcn_s_barrier();          \
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
+#ifdef LECCR_G256_STAMPS
+#define STAMP(i)                                                            \
+    do {                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
+        stamp_sum[i] += now_ - stamp_last;                                  \
+        stamp_last = now_;                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+    } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 #define WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 // FLAGS (compile-time epilogue shape, so the per-item epilogue carries no runtime branches):
@@ -265,26 +281,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
     const uint32_t smem_off = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // wave-uniform LDS destination of this wave's DMA pieces (M0): must be an SGPR or hipcc emits a waterfall loop
     const uint32_t wave_off = smem_off + (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63) * 16u;
-    Cursor cB, cA;                                     // stream positions t+1 (B prefetch) and t+2 (A prefetch)
+    Cursor cB;                                         // prefetch position: K-tile t+1 in the prologue, then t+2
     Cursor cur;
     cur.j = 0; cur.kt = 0;
     decode<TRANS>(a, first_item, stride, cur);
     cB = cur;
     advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);
-    cA = cB;
 
-    // prologue: A(0), B(0), A(1) then vmcnt(4) (A(1) stays in flight), publish
+    // prologue: K-tiles 0 and 1 (8 + 8 pieces); vmcnt(8) retires tile 0, publish
     issue_half<TRANS, 0>(a, so, cur, 0, wave_off);
     issue_half<TRANS, 1>(a, so, cur, 0, wave_off);
     issue_half<TRANS, 2>(a, so, cur, 0, wave_off);
     issue_half<TRANS, 3>(a, so, cur, 0, wave_off);
-    issue_half<TRANS, 0>(a, so, cA, SLOT, wave_off);
-    issue_half<TRANS, 1>(a, so, cA, SLOT, wave_off);
-    advance<TRANS, 0, 1>(a, first_item, stride, n_mine, cA);        // cA -> t+2
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    issue_half<TRANS, 2>(a, so, cB, SLOT, wave_off);
+    issue_half<TRANS, 3>(a, so, cB, SLOT, wave_off);
+    issue_half<TRANS, 0>(a, so, cB, SLOT, wave_off);
+    issue_half<TRANS, 1>(a, so, cB, SLOT, wave_off);
+    advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);        // cB -> t+2
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     SEG_BARRIER();
     if (wr == 1) SEG_BARRIER();                        // group 1 runs one segment behind group 0
 
+#ifdef LECCR_G256_STAMPS
+    unsigned long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     const LaneAddr la = make_lane_addr(lane);
     // wave-uniform pieces of the fragment addresses: this wave's A half, its B half and its 64-row window inside it
     const uint32_t offA = smem_off + wr * HALF;
@@ -298,85 +319,71 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bf16x8 af[4][2], bfv[2][2];
+        bf16x8 af[4][2], b0v[2][2], b1v[2][2];
+
+#define MMA_QUAD(BF, NI0, MI0)                                                                                       \
+        do {                                                                                                         \
+            __builtin_amdgcn_s_setprio(1);                                                                           \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                         \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                         \
+                acc[NI0 + ni][MI0 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BF[ni][ks], af[mi][ks],            \
+                                                                                  acc[NI0 + ni][MI0 + mi], 0, 0, 0); \
+            __builtin_amdgcn_s_setprio(0);                                                                           \
+        } while (0)
 
         for (int kt = 0; kt < a.nkt; ++kt, ++t) {
-            const uint32_t so_ = (t & 1) * SLOT;                 // this K-tile's slot; the other one is SLOT - so_
+            const uint32_t so_ = (t & 1) * SLOT;                 // this K-tile's slot; K-tile t+1 lives in SLOT - so_
             const uint32_t a0 = la.nt[0] + offA + so_, a1 = la.nt[1] + offA + so_, at = la.tbase + offA + so_;
             const uint32_t b0 = la.nt[0] + offB + so_ + bwin_nt, b1 = la.nt[1] + offB + so_ + bwin_nt;
             const uint32_t bt = la.tbase + offB + so_;
 #define RD_A(ROW0, KS) rd<TRANS, ROW0, KS>(la, a0, a1, at, la.tx)
 #define RD_B(ROW0, KS) rd<TRANS, ROW0, KS>(la, b0, b1, bt, bx)
 
-            // ---- quadrant (mh=0, nh=0): LOAD A rows 0-63 + B rows 0-31 of this wave, issue B0(t+1)
-            bfv[0][0] = RD_B(0, 0); bfv[0][1] = RD_B(0, 1); bfv[1][0] = RD_B(16, 0); bfv[1][1] = RD_B(16, 1);
+            // ---- L1: A rows 0-63 + B rows 0-31 (12 reads, no DMA) | C(0,0)
+            b0v[0][0] = RD_B(0, 0); b0v[0][1] = RD_B(0, 1); b0v[1][0] = RD_B(16, 0); b0v[1][1] = RD_B(16, 1);
             af[0][0] = RD_A(0, 0); af[0][1] = RD_A(0, 1); af[1][0] = RD_A(16, 0); af[1][1] = RD_A(16, 1);
             af[2][0] = RD_A(32, 0); af[2][1] = RD_A(32, 1); af[3][0] = RD_A(48, 0); af[3][1] = RD_A(48, 1);
-            issue_half<TRANS, 2>(a, so, cB, SLOT - so_, wave_off);
+            WAIT_LDS();
+            STAMP(0);
+            SEG_BARRIER();
+            STAMP(1);
+            MMA_QUAD(b0v, 0, 0);
+            STAMP(2);
+            SEG_BARRIER();
+            STAMP(3);
+
+            // ---- L2: B rows 32-63 (4 reads; last read of this wave column's B half) | C(0,1)
+            b1v[0][0] = RD_B(32, 0); b1v[0][1] = RD_B(32, 1); b1v[1][0] = RD_B(48, 0); b1v[1][1] = RD_B(48, 1);
             WAIT_LDS();
             SEG_BARRIER();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[ni][ks], af[mi][ks], acc[ni][mi], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            MMA_QUAD(b1v, 2, 0);
             SEG_BARRIER();
 
-            // ---- quadrant (0, 1): LOAD B rows 32-63, issue B1(t+1)
-            bfv[0][0] = RD_B(32, 0); bfv[0][1] = RD_B(32, 1); bfv[1][0] = RD_B(48, 0); bfv[1][1] = RD_B(48, 1);
-            issue_half<TRANS, 3>(a, so, cB, SLOT - so_, wave_off);
-            WAIT_LDS();
-            SEG_BARRIER();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[2 + ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[ni][ks], af[mi][ks], acc[2 + ni][mi], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            SEG_BARRIER();
-
-            // ---- quadrant (1, 1): LOAD A rows 64-127 (last read of this wave row's A half)
+            // ---- L3: A rows 64-127 (8 reads; last read of this wave row's A half) + issue B(t+2) | C(1,1)
             af[0][0] = RD_A(64, 0); af[0][1] = RD_A(64, 1); af[1][0] = RD_A(80, 0); af[1][1] = RD_A(80, 1);
             af[2][0] = RD_A(96, 0); af[2][1] = RD_A(96, 1); af[3][0] = RD_A(112, 0); af[3][1] = RD_A(112, 1);
+            issue_half<TRANS, 2>(a, so, cB, so_, wave_off);
+            issue_half<TRANS, 3>(a, so, cB, so_, wave_off);
             WAIT_LDS();
+            STAMP(4);
             SEG_BARRIER();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[2 + ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[ni][ks], af[mi][ks], acc[2 + ni][4 + mi], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            STAMP(5);
+            MMA_QUAD(b1v, 2, 4);
             SEG_BARRIER();
+            STAMP(6);
 
-            // ---- quadrant (1, 0): LOAD B rows 0-31 again, issue A0(t+2), A1(t+2) into THIS slot, the K-tile's one wait
-            bfv[0][0] = RD_B(0, 0); bfv[0][1] = RD_B(0, 1); bfv[1][0] = RD_B(16, 0); bfv[1][1] = RD_B(16, 1);
-            issue_half<TRANS, 0>(a, so, cA, so_, wave_off);
-            issue_half<TRANS, 1>(a, so, cA, so_, wave_off);
-            advance<TRANS, 2, 3>(a, first_item, stride, n_mine, cB);
-            advance<TRANS, 0, 1>(a, first_item, stride, n_mine, cA);
-            WAIT_LDS();
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // retires A(t+1) and B(t+1); A(t+2) stays in flight
+            // ---- L4: no reads (B rows 0-31 are still in registers); issue A(t+2); the K-tile's one counted wait | C(1,0)
+            issue_half<TRANS, 0>(a, so, cB, so_, wave_off);
+            issue_half<TRANS, 1>(a, so, cB, so_, wave_off);
+            advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);
+            STAMP(7);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // retires K-tile t+1 (8 loads); t+2 stays in flight
+            STAMP(8);
             SEG_BARRIER();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-                        acc[ni][4 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfv[ni][ks], af[mi][ks], acc[ni][4 + mi], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
+            MMA_QUAD(b0v, 0, 4);
             SEG_BARRIER();
+            STAMP(9);
         }
 
         // ---- epilogue segment of this item (the partner wave is in its last COMPUTE / first LOAD meanwhile)
@@ -431,6 +438,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             // loop carries no conservative vmcnt(0) (costs the in-flight A(t+2), once per item, long landed by now)
             __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) expcnt(7) lgkmcnt(15)
             SEG_BARRIER();
+            STAMP(10);
         }
         // move `cur` to the next item
         if (j + 1 < n_mine) {
@@ -439,6 +447,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             decode<TRANS>(a, first_item, stride, cur);
         }
     }
+#ifdef LECCR_G256_STAMPS
+    if (a.stamps && blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == 4))
+        for (int i = 0; i < 12; ++i) a.stamps[(wave >> 2) * 12 + i] = stamp_sum[i];
+#endif
     if (wr == 0) SEG_BARRIER();                        // group 0 waits out group 1's trailing segment
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches still target this block's LDS
 }
@@ -490,9 +502,13 @@ static void launch_inst(const g256::Args& a, int grid, hipStream_t st) {
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTHREADS), 2 * SLOT, st, a);
 }
 
+static unsigned long long* g_stamps = nullptr;
+void gemm256_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
+
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     using namespace g256;
     Args a{};
+    a.stamps = g_stamps;
     a.A = (const bf16_t*)p.A; a.B = (const bf16_t*)p.B; a.C = p.C;
     a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc;
     a.bias = p.bias; a.aux = p.aux; a.ldaux = p.ldaux; a.aux_out = p.aux_out; a.residual = p.residual; a.ldr = p.ldr;
@@ -502,7 +518,8 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     const int tiles = a.tiles_m * a.tiles_n;
     int splits = 1;
     if (p.trans_a == 1) {
-        splits = (int)((256 + tiles - 1) / tiles);                     // about one item per CU
+        // one item per CU in ONE round: tiles * splits <= 256 (a second, partial round would double the time)
+        splits = tiles >= 256 ? 1 : 256 / tiles;
         if (splits > ktiles / 8) splits = (int)(ktiles / 8);
         if (splits < 1) splits = 1;
     }
