@@ -260,6 +260,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
     const int wr = wave >> 2, wc = wave & 3;          // wr doubles as the ping-pong group
 
     // persistent item assignment: XCD x (= block id % 8, a speed-only assumption) owns a contiguous range of items
+#ifdef LECCR_G256_STAMPS
+    const unsigned long long blk_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int G = gridDim.x, bid = blockIdx.x;
     int first_item, stride, n_mine;
     if ((G & 7) == 0) {
@@ -271,9 +274,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
         stride = gx;
         n_mine = j < cnt ? (cnt - j + gx - 1) / gx : 0;
     } else {
-        first_item = bid;
-        stride = G;
-        n_mine = bid < a.n_items ? (a.n_items - bid + G - 1) / G : 0;
+        // G == n_items (< 256, not a multiple of 8): exactly one item per block, still XCD-contiguous:
+        // XCD x owns blocks {bid % 8 == x} = (G + 7 - x) / 8 of them, and the item range that follows XCD x-1's
+        const int x = bid & 7, jx = bid >> 3;
+        int off = 0;
+        for (int y = 0; y < x; ++y) off += (G + 7 - y) >> 3;
+        first_item = off + jx;
+        stride = 1;
+        n_mine = 1;
     }
     if (n_mine == 0) return;                           // whole block exits together: no barrier imbalance
 
@@ -450,6 +458,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
 #ifdef LECCR_G256_STAMPS
     if (a.stamps && blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == 4))
         for (int i = 0; i < 12; ++i) a.stamps[(wave >> 2) * 12 + i] = stamp_sum[i];
+    if (a.stamps && tid == 0) {      // per-block wall-clock window (100 MHz) and XCC id
+        a.stamps[32 + blockIdx.x * 4 + 0] = blk_t0;
+        a.stamps[32 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[32 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
+        a.stamps[32 + blockIdx.x * 4 + 3] = first_item;
+    }
 #endif
     if (wr == 0) SEG_BARRIER();                        // group 0 waits out group 1's trailing segment
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches still target this block's LDS
@@ -526,8 +540,7 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     a.splits = splits;
     a.nkt = (int)cdiv(ktiles, splits);
     a.n_items = tiles * splits;
-    int grid = a.n_items < 256 ? a.n_items : 256;
-    if (grid >= 8) grid &= ~7;                                         // multiple of 8: the XCD-contiguous item ranges
+    const int grid = a.n_items < 256 ? a.n_items : 256;              // <= 256: one item per block (any count)
     const int f = flags_of(p);
     if (p.trans_a == 1) {
         if (splits > 1) launch_inst<1, float, LECCR_EPI_NONE, F_ATOMIC>(a, grid, st);
