@@ -1,0 +1,83 @@
+"""Evaluation side of the path: evaluation_coarse and itm_eval with the reference's signatures
+(image_Retrieval_caption.py:83-163, 261-317), the score matrix and the ranking computed on the GPU.
+
+itm_eval replaces the host loop of per-row `np.argsort(score)[::-1]` + `np.where(inds == gt)` with one launch of
+leccr_rank_of_gt (rank = number of strictly larger scores in the row), which is the same integer for tie-free rows, and
+returns the same 13-key dict, bit for bit.
+"""
+import time
+import datetime
+
+import numpy as np
+import torch
+
+from . import kernels as K
+
+
+def _ranks(scores, gt_lists, device):
+    s = torch.as_tensor(np.asarray(scores) if not torch.is_tensor(scores) else scores, dtype=torch.float32)
+    s = s.to(device).contiguous()
+    per = max(len(g) for g in gt_lists)
+    gt = torch.full((s.shape[0], per), -1, dtype=torch.int32)
+    for i, g in enumerate(gt_lists):
+        gt[i, :len(g)] = torch.as_tensor(list(g), dtype=torch.int32)
+    return K.rank_of_gt(s, gt.to(device)).cpu().numpy().astype(np.float64)
+
+
+@torch.no_grad()
+def itm_eval(scores_i2t, scores_t2i, txt2img, img2txt, device='cuda'):
+    """image_Retrieval_caption.py:261-317.  img2txt: {image index: [text indices]}, txt2img: {text index: image index}."""
+    n_img, n_txt = (scores_i2t.shape[0], scores_t2i.shape[0])
+    ranks = _ranks(scores_i2t, [img2txt[i] for i in range(n_img)], device)
+    tr1 = 100.0 * len(np.where(ranks < 1)[0]) / len(ranks)
+    tr5 = 100.0 * len(np.where(ranks < 5)[0]) / len(ranks)
+    tr10 = 100.0 * len(np.where(ranks < 10)[0]) / len(ranks)
+    ranks = _ranks(scores_t2i, [[txt2img[t]] for t in range(n_txt)], device)
+    ir1 = 100.0 * len(np.where(ranks < 1)[0]) / len(ranks)
+    ir5 = 100.0 * len(np.where(ranks < 5)[0]) / len(ranks)
+    ir10 = 100.0 * len(np.where(ranks < 10)[0]) / len(ranks)
+    tr_mean = (tr1 + tr5 + tr10) / 3
+    ir_mean = (ir1 + ir5 + ir10) / 3
+    r_mean = (tr_mean + ir_mean) / 2
+    txt_sumr = tr1 + tr5 + tr10
+    img_sumr = ir1 + ir5 + ir10
+    sumr_avg = np.round((txt_sumr + img_sumr) / 6, 2)
+    return {'txt_r1': tr1, 'txt_r5': tr5, 'txt_r10': tr10, 'txt_r_mean': tr_mean, 'txt_sum_r': txt_sumr,
+            'img_r1': ir1, 'img_r5': ir5, 'img_r10': ir10, 'img_r_mean': ir_mean, 'r_mean': r_mean,
+            'img_sumr': img_sumr, 'sumr_avg': sumr_avg, 'sumr_sum': (txt_sumr + img_sumr)}
+
+
+@torch.no_grad()
+def evaluation_coarse(model, data_loader, tokenizer, device, config):
+    """image_Retrieval_caption.py:83-163: text features in chunks of batch_size_test_text, image features through the
+    caption interaction, score = image_embeds @ text_embeds^T (one HIP GEMM, f32).  Returns (i2t, t2i) numpy arrays.
+    The reference's all_reduce of the (already complete) score matrix only scales it by W - dropped: ranking-invariant."""
+    model.eval()
+    print('Computing features for evaluation...')
+    start_time = time.time()
+    texts = data_loader.dataset.text
+    num_text = len(texts)
+    text_bs = config['batch_size_test_text']
+    text_embeds = []
+    for i in range(0, num_text, text_bs):
+        text = texts[i: min(num_text, i + text_bs)]
+        ti = tokenizer(text, padding='max_length', truncation=True, max_length=config['max_tokens'],
+                       return_tensors='pt').to(device)
+        text_embeds.append(model.get_features(text_embeds=model.get_text_embeds(ti.input_ids, ti.attention_mask)))
+    text_embeds = torch.cat(text_embeds, dim=0)
+    image_embeds = []
+    for image, generated_captions, img_id in data_loader:
+        image = image.to(device)
+        image_feat, _ = model.get_vision_embeds(image)
+        ci = tokenizer(generated_captions, padding='max_length', truncation=True, max_length=config['max_tokens'],
+                       return_tensors='pt').to(device)
+        caption_embed = model.get_caption_embeds(ci.input_ids, ci.attention_mask)
+        key_padding_mask = ~ci.attention_mask.bool()
+        image_feat, _, _ = model.interaction_with_caption(image_embeds=image_feat, caption_embeds=caption_embed,
+                                                          key_padding_mask=key_padding_mask)
+        image_embeds.append(model.get_features(image_embeds=image_feat.transpose(0, 1).contiguous()))
+    image_embeds = torch.cat(image_embeds, dim=0)
+    score_matrix_i2t = K.gemm(image_embeds.float().contiguous(), text_embeds.float().contiguous())
+    score_matrix_t2i = score_matrix_i2t.t().contiguous()
+    print('Evaluation time {}'.format(str(datetime.timedelta(seconds=int(time.time() - start_time)))))
+    return score_matrix_i2t.cpu().numpy(), score_matrix_t2i.cpu().numpy()

@@ -26,7 +26,9 @@ class AllGather(torch.autograd.Function):
     def forward(ctx, tensor, rank, world_size):
         tensor = tensor.contiguous()
         out = torch.empty((world_size,) + tuple(tensor.shape), device=tensor.device, dtype=tensor.dtype)
-        dist.all_gather_into_tensor(out.view(-1), tensor.view(-1)) if tensor.is_cuda else \
+        if dist.get_backend() == 'nccl':         # RCCL: one flat all-gather straight into the output
+            dist.all_gather_into_tensor(out.view(-1), tensor.view(-1))
+        else:                                    # gloo (CPU tests, single-GPU rehearsal)
             dist.all_gather(list(out.unbind(0)), tensor)
         ctx.rank, ctx.batch_size = rank, tensor.shape[0]
         return out.view((world_size * tensor.shape[0],) + tuple(tensor.shape[1:]))

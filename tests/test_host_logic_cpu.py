@@ -1,0 +1,125 @@
+"""Host-side logic that needs no GPU: reference-compatible module tree / state_dict keys, optimizer grouping rule,
+LR schedule, synthetic batches, AllGather autograd semantics and gradient averaging under 2-rank gloo."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.helpers import load_npz
+
+TINY = {'embed_dim': 16, 'temp': 0.07, 'use_one_cl_proj_only': False, 'caption_encoder_name': 'mbert',
+        'num_queries': 4, 'caption_ca_layer': 2, 'caption_interaction_layer': 2, 'weight_reg_loss': 0.01,
+        'weight_caption_loss': 0.01, 'weight_dstl_loss': 0.5, 'weight_cv_loss': 0.01,
+        'clip_geometry': dict(embed_dim=32, image_resolution=64, vision_layers=2, vision_width=64,
+                              vision_patch_size=16, context_length=8, vocab_size=32, transformer_width=64,
+                              transformer_heads=1, transformer_layers=1),
+        'text_config': dict(vocab_size=100, hidden_size=64, num_hidden_layers=2, num_attention_heads=2,
+                            intermediate_size=128, max_position_embeddings=40)}
+
+
+def _model():
+    from leccr_amd.models import RetrievalModel
+    m = RetrievalModel(dict(TINY))
+    m.init_caption_encoder()
+    return m
+
+
+def test_state_dict_keys_and_shapes_match_the_reference_fixture():
+    z = load_npz('model_tiny_w1.npz')
+    sd = _model().state_dict()
+    ref = {k[2:]: v.shape for k, v in z.items() if k.startswith('w/')}
+    assert set(ref) <= set(sd)
+    for k, shp in ref.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+    extra = [k for k in sd if k not in ref and not k.startswith('caption_encoder.')]
+    assert not extra, extra[:5]
+    # the aliased caption encoder appears under both prefixes, as in the reference (model_retrieval_caption.py:35)
+    assert 'caption_encoder.embeddings.word_embeddings.weight' in sd
+
+
+def test_unused_parameters_are_the_references():
+    from leccr_amd.models.xvlm import is_unused_parameter
+    names = [n for n, _ in _model().named_parameters()]
+    unused = {n for n in names if is_unused_parameter(n)}
+    z = load_npz('model_tiny_w1.npz')
+    no_grad_in_reference = {k[2:] for k in z if k.startswith('w/')} - {k[2:] for k in z if k.startswith('g/')}
+    no_grad_in_reference = {n for n in no_grad_in_reference if n in names}
+    assert unused == no_grad_in_reference, sorted(unused ^ no_grad_in_reference)[:6]
+
+
+def test_forward_on_cpu_fails_loudly():
+    m = _model()
+    with pytest.raises(RuntimeError, match='MI355X'):
+        m.get_vision_embeds(torch.zeros(1, 3, 64, 64))
+
+
+def test_decay_rule_matches_optim_py():
+    from leccr_amd.optim import decay_of_factory
+    d = decay_of_factory(0.01)
+    assert d('text_encoder.encoder.layer.0.output.LayerNorm.weight', None) == 0.0
+    assert d('crossattn.layers.0.norm2.weight', None) == 0.0
+    assert d('vision_proj.bias', None) == 0.0
+    assert d('clip_encoder.visual.ln_pre.weight', None) == 0.01        # 'ln_pre.weight' matches no no-decay substring
+    assert d('temp', None) == 0.01 and d('queries', None) == 0.01
+
+
+def test_scheduler_is_linear_warmup_then_decay():
+    from leccr_amd.scheduler import create_scheduler
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1.0)
+    sched = create_scheduler(dict(sched='linear', epochs=2, step_per_epoch=10, num_warmup_steps=0.1), opt)
+    lrs = []
+    for _ in range(20):
+        lrs.append(opt.param_groups[0]['lr'])
+        opt.step()
+        sched.step()
+    assert lrs[0] == 0.0 and lrs[1] == 0.5 and lrs[2] == 1.0
+    assert abs(lrs[11] - (20 - 11) / 18) < 1e-12 and lrs[-1] > 0
+
+
+def test_synthetic_batch_contract():
+    from leccr_amd.synthetic import CLS, SEP, make_batch
+    b = make_batch(32, rank=1)
+    assert b['image'].shape == (32, 3, 384, 384) and b['image'].dtype == torch.float32
+    for enc, L in ((b['text'][0], 32), (b['text'][1], 32), (b['captions'], 64)):
+        ids, m = enc.input_ids, enc.attention_mask
+        assert ids.shape == (32, L) and ids.dtype == torch.int64
+        assert (ids[:, 0] == CLS).all() and ((ids == SEP).sum(1) == 1).all()
+        assert ((ids == 0) == (m == 0)).all() and m[:, 0].all()
+    assert b['idx'][15] == b['idx'][14] and b['idx'][0] == 32             # 1-in-16 duplicates, rank offset
+    assert torch.equal(make_batch(4)['image'], make_batch(4)['image'])    # seeded
+
+
+def _gather_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from leccr_amd.models.xvlm import allgather, gather_rows
+    from leccr_amd.parallel import attach_grad_sync
+    x = (torch.arange(6, dtype=torch.float32).view(3, 2) + 10 * rank).requires_grad_(True)
+    g = allgather(x, rank, world)
+    w = torch.arange(12, dtype=torch.float32).view(6, 2)
+    (g * w).sum().backward()
+    ok = torch.equal(g.detach()[3 * rank:3 * rank + 3], x.detach()) and g.shape == (6, 2)
+    ok &= torch.equal(x.grad, w[3 * rank:3 * rank + 3])                  # ONLY the local slice (xvlm.py:62-67)
+    ok &= gather_rows(torch.tensor([[rank]])).view(-1).tolist() == [0, 1]
+
+    class FakeOpt:                                                       # what attach_grad_sync needs
+        class arena:
+            grad = torch.full((10,), float(rank + 1))
+        grad_sync, grad_scale = None, 1.0
+    opt = attach_grad_sync(FakeOpt)
+    opt.grad_sync()
+    ok &= torch.allclose(FakeOpt.arena.grad * opt.grad_scale, torch.full((10,), 1.5))   # mean over the 2 ranks
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_and_grad_sync_two_ranks_gloo():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_worker, args=(2, 29641, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]
