@@ -38,6 +38,7 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 16384;            // bytes per half-tile
 constexpr int SLOT = 4 * HALF;         // A0 A1 B0 B1
 constexpr int NTHREADS = 512;
+constexpr int LDS_BYTES = 2 * SLOT + 8 * (8 * 68 * 4);      // operand slots + per-wave epilogue staging (8 rows x 68 f32)
 
 struct Args {
     const bf16_t* A;
@@ -412,6 +413,59 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = acc[ni][mi] * a.alpha + bvn;
             }
+            if constexpr (sizeof(TC) == 2 && !ATOMIC) {
+                // bf16 output: transpose each 16 x 64 accumulator strip through a wave-private LDS buffer (8 rows at a
+                // time) so that a lane owns 8 CONSECUTIVE columns of one row: every global access of the epilogue
+                // (C, aux, aux_out, residual) is 16 bytes per lane and a wave instruction covers 8 full 128-byte rows,
+                // instead of 8-byte pieces scattered over 16 rows (the store tail was issue-bound: 15-17 % of a
+                // K = 768 item, in-kernel stamps).
+                float* stg = reinterpret_cast<float*>(smem + 2 * SLOT) + wave * (8 * 68);
+                const int rrow = lane >> 3, rcol = (lane & 7) * 8;             // read side: row 0-7, 8 columns
+                const int64_t ncol = n0 + wc * 64 + rcol;
+                const bool col_ok = interior || ncol < a.N;                    // N % 8 == 0 (dispatcher)
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+                    for (int hp = 0; hp < 2; ++hp) {
+                        if (((lane & 15) >> 3) == hp) {
+#pragma unroll
+                            for (int ni = 0; ni < 4; ++ni)
+                                *reinterpret_cast<f32x4*>(stg + (lane & 7) * 68 + ni * 16 + (lane >> 4) * 4) = acc[ni][mi];
+                        }
+                        f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rrow * 68 + rcol);
+                        f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rrow * 68 + rcol + 4);
+                        const int64_t m = m0 + wr * 128 + mi * 16 + hp * 8 + rrow;
+                        if (!(col_ok && (interior || m < a.M))) continue;
+                        bf16_t* crow = reinterpret_cast<bf16_t*>(a.C) + m * a.ldc + ncol;
+                        if constexpr ((FLAGS & F_AUXOUT) != 0) {
+                            bf16_t* orow = reinterpret_cast<bf16_t*>(a.aux_out) + m * a.ldc + ncol;
+                            bf16x8 pv;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { pv[r] = (bf16_t)v0[r]; pv[4 + r] = (bf16_t)v1[r]; }
+                            *reinterpret_cast<bf16x8*>(orow) = pv;
+                        }
+                        if constexpr (EPI != LECCR_EPI_NONE) {
+                            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+                            if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) {
+                                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.aux) + m * a.ldaux + ncol);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { x0[r] = (float)xv[r]; x1[r] = (float)xv[4 + r]; }
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { v0[r] = apply_epi<EPI>(v0[r], x0[r]); v1[r] = apply_epi<EPI>(v1[r], x1[r]); }
+                        }
+                        if constexpr ((FLAGS & F_RES) != 0) {
+                            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.residual) + m * a.ldr + ncol);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { v0[r] += (float)rv[r]; v1[r] += (float)rv[4 + r]; }
+                        }
+                        bf16x8 ov;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { ov[r] = (bf16_t)v0[r]; ov[4 + r] = (bf16_t)v1[r]; }
+                        *reinterpret_cast<bf16x8*>(crow) = ov;
+                    }
+                }
+            } else {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 const int64_t m = m0 + wr * 128 + mi * 16 + (lane & 15);
@@ -441,6 +495,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                         store4(crow + ni * 16, v);
                     }
                 }
+            }
             }
             // a compiler-visible wait: every ordinary load of the epilogue is retired for hipcc's scoreboard, so the K
             // loop carries no conservative vmcnt(0) (costs the in-flight A(t+2), once per item, long landed by now)
@@ -494,7 +549,8 @@ static bool shape_compiled(const leccr_gemm_params& p) {
 }
 
 bool gemm256_legal(const leccr_gemm_params& p) {
-    return p.M >= 256 && p.N >= 256 && p.lda < (1 << 24) && p.ldb < (1 << 24) && shape_compiled(p);
+    return p.M >= 256 && p.N >= 256 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.ldr & 7) == 0 && (p.ldaux & 7) == 0 &&
+           p.lda < (1 << 24) && p.ldb < (1 << 24) && shape_compiled(p);
 }
 
 bool gemm256_wanted(const leccr_gemm_params& p) {
@@ -510,10 +566,10 @@ static void launch_inst(const g256::Args& a, int grid, hipStream_t st) {
     auto kfn = gemm256_kernel<TRANS, TC, EPI, FLAGS>;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SLOT);
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTHREADS), 2 * SLOT, st, a);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTHREADS), LDS_BYTES, st, a);
 }
 
 static unsigned long long* g_stamps = nullptr;
