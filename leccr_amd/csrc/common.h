@@ -107,16 +107,35 @@ __device__ __forceinline__ float block_min(float v, float* sh) {
     return r;
 }
 
-// activations (clip/model.py:166-168 QuickGELU; exact erf GELU) and their derivatives
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+// activations (clip/model.py:166-168 QuickGELU; erf GELU of attention.py:16-17 / HF BERT) and their derivatives.
+// Epilogue-hot (128 evaluations per lane per 256x256 output tile): hardware exp2/rcp instead of libm expf / IEEE
+// division, and erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far inside the f32 parity tolerance) whose
+// exp(-x^2/2) factor is shared with the Gaussian pdf the GELU derivative needs.
+__device__ __forceinline__ float fast_sigmoid(float z) {      // 1 / (1 + e^-z)
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+__device__ __forceinline__ float quick_gelu(float x) { return x * fast_sigmoid(1.702f * x); }
 __device__ __forceinline__ float dquick_gelu(float x) {
-    const float s = 1.f / (1.f + __expf(-1.702f * x));
+    const float s = fast_sigmoid(1.702f * x);
     return s * (1.f + 1.702f * x * (1.f - s));
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// returns erf(x / sqrt 2) and e = exp(-x^2 / 2)
+__device__ __forceinline__ float erf_half(float x, float& e) {
+    const float ax = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.f - poly * e;
+    return x < 0.f ? -r : r;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float e;
+    return 0.5f * x * (1.f + erf_half(x, e));
+}
 __device__ __forceinline__ float dgelu_erf(float x) {
-    const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
-    return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float e;
+    const float cdf = 0.5f * (1.f + erf_half(x, e));
+    return cdf + x * 0.3989422804014327f * e;
 }
 
 template <int EPI> __device__ __forceinline__ float apply_epi(float v, float aux) {
