@@ -48,7 +48,7 @@ def build_model(args, device):
     torch.manual_seed(1234)                      # identical weights on every rank (DDP broadcasts rank 0's)
     model = RetrievalModel(cfg)
     model.init_caption_encoder()
-    return model.to(device), cfg
+    return model.to(device).train(), cfg
 
 
 def train_step(model, batch, opt, sched):
@@ -150,7 +150,7 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'Multi30K en-de shaped, {args.clip}@384 + mBERT, {args.dtype}, batch {args.batch}/GPU '
-                                   f'(global {G}), L_t=32, L_c=64, full train step (fwd+bwd+all-gather+all-reduce+AdamW)',
+                                   f'(global {G}), L_t=32, L_c=64, train mode (dropout 0.1 on), full step (fwd+bwd+all-gather+all-reduce+AdamW)',
                        'global_batch': G, 'parallelism': f'dp{world}',
                        'step_tflops_algorithmic': round(F_PAIR_GFLOP * value / 1e3, 1) if args.clip == 'ViT-B/16' else None,
                        'losses': [round(float(l), 4) for l in losses]},

@@ -103,15 +103,19 @@ int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, co
  * lse [b, heads, Lq] f32 = log-sum-exp of the scaled scores (saved for backward).
  * A row whose keys are all masked returns zeros (the reference would return NaN; never happens on the path:
  * [CLS] is always unmasked).
+ * Dropout on the attention probabilities (nn.MultiheadAttention(dropout=0.1) at attention.py:27,90; HF
+ * attention_probs_dropout_prob): drop_p in [0,1), keep(b,h,q,k) = hash(seed, ((b*heads+h)*Lq+q)*Lk+k) >= drop_p*2^32,
+ * kept probabilities scaled by 1/(1-drop_p) AFTER the softmax normalisation (the row sum uses the undropped values);
+ * the backward regenerates the mask from the same seed.  drop_p = 0 disables it.
  */
 int leccr_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                    int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
-                   int64_t ldv, int64_t ldo, int dtype, void* stream);
+                   int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream);
 /* dq/dk/dv have the same strides as q/k/v.  delta [b, heads, Lq] f32 is workspace (rowsum(dO*O)). */
 int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, int64_t b, int64_t heads,
                    int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                   int dtype, void* stream);
+                   int dtype, float drop_p, uint64_t seed, void* stream);
 
 /* ---- ViT input stage --------------------------------------------------------------------------------------
  * patchify: image [b,3,R,R] f32 NCHW -> patches [b*g*g, Kp] (T), g = R/p, column order (c, py, px) = the
@@ -206,6 +210,9 @@ int leccr_adamw(float* p, const float* g, float* m, float* v, int64_t n, const i
 int leccr_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int leccr_transpose_cast(const float* src, void* dst, int64_t R, int64_t C, int dtype, void* stream);
 int leccr_axpy(const void* x, void* y, float a, int64_t n, int dtype, void* stream);   /* y += a*x */
+/* Elementwise dropout y[i] = keep(seed, i) ? x[i] / (1-p) : 0 (nn.Dropout at attention.py:29-37,92-100; HF
+ * hidden_dropout_prob).  The same call on the incoming gradient is the backward.  y may alias x. */
+int leccr_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

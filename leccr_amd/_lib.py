@@ -34,9 +34,9 @@ _SIGS = {
     'leccr_gemm': ([C.POINTER(GemmParams), vp], C.c_int),
     'leccr_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, vp], C.c_int),
     'leccr_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),
-    'leccr_attn_fwd': ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, vp], C.c_int),
+    'leccr_attn_fwd': ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, f32, C.c_uint64, vp], C.c_int),
     'leccr_attn_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64,
-                        C.c_int, vp], C.c_int),
+                        C.c_int, f32, C.c_uint64, vp], C.c_int),
     'leccr_patchify': ([vp, vp, i64, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_vit_assemble_fwd': ([vp, vp, vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_vit_assemble_bwd': ([vp, vp, vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),
@@ -60,6 +60,7 @@ _SIGS = {
     'leccr_cast_bf16': ([vp, vp, i64, vp], C.c_int),
     'leccr_transpose_cast': ([vp, vp, i64, i64, C.c_int, vp], C.c_int),
     'leccr_axpy': ([vp, vp, f32, i64, C.c_int, vp], C.c_int),
+    'leccr_dropout': ([vp, vp, i64, f32, C.c_uint64, C.c_int, vp], C.c_int),
 }
 
 _lib = None

@@ -6,6 +6,8 @@ namespace leccr {
 
 struct AttnDims {
     int64_t b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo;
+    DropCfg drop;       // attention-probability dropout (thr == 0: off)
+    bool dropout;
 };
 
 template <typename T>

@@ -19,9 +19,11 @@ using namespace leccr;
 
 extern "C" int leccr_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                               int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
-                              int64_t ldv, int64_t ldo, int dtype, void* stream) {
+                              int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream) {
     LECCR_REQUIRE(q && k && v && o && lse, LECCR_EINVAL, "attn_fwd: null pointer");
-    const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo};
+    LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_fwd: drop_p must be in [0,1)");
+    LECCR_REQUIRE(b * heads * Lq * Lk < (1ll << 32) || drop_p == 0.f, LECCR_EINVAL, "attn_fwd: dropout index space exceeds 2^32");
+    const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
     if (int rc = check_dims("attn_fwd", D, dtype)) return rc;
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
@@ -34,9 +36,10 @@ extern "C" int leccr_attn_fwd(const void* q, const void* k, const void* v, void*
 extern "C" int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                               const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
                               int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
-                              int64_t ldv, int64_t ldo, int dtype, void* stream) {
+                              int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream) {
     LECCR_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && delta, LECCR_EINVAL, "attn_bwd: null pointer");
-    const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo};
+    LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_bwd: drop_p must be in [0,1)");
+    const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
     if (int rc = check_dims("attn_bwd", D, dtype)) return rc;
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);

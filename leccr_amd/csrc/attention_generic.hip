@@ -47,6 +47,10 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const T* __restri
     __builtin_amdgcn_wave_barrier();
     const float inv = l > 0.f ? 1.f / l : 0.f;
     if (lane == 0) lse[row] = l > 0.f ? mx + __logf(l) : INFINITY;
+    if (D.dropout) {      // dropout on the normalised probabilities; the row sum above used the undropped values
+        for (int64_t j = lane; j < D.Lk; j += 64) ps[j] *= drop_mul(D.drop, (uint32_t)(row * D.Lk + j));
+        __builtin_amdgcn_wave_barrier();
+    }
     T* op = o + (bb * D.Lq + i) * D.ldo + h * D.hd;
     for (int d = lane; d < D.hd; d += 64) {
         float acc = 0.f;
@@ -104,7 +108,8 @@ __global__ __launch_bounds__(256) void attn_generic_dq_kernel(const T* __restric
                 dp = fmaf(dos[d], to_f32(vp[d]), dp);
             }
             const float p = __expf(s * scale - L);
-            dsv = p * (dp - dl);
+            const float dm = D.dropout ? drop_mul(D.drop, (uint32_t)(row * D.Lk + j)) : 1.f;
+            dsv = p * (dm * dp - dl);
         }
         ds[j] = dsv;
     }
@@ -154,7 +159,9 @@ __global__ __launch_bounds__(256) void attn_generic_dkv_kernel(const T* __restri
             }
             const int64_t r = (bb * D.heads + h) * D.Lq + i;
             p = __expf(s * scale - lse[r]);
-            dsv = p * (dp - delta[r]);
+            const float dm = D.dropout ? drop_mul(D.drop, (uint32_t)(r * D.Lk + j)) : 1.f;
+            dsv = p * (dm * dp - delta[r]);
+            p *= dm;                                  // dV uses the dropped probabilities
         }
         ps[i] = p;
         ds[i] = dsv;

@@ -37,6 +37,7 @@ struct FP {
     const uint8_t* kmask;
     int64_t heads, Lq, Lk, ldq, ldk, ldv, ldo;
     float scale;
+    DropCfg drop;
 };
 
 // Stage a [64 rows][64 bf16] tile (rows clamped to n_rows-1) from `base` (row stride ld elements) into LDS.
@@ -104,6 +105,7 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 // LDS per stage: K tile | V tile | bias[64] f32
 constexpr int FWD_STAGE = 2 * TILE_BYTES + 256;
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void flash_fwd_kernel(FP p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
@@ -179,6 +181,13 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FP p) {
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs;
         m = mn;
+        if constexpr (DROP) {   // dropout on the probabilities that enter PV; the normaliser l keeps the undropped sum
+            const uint32_t base = (uint32_t)((bh * p.Lq + q0 + wave * 16 + (lane & 15)) * p.Lk + (int64_t)t * BT + 4 * h4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[j][r] *= drop_mul(p.drop, base + 16 * j + r);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] *= alpha;
         const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
@@ -203,6 +212,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FP p) {
 // LDS per stage: Q tile | dO tile | lse2[64] | delta[64]
 constexpr int DKV_STAGE = 2 * TILE_BYTES + 512;
 
+template <bool DROP>
 __global__ __launch_bounds__(256) void flash_dkdv_kernel(FP p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
@@ -269,8 +279,11 @@ __global__ __launch_bounds__(256) void flash_dkdv_kernel(FP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = exp2_fast(s[j][r] * c + kbias - lj[r]);
-                s[j][r] = pr;
-                dp[j][r] = pr * (dp[j][r] - dj[r]);
+                float dm = 1.f;
+                if constexpr (DROP)
+                    dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + (int64_t)t * BT + 16 * j + 4 * h4 + r) * p.Lk + key));
+                s[j][r] = pr * dm;                               // dV uses the dropped probabilities
+                dp[j][r] = pr * (dm * dp[j][r] - dj[r]);
             }
         }
         const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(256) void flash_dkdv_kernel(FP p) {
 }
 
 // --------------------------------------------------------------------------------------------------- backward: dQ
+template <bool DROP>
 __global__ __launch_bounds__(256) void flash_dq_kernel(FP p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
@@ -357,7 +371,10 @@ __global__ __launch_bounds__(256) void flash_dq_kernel(FP p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pr = exp2_fast(s[j][r] * c + bj[r] - lse2);
-                dp[j][r] = pr * (dp[j][r] - dlt);
+                float dm = 1.f;
+                if constexpr (DROP)
+                    dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + qi) * p.Lk + (int64_t)t * BT + 16 * j + 4 * h4 + r));
+                dp[j][r] = pr * (dm * dp[j][r] - dlt);
             }
         }
         const bf16x8 df0 = pack2(dp[0], dp[1]), df1 = pack2(dp[2], dp[3]);
@@ -416,11 +433,10 @@ int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* l
     FP p{};
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)o; p.lse = lse;
     p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk; p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv;
-    p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD);
-    static bool once = (set_smem(flash_fwd_kernel, 2 * FWD_STAGE), true);
-    (void)once;
+    p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
     dim3 grid((unsigned)(cdiv(D.Lq, BT) * D.b * D.heads));
-    hipLaunchKernelGGL(flash_fwd_kernel, grid, dim3(256), 2 * FWD_STAGE, st, p);
+    if (D.dropout) hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 2 * FWD_STAGE, st, p);
+    else hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(256), 2 * FWD_STAGE, st, p);
     return check_launch("flash_fwd");
 }
 
@@ -434,14 +450,18 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)o;
     p.dout = (const bf16_t*)dout; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lse = const_cast<float*>(lse); p.delta = delta; p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk;
-    p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv; p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD);
-    static bool once = (set_smem(flash_dkdv_kernel, 2 * DKV_STAGE), set_smem(flash_dq_kernel, 2 * FWD_STAGE), true);
-    (void)once;
+    p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv; p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
     const int64_t rows = D.b * D.heads * D.Lq;
     hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, (const bf16_t*)o,
                        (const bf16_t*)dout, delta, D.heads, D.Lq, D.ldo, rows);
-    hipLaunchKernelGGL(flash_dkdv_kernel, dim3((unsigned)(cdiv(D.Lk, BT) * D.b * D.heads)), dim3(256), 2 * DKV_STAGE, st, p);
-    hipLaunchKernelGGL(flash_dq_kernel, dim3((unsigned)(cdiv(D.Lq, BT) * D.b * D.heads)), dim3(256), 2 * FWD_STAGE, st, p);
+    const dim3 gk((unsigned)(cdiv(D.Lk, BT) * D.b * D.heads)), gq((unsigned)(cdiv(D.Lq, BT) * D.b * D.heads));
+    if (D.dropout) {
+        hipLaunchKernelGGL(flash_dkdv_kernel<true>, gk, dim3(256), 2 * DKV_STAGE, st, p);
+        hipLaunchKernelGGL(flash_dq_kernel<true>, gq, dim3(256), 2 * FWD_STAGE, st, p);
+    } else {
+        hipLaunchKernelGGL(flash_dkdv_kernel<false>, gk, dim3(256), 2 * DKV_STAGE, st, p);
+        hipLaunchKernelGGL(flash_dq_kernel<false>, gq, dim3(256), 2 * FWD_STAGE, st, p);
+    }
     return check_launch("flash_bwd");
 }
 

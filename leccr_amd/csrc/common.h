@@ -148,6 +148,33 @@ template <int EPI> __device__ __forceinline__ float apply_epi(float v, float aux
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Counter-based dropout RNG: keep(element) depends only on (seed, element index), so the backward pass and the
+// recomputing attention kernels regenerate the forward mask without storing it.  Two rounds of a 32-bit integer
+// finaliser (lowbias32) keyed by the two seed halves.
+struct DropCfg {
+    uint32_t s0, s1, thr;   // keep iff hash >= thr, thr = p * 2^32
+    float scale;            // 1 / (1 - p)
+};
+__host__ __device__ inline uint32_t drop_hash(uint32_t s0, uint32_t s1, uint32_t idx) {
+    uint32_t x = idx ^ s0;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    x += s1 * 0x9e3779b9u;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float drop_mul(const DropCfg& d, uint32_t idx) {   // scale or 0
+    return drop_hash(d.s0, d.s1, idx) >= d.thr ? d.scale : 0.f;
+}
+inline DropCfg make_drop(float p, uint64_t seed) {
+    DropCfg d;
+    d.s0 = (uint32_t)seed;
+    d.s1 = (uint32_t)(seed >> 32);
+    const double t = (double)p * 4294967296.0;
+    d.thr = t >= 4294967295.0 ? 0xffffffffu : (uint32_t)t;
+    d.scale = p < 1.f ? 1.f / (1.f - p) : 0.f;
+    return d;
+}
+
 }  // namespace leccr
 
 #define LECCR_REQUIRE(cond, code, ...)          \

@@ -63,6 +63,13 @@ __global__ __launch_bounds__(256) void axpy_kernel(const T* __restrict__ x, T* _
         y[i] = from_f32<T>(to_f32(y[i]) + a * to_f32(x[i]));
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, DropCfg d) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        y[i] = from_f32<T>(to_f32(x[i]) * drop_mul(d, (uint32_t)i));
+}
+
 static unsigned stream_grid(int64_t n_items) {
     int64_t nb = cdiv(n_items, 256);
     return (unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
@@ -108,4 +115,15 @@ extern "C" int leccr_axpy(const void* x, void* y, float a, int64_t n, int dtype,
     else if (dtype == LECCR_BF16) hipLaunchKernelGGL((axpy_kernel<bf16_t>), dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, a, n);
     else { set_error("axpy: bad dtype"); return LECCR_EINVAL; }
     return check_launch("axpy");
+}
+
+extern "C" int leccr_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream) {
+    LECCR_REQUIRE(x && y && p >= 0.f && p < 1.f, LECCR_EINVAL, "dropout: bad argument");
+    LECCR_REQUIRE(n < (1ll << 32), LECCR_EINVAL, "dropout: more than 2^32 elements");
+    if (n == 0) return LECCR_OK;
+    const DropCfg d = make_drop(p, seed);
+    if (dtype == LECCR_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, n, d);
+    else if (dtype == LECCR_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, n, d);
+    else { set_error("dropout: bad dtype"); return LECCR_EINVAL; }
+    return check_launch("dropout");
 }

@@ -87,7 +87,7 @@ def _attn_args(q, k, v):
     return q.shape[0], q.shape[1], k.shape[1]
 
 
-def attn_fwd(q, k, v, heads, kmask=None):
+def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0):
     b, Lq, Lk = _attn_args(q, k, v)
     d = q.shape[2]
     hd = d // heads
@@ -96,12 +96,12 @@ def attn_fwd(q, k, v, heads, kmask=None):
     if kmask is not None:
         assert kmask.dtype == torch.uint8 and kmask.shape == (b, Lk) and kmask.is_contiguous()
     check(lib().leccr_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), b, heads, Lq, Lk, hd,
-                               q.stride(1), k.stride(1), v.stride(1), o.stride(1), dtype_code(q), stream()),
-          'leccr_attn_fwd')
+                               q.stride(1), k.stride(1), v.stride(1), o.stride(1), dtype_code(q), float(drop_p),
+                               int(seed), stream()), 'leccr_attn_fwd')
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None):
+def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None, drop_p=0.0, seed=0):
     b, Lq, Lk = _attn_args(q, k, v)
     d = q.shape[2]
     hd = d // heads
@@ -114,7 +114,7 @@ def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None
     delta = torch.empty_like(lse)
     check(lib().leccr_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(kmask), ptr(dq), ptr(dk),
                                ptr(dv), ptr(delta), b, heads, Lq, Lk, hd, q.stride(1), k.stride(1), v.stride(1),
-                               o.stride(1), dtype_code(q), stream()), 'leccr_attn_bwd')
+                               o.stride(1), dtype_code(q), float(drop_p), int(seed), stream()), 'leccr_attn_bwd')
     return dq, dk, dv
 
 
@@ -316,3 +316,11 @@ def axpy(x, y, a):
     assert x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     check(lib().leccr_axpy(ptr(x), ptr(y), float(a), x.numel(), dtype_code(x), stream()), 'leccr_axpy')
     return y
+
+
+def dropout(x, p, seed, out=None):
+    """y = keep(seed, i) ? x / (1-p) : 0; the same call on a gradient is the backward.  out may be x (in place)."""
+    assert x.is_contiguous()
+    out = torch.empty_like(x) if out is None else out
+    check(lib().leccr_dropout(ptr(x), ptr(out), x.numel(), float(p), int(seed), dtype_code(x), stream()), 'leccr_dropout')
+    return out

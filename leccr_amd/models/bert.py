@@ -3,7 +3,8 @@ called at xvlm.py:238 and model_retrieval_caption.py:60) over the HIP ops.
 
 Arithmetic restated from transformers' modeling_bert (third-party; `transformers==4.12.5` in LECCR/requirements.txt):
 embeddings = word[ids] + position[0..L-1] + token_type[0] -> LayerNorm(1e-12); post-LN layers; erf-GELU; additive
-key-padding mask; dropout is a no-op here (p = 0 / eval parity).
+key-padding mask; dropout (hidden 0.1, attention probabilities 0.1 - xvlm.py:94-97) is active in train mode with
+counter-based masks regenerated in the backward (leccr_dropout, leccr_attn_* drop_p).
 """
 import types
 
@@ -15,7 +16,8 @@ from .layers import LayerNormParams, Linear, mark_unused
 
 BERT_BASE_MULTILINGUAL = dict(vocab_size=119547, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                               intermediate_size=3072, max_position_embeddings=512, type_vocab_size=2,
-                              layer_norm_eps=1e-12, pad_token_id=0)
+                              layer_norm_eps=1e-12, pad_token_id=0,
+                              hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)     # xvlm.py:94-97
 
 
 class BertEmbeddings(nn.Module):
@@ -26,6 +28,7 @@ class BertEmbeddings(nn.Module):
         self.token_type_embeddings = nn.Embedding(c['type_vocab_size'], c['hidden_size'])
         self.LayerNorm = LayerNormParams(c['hidden_size'], c['layer_norm_eps'])
         self.eps, self.pad_id = c['layer_norm_eps'], c['pad_token_id']
+        self.dropout_p = c['hidden_dropout_prob']
         for e in (self.word_embeddings, self.position_embeddings, self.token_type_embeddings):
             nn.init.normal_(e.weight, std=0.02)
         with torch.no_grad():
@@ -67,6 +70,7 @@ class BertLayer(nn.Module):
         super().__init__()
         d = c['hidden_size']
         self.heads, self.eps = c['num_attention_heads'], c['layer_norm_eps']
+        self.hidden_dropout_p, self.attn_dropout_p = c['hidden_dropout_prob'], c['attention_probs_dropout_prob']
         self.attention = _Attention(d, self.eps)
         self.intermediate = _Intermediate(d, c['intermediate_size'])
         self.output = _SelfOutput(c['intermediate_size'], d, self.eps)

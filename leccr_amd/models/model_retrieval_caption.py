@@ -101,6 +101,10 @@ class RetrievalModel(XVLMBase):
         """model_retrieval_caption.py:154-199 -> (loss_itc_vs + loss_cv, loss_itc_vt', loss_itc_st, w_c loss_itc_c,
         w_r loss_reg_c).  Same five scalars; internally batch-major, src+tgt text in one BERT pass."""
         self._ensure_runtime()
+        if self.training:          # fresh dropout masks per step and per rank (the reference seeds with seed + rank)
+            self._step_count = getattr(self, '_step_count', 0) + 1
+            rank, _ = _dist_info()
+            ops.set_dropout_seed((int(self.config.get('seed', 42)) + rank) * 1000003 + self._step_count)
         tval = float(self.temp.detach())          # the step's only host read of a device scalar
         ori_image, _ = self.get_vision_embeds(image)
         with torch.no_grad():

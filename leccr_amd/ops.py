@@ -19,6 +19,26 @@ from ._lib import EPI_DGELU, EPI_DQUICKGELU, EPI_GELU, EPI_NONE, EPI_QUICKGELU
 _DACT = {EPI_QUICKGELU: EPI_DQUICKGELU, EPI_GELU: EPI_DGELU}
 
 
+# --------------------------------------------------------------------------------------- dropout plumbing
+class _Rng:
+    base, n = 0x5EED, 0
+
+
+def set_dropout_seed(seed):
+    """Start a new stream of dropout masks (call once per training step; identical on no rank: add the rank)."""
+    _Rng.base, _Rng.n = int(seed) & 0x7FFFFFFFFFFFFFFF, 0
+
+
+def _next_seed():
+    _Rng.n += 1
+    return (_Rng.base * 1000003 + _Rng.n * 7919) & 0xFFFFFFFFFFFFFFFF
+
+
+def _p(module, attr):
+    """Effective dropout probability of a layer: its configured p in train mode, 0 in eval mode."""
+    return float(getattr(module, attr, 0.0)) if module.training else 0.0
+
+
 # --------------------------------------------------------------------------------------- raw linear helpers
 def _bias(b):
     return None if b is None else b.data.reshape(-1)
@@ -256,6 +276,9 @@ class BertEmbedFn(torch.autograd.Function):
         e = K.bert_embed_fwd(ids.contiguous(), emb.word_embeddings.weight.data, emb.position_embeddings.weight.data,
                              emb.token_type_embeddings.weight.data, dtype)
         y, mean, rstd, _ = K.layernorm_fwd(e, emb.LayerNorm.weight.data, emb.LayerNorm.bias.data, emb.eps)
+        ctx.drop = (_p(emb, 'dropout_p'), _next_seed())
+        if ctx.drop[0] > 0:
+            K.dropout(y, ctx.drop[0], ctx.drop[1], out=y)
         ctx.save_for_backward(ids, e, mean, rstd)
         ctx.emb = emb
         return y
@@ -264,7 +287,10 @@ class BertEmbedFn(torch.autograd.Function):
     def backward(ctx, dy):
         ids, e, mean, rstd = ctx.saved_tensors
         emb = ctx.emb
-        de = K.layernorm_bwd(dy.contiguous(), e, emb.LayerNorm.weight.data, mean, rstd, emb.LayerNorm.weight._g,
+        dy = dy.contiguous()
+        if ctx.drop[0] > 0:
+            dy = K.dropout(dy, ctx.drop[0], ctx.drop[1])
+        de = K.layernorm_bwd(dy, e, emb.LayerNorm.weight.data, mean, rstd, emb.LayerNorm.weight._g,
                              emb.LayerNorm.bias._g)
         K.bert_embed_bwd(ids, de, emb.word_embeddings.weight._g, emb.position_embeddings.weight._g,
                          emb.token_type_embeddings.weight._g, emb.pad_id)
@@ -275,47 +301,65 @@ class BertEmbedFn(torch.autograd.Function):
 
 
 class BertLayerFn(torch.autograd.Function):
-    """One post-LN BERT layer: packed QKV GEMM -> masked attention -> dense + residual -> LN -> GELU FFN + residual -> LN."""
+    """One post-LN BERT layer: packed QKV GEMM -> masked attention -> dense (+dropout) + residual -> LN -> GELU FFN
+    (+dropout) + residual -> LN.  Dropout sites as in HF BertSelfAttention / BertSelfOutput / BertOutput."""
 
     @staticmethod
     def forward(ctx, x, kmask, layer, *params):
         b, L, d = x.shape
+        ph, pa = _p(layer, 'hidden_dropout_p'), _p(layer, 'attn_dropout_p')
+        seeds = (_next_seed(), _next_seed(), _next_seed())
         qkv = lin_fwd(_rows(x), layer._qkv_w, layer._qkv_b).view(b, L, 3 * d)
-        o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask)
+        o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask, pa, seeds[0])
         ao = layer.attention.output
-        s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, residual=_rows(x)).view(b, L, d)
-        x1, mean1, rstd1, _ = K.layernorm_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps)
+        if ph > 0:      # dense -> dropout -> + residual (inside the LayerNorm kernel)
+            a1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias)
+            K.dropout(a1, ph, seeds[1], out=a1)
+            x1, mean1, rstd1, s1 = K.layernorm_fwd(a1.view(b, L, d), ao.LayerNorm.weight.data, ao.LayerNorm.bias.data,
+                                                   layer.eps, add=x, want_sum=True)
+        else:
+            s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, residual=_rows(x)).view(b, L, d)
+            x1, mean1, rstd1, _ = K.layernorm_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps)
         pre = torch.empty(b * L, layer.intermediate.dense.weight.shape[0], device=x.device, dtype=x.dtype)
         h = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, epilogue=EPI_GELU,
                     aux_out=pre)
-        s2 = lin_fwd(h, layer.output.dense.weight, layer.output.dense.bias, residual=_rows(x1)).view(b, L, d)
-        x2, mean2, rstd2, _ = K.layernorm_fwd(s2, layer.output.LayerNorm.weight.data, layer.output.LayerNorm.bias.data,
-                                              layer.eps)
+        out = layer.output
+        if ph > 0:
+            a2 = lin_fwd(h, out.dense.weight, out.dense.bias)
+            K.dropout(a2, ph, seeds[2], out=a2)
+            x2, mean2, rstd2, s2 = K.layernorm_fwd(a2.view(b, L, d), out.LayerNorm.weight.data, out.LayerNorm.bias.data,
+                                                   layer.eps, add=x1, want_sum=True)
+        else:
+            s2 = lin_fwd(h, out.dense.weight, out.dense.bias, residual=_rows(x1)).view(b, L, d)
+            x2, mean2, rstd2, _ = K.layernorm_fwd(s2, out.LayerNorm.weight.data, out.LayerNorm.bias.data, layer.eps)
         ctx.save_for_backward(x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2)
-        ctx.layer = layer
+        ctx.layer, ctx.drop = layer, (ph, pa, seeds)
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
         x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2 = ctx.saved_tensors
         layer = ctx.layer
+        ph, pa, seeds = ctx.drop
         ao, out = layer.attention.output, layer.output
         b, L, d = x.shape
         ds2 = K.layernorm_bwd(dx2.contiguous(), s2, out.LayerNorm.weight.data, mean2, rstd2, out.LayerNorm.weight._g,
                               out.LayerNorm.bias._g)
-        g2 = _rows(ds2)
-        dpre = lin_dx(g2, out.dense.weight, epilogue=EPI_DGELU, aux=pre)
-        lin_dw(g2, h, out.dense.weight, out.dense.bias)
+        g2 = _rows(ds2)                                   # gradient of the sum: the residual path takes it as is
+        gd2 = K.dropout(g2, ph, seeds[2]) if ph > 0 else g2   # the dense path takes it through the dropout mask
+        dpre = lin_dx(gd2, out.dense.weight, epilogue=EPI_DGELU, aux=pre)
+        lin_dw(gd2, h, out.dense.weight, out.dense.bias)
         dx1 = lin_dx(dpre, layer.intermediate.dense.weight, residual=g2)          # + residual path of s2 = .. + x1
         lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
         ds1 = K.layernorm_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                               ao.LayerNorm.bias._g)
         g1 = _rows(ds1)
-        do = lin_dx(g1, ao.dense.weight).view(b, L, d)
-        lin_dw(g1, _rows(o), ao.dense.weight, ao.dense.bias)
+        gd1 = K.dropout(g1, ph, seeds[1]) if ph > 0 else g1
+        do = lin_dx(gd1, ao.dense.weight).view(b, L, d)
+        lin_dw(gd1, _rows(o), ao.dense.weight, ao.dense.bias)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, layer.heads, kmask,
-                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], drop_p=pa, seed=seeds[0])
         dx = lin_dx(_rows(dqkv), layer._qkv_w, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
         lin_dw(_rows(dqkv), _rows(x), layer._qkv_w, layer._qkv_b)
         for p in (out.LayerNorm.weight, out.LayerNorm.bias, ao.LayerNorm.weight, ao.LayerNorm.bias):
@@ -326,32 +370,42 @@ class BertLayerFn(torch.autograd.Function):
 # --------------------------------------------------------------------------------------- caption interaction
 class CrossAttnLayerFn(torch.autograd.Function):
     """CrossAttentionLayer / SelfAttentionLayer (models/attention.py:24-128), batch-major:
-    a = MHA(tgt, memory, key_padding_mask); y = norm2(tgt + linear2(gelu(linear1(a)))).   (norm1 unused, a NOT
-    residual-added before the FFN - attention.py:47-54.)"""
+    a = MHA(tgt, memory, key_padding_mask, dropout p); y = norm2(tgt + dropout2(linear2(dropout(gelu(linear1(a)))))).
+    (norm1 unused, a NOT residual-added before the FFN - attention.py:47-54.)"""
 
     @staticmethod
     def forward(ctx, tgt, memory, kmask, layer, *params):
         b, Lq, d = tgt.shape
         Lk = memory.shape[1]
         mha = layer.multihead_attn
+        pd = _p(layer, 'dropout_p')
+        seeds = (_next_seed(), _next_seed(), _next_seed())
         wq, wkv = _Slice(mha.in_proj_weight, 0, d), _Slice(mha.in_proj_weight, d, 3 * d)
         bq, bkv = _Slice(mha.in_proj_bias, 0, d), _Slice(mha.in_proj_bias, d, 3 * d)
         q = lin_fwd(_rows(tgt), wq, bq).view(b, Lq, d)
         kv = lin_fwd(_rows(memory), wkv, bkv).view(b, Lk, 2 * d)
-        o, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], layer.heads, kmask)
+        o, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], layer.heads, kmask, pd, seeds[0])
         a = lin_fwd(_rows(o), mha.out_proj.weight, mha.out_proj.bias)
         pre = torch.empty_like(a)
         h = lin_fwd(a, layer.linear1.weight, layer.linear1.bias, epilogue=EPI_GELU, aux_out=pre)
-        s = lin_fwd(h, layer.linear2.weight, layer.linear2.bias, residual=_rows(tgt)).view(b, Lq, d)
-        y, mean, rstd, _ = K.layernorm_fwd(s, layer.norm2.weight.data, layer.norm2.bias.data, 1e-5)
+        if pd > 0:
+            K.dropout(h, pd, seeds[1], out=h)
+            l2 = lin_fwd(h, layer.linear2.weight, layer.linear2.bias)
+            K.dropout(l2, pd, seeds[2], out=l2)
+            y, mean, rstd, s = K.layernorm_fwd(l2.view(b, Lq, d), layer.norm2.weight.data, layer.norm2.bias.data, 1e-5,
+                                               add=tgt.contiguous(), want_sum=True)
+        else:
+            s = lin_fwd(h, layer.linear2.weight, layer.linear2.bias, residual=_rows(tgt)).view(b, Lq, d)
+            y, mean, rstd, _ = K.layernorm_fwd(s, layer.norm2.weight.data, layer.norm2.bias.data, 1e-5)
         ctx.save_for_backward(tgt, memory, kmask, q, kv, o, lse, a, pre, h, s, mean, rstd)
-        ctx.layer = layer
+        ctx.layer, ctx.drop = layer, (pd, seeds)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         tgt, memory, kmask, q, kv, o, lse, a, pre, h, s, mean, rstd = ctx.saved_tensors
         layer = ctx.layer
+        pd, seeds = ctx.drop
         mha = layer.multihead_attn
         b, Lq, d = tgt.shape
         Lk = memory.shape[1]
@@ -362,8 +416,11 @@ class CrossAttnLayerFn(torch.autograd.Function):
         _mark(layer.norm2.weight)
         _mark(layer.norm2.bias)
         gs = _rows(ds)
-        dpre = lin_dx(gs, layer.linear2.weight, epilogue=EPI_DGELU, aux=pre)
-        lin_dw(gs, h, layer.linear2.weight, layer.linear2.bias)
+        gd = K.dropout(gs, pd, seeds[2]) if pd > 0 else gs
+        dpre = lin_dx(gd, layer.linear2.weight, epilogue=EPI_DGELU, aux=pre)      # (g W2) * gelu'(pre) ...
+        if pd > 0:
+            K.dropout(dpre, pd, seeds[1], out=dpre)                               # ... * dropout mask (both elementwise)
+        lin_dw(gd, h, layer.linear2.weight, layer.linear2.bias)
         da = lin_dx(dpre, layer.linear1.weight)
         lin_dw(dpre, a, layer.linear1.weight, layer.linear1.bias)
         do = lin_dx(da, mha.out_proj.weight).view(b, Lq, d)
@@ -371,7 +428,7 @@ class CrossAttnLayerFn(torch.autograd.Function):
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         K.attn_bwd(q, kv[..., :d], kv[..., d:], o, do, lse, layer.heads, kmask, dq=dq, dk=dkv[..., :d],
-                   dv=dkv[..., d:])
+                   dv=dkv[..., d:], drop_p=pd, seed=seeds[0])
         dtgt = lin_dx(_rows(dq), wq, residual=gs).view(b, Lq, d) if ctx.needs_input_grad[0] else None
         lin_dw(_rows(dq), _rows(tgt), wq, bq)
         dmem = lin_dx(_rows(dkv), wkv).view(b, Lk, d) if ctx.needs_input_grad[1] else None

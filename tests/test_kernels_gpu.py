@@ -450,3 +450,43 @@ def test_gemm256_matches_128_bitwise_inputs(K):
     o2 = K.gemm(a, b, out_dtype=torch.float32)
     _lib.lib().leccr_set_gemm_variant(0)
     assert float((o1 - o2).abs().max()) <= 1e-4 * float(o1.abs().max())
+
+
+# ------------------------------------------------------------------------------------------ dropout
+def test_dropout_mask_is_counter_based(K):
+    x = torch.ones(1 << 20, device=DEV)
+    y1, y2 = K.dropout(x, 0.1, 1234), K.dropout(x, 0.1, 1234)
+    assert torch.equal(y1, y2)                                       # same (seed, index) -> same mask: backward = forward call
+    keep = float((y1 != 0).float().mean())
+    assert abs(keep - 0.9) < 2e-3 and abs(float(y1.max()) - 1 / 0.9) < 1e-6
+    y3 = K.dropout(x, 0.1, 1235)
+    assert float(((y1 != 0) == (y3 != 0)).float().mean()) < 0.85     # a different seed decorrelates (0.82 expected)
+    assert torch.equal(K.dropout(x, 0.0, 7), x)
+
+
+@pytest.mark.parametrize('dtype,hd', [(torch.float32, 64), (torch.bfloat16, 64), (torch.float32, 8)])
+def test_attention_dropout_matches_masked_reference(K, dtype, hd):
+    b, heads, Lq, Lk, p, seed = 2, 4, 70, 50, 0.25, 99
+    d = heads * hd
+    q, kv = _rand((b, Lq, d), dtype, 100), _rand((b, Lk, 2 * d), dtype, 101)
+    k, v = kv[..., :d], kv[..., d:]
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    o, lse = K.attn_fwd(qd, kvd[..., :d], kvd[..., d:], heads, None, p, seed)
+    # the mask the kernels used: element index ((b*heads + h)*Lq + q)*Lk + k
+    mask = K.dropout(torch.ones(b * heads * Lq * Lk, device=DEV), p, seed).view(b, heads, Lq, Lk).cpu().double()
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh = qr.reshape(b, Lq, heads, hd).permute(0, 2, 1, 3)
+    kh = kr.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    vh = vr.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    pr = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd), -1) * mask
+    ref = (pr @ vh).permute(0, 2, 1, 3).reshape(b, Lq, d)
+    e, s = _err(o, ref)
+    assert e <= _tol(dtype) * s, (e, s)
+    do = _rand((b, Lq, d), dtype, 102)
+    (ref * do.double()).sum().backward()
+    dkv = torch.zeros_like(kvd)
+    dq, dk, dv = K.attn_bwd(qd, kvd[..., :d], kvd[..., d:], o, do.to(DEV), lse, heads, None, dk=dkv[..., :d],
+                            dv=dkv[..., d:], drop_p=p, seed=seed)
+    for name, got, r in (('dq', dq, qr.grad), ('dk', dk, kr.grad), ('dv', dv, vr.grad)):
+        e, s = _err(got, r)
+        assert e <= (1e-4 if dtype == torch.float32 else 3e-2) * s, (name, e, s)

@@ -40,7 +40,7 @@ def build(cfg_extra, state=None, seed=0):
         msg = m.load_state_dict(state, strict=False)
         assert not [k for k in msg.unexpected_keys], msg.unexpected_keys
         assert all(k.startswith('caption_encoder.') for k in msg.missing_keys), msg.missing_keys
-    return m.to(DEV)
+    return m.to(DEV).eval()          # parity runs: dropout off (the fixtures were captured in eval mode)
 
 
 def run(model, z, sl=slice(None)):
@@ -200,3 +200,53 @@ def test_train_step_updates_like_reference_optimizer():
     assert abs(opt.param_groups[0]['lr'] - 1e-3) < 1e-12
     sched.step()
     assert abs(opt.param_groups[0]['lr'] - 1e-3 * 8 / 9) < 1e-12
+
+
+def test_bert_layer_dropout_matches_masked_reference():
+    """Train-mode BertLayer (hidden + attention dropout 0.1): forward and input gradient equal a plain-torch layer that
+    applies the SAME masks (regenerated from the kernels' counter-based RNG)."""
+    import math
+    from leccr_amd import kernels as K, ops
+    from leccr_amd.models.bert import BertModel
+    from leccr_amd.arena import ParamArena
+    torch.manual_seed(5)
+    cfg = dict(vocab_size=50, hidden_size=128, num_hidden_layers=1, num_attention_heads=2, intermediate_size=256,
+               max_position_embeddings=16)
+    bert = BertModel(cfg).to(DEV).train()
+    arena = ParamArena(bert, torch.float32, torch.device(DEV))
+    layer = bert.encoder.layer[0]
+    b, L, d, H = 3, 10, 128, 2
+    x = torch.randn(b, L, d, device=DEV, requires_grad=True)
+    kmask = torch.zeros(b, L, dtype=torch.uint8, device=DEV)
+    kmask[1, 7:] = 1
+    ops.set_dropout_seed(77)
+    y = layer(x, kmask)
+    probe = torch.randn_like(y)
+    (y * probe).sum().backward()
+    # replay the seed sequence the layer consumed
+    ops.set_dropout_seed(77)
+    s_attn, s1, s2 = ops._next_seed(), ops._next_seed(), ops._next_seed()
+    ones = lambda n: torch.ones(n, device=DEV)
+    m_attn = K.dropout(ones(b * H * L * L), 0.1, s_attn).view(b, H, L, L).double().cpu()
+    m1 = K.dropout(ones(b * L * d), 0.1, s1).view(b, L, d).double().cpu()
+    m2 = K.dropout(ones(b * L * d), 0.1, s2).view(b, L, d).double().cpu()
+    P = {n: p.detach().double().cpu() for n, p in layer.named_parameters()}
+    xr = x.detach().double().cpu().requires_grad_(True)
+    F = torch.nn.functional
+    lin = lambda t, n: F.linear(t, P[n + '.weight'], P[n + '.bias'])
+    heads = lambda t: t.view(b, L, H, d // H).permute(0, 2, 1, 3)
+    qh, kh, vh = (heads(lin(xr, f'attention.self.{n}')) for n in ('query', 'key', 'value'))
+    sc = (qh @ kh.transpose(-1, -2) / math.sqrt(d // H)).masked_fill(kmask.bool().cpu()[:, None, None, :], float('-inf'))
+    o = ((torch.softmax(sc, -1) * m_attn) @ vh).permute(0, 2, 1, 3).reshape(b, L, d)
+    x1 = F.layer_norm(lin(o, 'attention.output.dense') * m1 + xr, (d,), P['attention.output.LayerNorm.weight'],
+                      P['attention.output.LayerNorm.bias'], 1e-12)
+    h = F.gelu(lin(x1, 'intermediate.dense'))
+    ref = F.layer_norm(lin(h, 'output.dense') * m2 + x1, (d,), P['output.LayerNorm.weight'], P['output.LayerNorm.bias'], 1e-12)
+    assert max_err(y, ref) < 5e-5
+    (ref * probe.double().cpu()).sum().backward()
+    assert max_err(x.grad, xr.grad) < 1e-4 * float(xr.grad.abs().max()) + 1e-6
+    # eval mode switches every mask off
+    bert.eval()
+    y_eval = layer(x.detach(), kmask)
+    ops.set_dropout_seed(78)
+    assert torch.equal(y_eval, layer(x.detach(), kmask))
