@@ -16,13 +16,14 @@ class Encoding:
 
 
 def _tokens(g, b, L, vocab):
-    ids = torch.randint(1000, vocab, (b, L), generator=g)
-    lens = torch.randint(8, L + 1, (b,), generator=g)
+    ids = torch.randint(min(1000, vocab // 2), vocab, (b, L), generator=g)
+    cls, sep = (CLS, SEP) if vocab > SEP else (1, 2)       # tiny test vocabularies
+    lens = torch.randint(min(8, L), L + 1, (b,), generator=g)
     lens[0] = L                                     # padding='longest': at least one full-length row
     pos = torch.arange(L)[None, :]
     mask = (pos < lens[:, None]).long()
-    ids[:, 0] = CLS
-    ids[torch.arange(b), lens - 1] = SEP
+    ids[:, 0] = cls
+    ids[torch.arange(b), lens - 1] = sep
     return Encoding(ids * mask, mask)
 
 

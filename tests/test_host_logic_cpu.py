@@ -123,3 +123,16 @@ def test_allgather_and_grad_sync_two_ranks_gloo():
     ret = mgr.dict()
     mp.spawn(_gather_worker, args=(2, 29641, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def test_launcher_and_script_cli_match_the_reference_flags():
+    import run
+    import image_Retrieval_caption as task
+    a = run.build_parser().parse_args(['--task', 'itr_multi30k_caption', '--dist', 'gpu0', '--config', 'c.yaml',
+                                       '--bs', '128', '--epoch', '70', '--checkpoint', 'null', '--output_dir', 'o'])
+    cmd = run.build_command(a)
+    assert 'torch.distributed.run' in cmd and '--nproc-per-node=1' in cmd and '--master-addr 127.0.0.1' in cmd
+    assert 'image_Retrieval_caption.py' in cmd and '--bs 128' in cmd and '--epoch 70' in cmd and '--config c.yaml' in cmd
+    t = task.build_parser().parse_args(['--config', 'c.yaml', '--bs', '128', '--epoch', '2', '--evaluate'])
+    assert t.bs == 128 and t.evaluate and t.checkpoint == 'null' and t.distributed is True and t.seed == 42
+    assert {'train', 'evaluation_coarse', 'itm_eval', 'main'} <= set(dir(task))

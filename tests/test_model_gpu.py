@@ -250,3 +250,24 @@ def test_bert_layer_dropout_matches_masked_reference():
     y_eval = layer(x.detach(), kmask)
     ops.set_dropout_seed(78)
     assert torch.equal(y_eval, layer(x.detach(), kmask))
+
+
+def test_training_script_synthetic_epoch(tmp_path):
+    """image_Retrieval_caption.main on synthetic batches (tiny geometry): runs train() with the reference's loop and
+    writes log.txt + the final checkpoint with the reference's dict layout."""
+    import image_Retrieval_caption as task
+    cfg = dict(TINY_CFG)
+    cfg.update(clip_geometry=MODEL_VIT, text_config=TINY_BERT, compute_dtype='fp32', clip_image_res=64, synthetic_L_t=9,
+               synthetic_L_c=12, synthetic_vocab=100, max_tokens=200, batch_size_train=8,
+               optimizer={'opt': 'adamW', 'lr': 1e-4, 'weight_decay': 0.01, 'lr_mult': 2},
+               schedular={'sched': 'linear', 'lr': 1e-4, 'epochs': 1, 'num_warmup_steps': 0.1})
+    args = task.build_parser().parse_args(['--synthetic', '--synthetic_steps', '3', '--bs', '8', '--epoch', '1',
+                                           '--output_dir', str(tmp_path)])
+    model = task.main(args, cfg)
+    import json
+    log = [json.loads(l) for l in open(tmp_path / 'log.txt')]
+    assert log[0]['epoch'] == 0 and float(log[0]['train_loss_itc_vs']) > 0
+    ck = torch.load(tmp_path / 'checkpoint_0.pth', map_location='cpu', weights_only=False)
+    assert set(ck) == {'model', 'optimizer', 'lr_scheduler', 'config', 'epoch'}
+    assert 'text_encoder.embeddings.word_embeddings.weight' in ck['model']
+    assert model.arena.step_count == 3
