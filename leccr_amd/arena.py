@@ -43,9 +43,18 @@ class ParamArena:
                             assert p.numel() % _ALIGN == 0, 'packed group members must be multiples of 64 elements'
                             add(p)
                         groups.append((m, gname, plist, start))
-        for p in model.parameters():
-            if not getattr(p, '_leccr_unused', False):      # inert state_dict-only parameters stay outside the arena
+        late = []                                          # parameters whose gradients are final last (the ViT trunk)
+        late_prefix = getattr(model, '_arena_late_prefix', None)
+        for n, p in model.named_parameters():
+            if getattr(p, '_leccr_unused', False):          # inert state_dict-only parameters stay outside the arena
+                continue
+            if late_prefix and n.startswith(late_prefix):
+                late.append(p)
+            else:
                 add(p)
+        n_early = len(params)
+        for p in late:
+            add(p)
         self.params = params
         self.names = {id(p): n for n, p in model.named_parameters()}
         device = device or params[0].device
@@ -57,6 +66,8 @@ class ParamArena:
             self.offsets.append(off)
             off += p.numel()
         self.numel = (off + _ALIGN - 1) // _ALIGN * _ALIGN
+        # [0, early_numel): gradients complete before the late region's backward starts -> their all-reduce can overlap it
+        self.early_numel = self.offsets[n_early] if n_early < len(params) else self.numel
         self.data = torch.zeros(self.numel, device=device, dtype=torch.float32)
         self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
         self.lp = torch.zeros(self.numel, device=device, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None

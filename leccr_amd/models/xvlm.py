@@ -110,6 +110,9 @@ class XVLMBase(nn.Module):
         if use_matching_loss:
             self.itm_head = mark_unused(build_mlp(input_dim=self.text_width, output_dim=2))
             self.init_params.extend(['itm_head.' + n for n, _ in self.itm_head.named_parameters()])
+        # the ViT trunk is first in forward, hence last in backward: its parameters go to the end of the arena so that
+        # everything before them can be all-reduced while the ViT backward still runs (leccr_amd.parallel)
+        self._arena_late_prefix = 'clip_encoder.visual.'
         dt = (config or {}).get('compute_dtype', 'fp32')
         self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[dt]
         self.arena = None

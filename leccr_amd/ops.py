@@ -34,6 +34,10 @@ def _next_seed():
     return (_Rng.base * 1000003 + _Rng.n * 7919) & 0xFFFFFFFFFFFFFFFF
 
 
+# called when the ViT backward begins (= every other parameter gradient of the step is final); set by parallel.py
+on_late_backward_start = None
+
+
 def _p(module, attr):
     """Effective dropout probability of a layer: its configured p in train mode, 0 in eval mode."""
     return float(getattr(module, attr, 0.0)) if module.training else 0.0
@@ -254,6 +258,8 @@ class LnProjFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if on_late_backward_start is not None:
+            on_late_backward_start()
         x, h, mean, rstd = ctx.saved_tensors
         ln_w, ln_b, proj = ctx.p
         b, N, d = x.shape

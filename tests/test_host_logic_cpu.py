@@ -109,8 +109,11 @@ def _gather_worker(rank, world, port, ret):
     class FakeOpt:                                                       # what attach_grad_sync needs
         class arena:
             grad = torch.full((10,), float(rank + 1))
+            early_numel = 6                                              # [0,6) early region, [6,10) late (ViT) region
         grad_sync, grad_scale = None, 1.0
+    from leccr_amd import ops
     opt = attach_grad_sync(FakeOpt)
+    ops.on_late_backward_start()                                         # what the first ViT backward node triggers
     opt.grad_sync()
     ok &= torch.allclose(FakeOpt.arena.grad * opt.grad_scale, torch.full((10,), 1.5))   # mean over the 2 ranks
     ret[rank] = bool(ok)
