@@ -42,19 +42,25 @@ struct FP {
 
 // Stage a [64 rows][64 bf16] tile (rows clamped to n_rows-1) from `base` (row stride ld elements) into LDS.
 // LDS image: row r at byte r*128, physical 16-byte chunk = logical chunk ^ (r & 7)  (swizzle on the SOURCE address).
+template <int NT>
 __device__ __forceinline__ void stage_tile64(const bf16_t* __restrict__ base, int64_t ld, int64_t row0, int64_t n_rows,
                                              unsigned char* lds) {
     const int tid = threadIdx.x;
     // wave-uniform in an SGPR: otherwise hipcc wraps every global_load_lds in a waterfall loop (M0 must be uniform)
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int slot = i * 256 + tid;
+    for (int i = 0; i < 512 / NT; ++i) {
+        const int slot = i * NT + tid;
         const int row = slot >> 3, pc = slot & 7, lc = pc ^ (row & 7);
+        // rows past the end re-read a valid row (their products are masked or never stored): one tile back, so
+        // the lanes of a load keep distinct cache lines (clamping all of them to the last row is several times slower)
         int64_t r = row0 + row;
-        r = r < n_rows ? r : n_rows - 1;
+        if (r >= n_rows) {
+            const int64_t back = r - (n_rows < BT ? n_rows : BT);
+            r = back >= 0 && back < n_rows ? back : n_rows - 1;
+        }
         const bf16_t* src = base + r * ld + lc * 8;
-        unsigned char* dst = lds + (size_t)(i * 256 + wave_base) * 16;
+        unsigned char* dst = lds + (size_t)(i * NT + wave_base) * 16;
         __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(dst), 16, 0, 0);
     }
 }
@@ -101,17 +107,126 @@ __device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_ex
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 
-// --------------------------------------------------------------------------------------------------- forward
-// LDS per stage: K tile | V tile | bias[64] f32
-constexpr int FWD_STAGE = 2 * TILE_BYTES + 256;
+// ---- LDS fragment reads through inline asm (same reason as gemm256.hip: a C++ LDS load makes the waitcnt pass drain
+// the in-flight global_load_lds prefetch with vmcnt(0) in the middle of the tile loop).  Completion is an explicit
+// lgkmcnt wait whose "+v" operands tie the consumers behind it.
+typedef __attribute__((ext_vector_type(4))) int int4_t;
+typedef __attribute__((ext_vector_type(2))) int int2_t;
 
-template <bool DROP>
-__global__ __launch_bounds__(256) void flash_fwd_kernel(FP p) {
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
+    int4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return __builtin_bit_cast(bf16x8, v);
+}
+// transposed pair: 4 rows at IMM and the 4 rows 16 further down (IMM + 2048)
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_tr16_pair(uint32_t addr) {
+    int2_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(IMM));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(IMM + 2048));
+    int4_t v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+#define LDS_WAIT8(N, f)                                                                                         \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")"                                                                    \
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]))
+
+__device__ __forceinline__ uint32_t lds_u32(const void* p) {
+    return (uint32_t)(size_t)(__attribute__((address_space(3))) const unsigned char*)p;
+}
+
+// per-lane byte offsets inside a 64x64 bf16 tile image
+struct TileLane {
+    uint32_t row[2];   // frag_rows: k-step 0 / 1 of rows (lane & 15); + 2048 per 16 rows
+    uint32_t tr[4];    // frag_tr:   columns 16*nd..; + 4096 per k-step, + 2048 for the second row group
+};
+__device__ __forceinline__ TileLane make_tile_lane(int lane) {
+    TileLane t;
+    const int i = lane & 15, h = lane >> 4;
+    t.row[0] = i * 128 + ((h ^ (i & 7)) << 4);
+    t.row[1] = t.row[0] ^ 64;
+    const int rowA = 4 * h + (i >> 2), sw = rowA & 7, c1 = (i & 3) >> 1, inb = (i & 1) * 8;
+#pragma unroll
+    for (int nd = 0; nd < 4; ++nd) t.tr[nd] = rowA * 128 + (((2 * nd + c1) ^ sw) << 4) + inb;
+    return t;
+}
+
+// cross-row-group reductions without LDS: lanes l, l^16, l^32, l^48 hold the 4 partials of one query
+__device__ __forceinline__ float xg_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float xg_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// Bit 4j + r set: key key0 + 16j + r is masked (beyond Lk, or flagged in the key-padding mask).  The mask bytes are
+// fetched with clamped indices and no branches, so the 16 loads are in flight together.
+__device__ __forceinline__ uint32_t dead_keys(const uint8_t* km, int64_t Lk, int64_t key0, bool ragged) {
+    uint32_t dead = 0;
+    if (km) {
+        uint8_t mk[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t key = key0 + 16 * j + r;
+                mk[4 * j + r] = km[key < Lk ? key : Lk - 1];
+            }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dead |= mk[i] ? (1u << i) : 0u;
+    }
+    if (ragged) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dead |= key0 + 16 * j + r >= Lk ? (1u << (4 * j + r)) : 0u;
+    }
+    return dead;
+}
+
+// Per-thread source pointers of the 16-byte chunks this thread stages for tile 0 (full tiles only add 64*ld rows).
+template <int NT>
+struct StageSrc {
+    const bf16_t* p[512 / NT];
+    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld) {
+#pragma unroll
+        for (int i = 0; i < 512 / NT; ++i) {
+            const int slot = i * NT + (int)threadIdx.x;
+            const int row = slot >> 3, lc = (slot & 7) ^ (row & 7);
+            p[i] = base + row * ld + lc * 8;
+        }
+    }
+    __device__ __forceinline__ void issue(int64_t elem_off, unsigned char* lds) const {
+        const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
+#pragma unroll
+        for (int i = 0; i < 512 / NT; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p[i] + elem_off), LDS_PTR(lds + (size_t)(i * NT + wave_base) * 16), 16, 0, 0);
+    }
+};
+
+// --------------------------------------------------------------------------------------------------- forward
+// LDS per stage: K tile | V tile
+constexpr int FWD_STAGE = 2 * TILE_BYTES;
+
+// NW waves per block, each owning 16 query rows; all share the streamed K/V tiles.
+// Per tile and wave: barrier -> issue DMA of tile t+1 -> 8 K-row reads -> 8 MFMA (S^T) -> issue the 16 transposed V
+// reads -> softmax on the VALU (hides the V reads; scale folded into the exp2 argument, row statistics by
+// permlane swaps) -> 8 MFMA (O^T).  The softmax VALU work (~2.5x the MFMA cycles at head 64) is the bound.
+template <bool DROP, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
+    constexpr int BQ = NW * 16, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
-    const int64_t nqb = (p.Lq + BT - 1) / BT;
+    const int64_t nqb = (p.Lq + BQ - 1) / BQ;
     const int64_t bh = blockIdx.x / nqb, b = bh / p.heads, head = bh % p.heads;
-    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BT;
+    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BQ;
     const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
     const bf16_t* Vp = p.v + b * p.Lk * p.ldv + head * HD;
@@ -125,60 +240,91 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FP p) {
     f32x4 o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m = -INFINITY, l = 0.f;
+    float m = -INFINITY, l = 0.f;       // m: running max of the RAW scores (scale applied inside exp2)
 
-    const int ntiles = (int)((p.Lk + BT - 1) / BT);
+    const int ntiles = (int)((p.Lk + BT - 1) / BT), nfull = (int)(p.Lk / BT);
+    StageSrc<NT> ksrc, vsrc;
+    ksrc.init(Kp, p.ldk);
+    vsrc.init(Vp, p.ldv);
     auto stage = [&](int t) {
         unsigned char* st = smem + (t & 1) * FWD_STAGE;
-        stage_tile64(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
-        stage_tile64(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
-        if (tid < BT) {
-            const int64_t key = (int64_t)t * BT + tid;
-            const bool ok = key < p.Lk && !(km && km[key]);
-            reinterpret_cast<float*>(st + 2 * TILE_BYTES)[tid] = ok ? 0.f : -INFINITY;
+        if (t < nfull) {
+            ksrc.issue((int64_t)t * BT * p.ldk, st);
+            vsrc.issue((int64_t)t * BT * p.ldv, st + TILE_BYTES);
+        } else {                                   // ragged last tile: rows clamped to Lk - 1
+            stage_tile64<NT>(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
+            stage_tile64<NT>(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
         }
     };
+    const TileLane tl = make_tile_lane(lane);
+    const uint32_t smem_off = lds_u32(smem);
+    // retire the Q fragment loads here, visibly to the compiler's waitcnt pass: otherwise it covers their first use
+    // inside the loop with a vmcnt(0) that also drains the prefetch
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) expcnt(7) lgkmcnt(15)
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]));
     stage(0);
     for (int t = 0; t < ntiles; ++t) {
-        const unsigned char* st = smem + (t & 1) * FWD_STAGE;
-        __syncthreads();
+        const uint32_t kt = smem_off + (t & 1) * FWD_STAGE, vt = kt + TILE_BYTES;
+        // key mask bytes of this tile are fetched BEFORE the next tile's DMA is issued, so waiting for them does
+        // not wait for the prefetch (vmcnt retires in order)
+        const bool ragged = t >= nfull;
+        const uint32_t dead = dead_keys(km, p.Lk, (int64_t)t * BT + 4 * h4, ragged);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
-        const unsigned char* kt = st;
-        const unsigned char* vt = st + TILE_BYTES;
-        const float* bias = reinterpret_cast<const float*>(st + 2 * TILE_BYTES);
+        bf16x8 kf[8];
+        kf[0] = lds_b128<0>(kt + tl.row[0]);
+        kf[1] = lds_b128<0>(kt + tl.row[1]);
+        kf[2] = lds_b128<2048>(kt + tl.row[0]);
+        kf[3] = lds_b128<2048>(kt + tl.row[1]);
+        kf[4] = lds_b128<4096>(kt + tl.row[0]);
+        kf[5] = lds_b128<4096>(kt + tl.row[1]);
+        kf[6] = lds_b128<6144>(kt + tl.row[0]);
+        kf[7] = lds_b128<6144>(kt + tl.row[1]);
+        LDS_WAIT8(0, kf);
         f32x4 s[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[j] = MFMA16(frag_rows(kt, j * 16, 0, lane), qf[0], s[j]);
-            s[j] = MFMA16(frag_rows(kt, j * 16, 1, lane), qf[1], s[j]);
+            s[j] = MFMA16(kf[2 * j], qf[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+            s[j] = MFMA16(kf[2 * j + 1], qf[1], s[j]);
         }
         // s[j][r] = <k[key = 16j + 4*h4 + r], q[query = lane&15]>
+        bf16x8 vf[8];                               // vf[2nd + ks]
+        vf[0] = lds_tr16_pair<0>(vt + tl.tr[0]);
+        vf[1] = lds_tr16_pair<4096>(vt + tl.tr[0]);
+        vf[2] = lds_tr16_pair<0>(vt + tl.tr[1]);
+        vf[3] = lds_tr16_pair<4096>(vt + tl.tr[1]);
+        vf[4] = lds_tr16_pair<0>(vt + tl.tr[2]);
+        vf[5] = lds_tr16_pair<4096>(vt + tl.tr[2]);
+        vf[6] = lds_tr16_pair<0>(vt + tl.tr[3]);
+        vf[7] = lds_tr16_pair<4096>(vt + tl.tr[3]);
+        if (dead) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (dead & (1u << (4 * j + r))) s[j][r] = -INFINITY;
+        }
         float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 bj = *reinterpret_cast<const f32x4*>(bias + j * 16 + 4 * h4);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[j][r] = s[j][r] * c + bj[r];
-                mx = fmaxf(mx, s[j][r]);
-            }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[j][r]);
+        mx = xg_max(mx);
         const float mn = fmaxf(m, mx);
         const float msafe = mn == -INFINITY ? 0.f : mn;       // every key so far masked: keep exp2 arguments finite
-        const float alpha = exp2_fast(m - msafe);              // m = -inf -> 0
+        const float mc = msafe * c;
+        const float alpha = exp2_fast(m * c - mc);             // m = -inf -> 0
         float rs = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                s[j][r] = exp2_fast(s[j][r] - msafe);
+                s[j][r] = exp2_fast(__builtin_fmaf(s[j][r], c, -mc));
                 rs += s[j][r];
             }
-        rs += __shfl_xor(rs, 16, 64);
-        rs += __shfl_xor(rs, 32, 64);
+        rs = xg_sum(rs);
         l = l * alpha + rs;
         m = mn;
         if constexpr (DROP) {   // dropout on the probabilities that enter PV; the normaliser l keeps the undropped sum
@@ -191,10 +337,12 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FP p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] *= alpha;
         const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
+        __builtin_amdgcn_sched_barrier(0);          // keep the softmax above the wait: it is what hides the V reads
+        LDS_WAIT8(0, vf);
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) {
-            o[nd] = MFMA16(frag_tr(vt, nd * 16, 0, lane), pf0, o[nd]);
-            o[nd] = MFMA16(frag_tr(vt, nd * 16, 1, lane), pf1, o[nd]);
+            o[nd] = MFMA16(vf[2 * nd], pf0, o[nd]);
+            o[nd] = MFMA16(vf[2 * nd + 1], pf1, o[nd]);
         }
     }
     // o[nd][r] = O^T[d = 16 nd + 4 h4 + r][query = lane&15]
@@ -204,21 +352,27 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(FP p) {
         bf16_t* op = p.out + (b * p.Lq + qi) * p.ldo + head * HD;
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) store4(op + nd * 16 + 4 * h4, o[nd] * inv);
-        if (h4 == 0) p.lse[(b * p.heads + head) * p.Lq + qi] = l > 0.f ? (m + __log2f(l)) * kLn2 : INFINITY;
+        if (h4 == 0) p.lse[(b * p.heads + head) * p.Lq + qi] = l > 0.f ? (m * c + __log2f(l)) * kLn2 : INFINITY;
     }
 }
 
 // --------------------------------------------------------------------------------------------------- backward: dK, dV
 // LDS per stage: Q tile | dO tile | lse2[64] | delta[64]
 constexpr int DKV_STAGE = 2 * TILE_BYTES + 512;
+// dq kernel, LDS per stage: K tile | V tile | bias[64] f32
+constexpr int DQ_STAGE = 2 * TILE_BYTES + 256;
 
-template <bool DROP>
-__global__ __launch_bounds__(256) void flash_dkdv_kernel(FP p) {
+#ifndef DKDV_WPE
+#define DKDV_WPE 4
+#endif
+template <bool DROP, int NW>
+__global__ __launch_bounds__(NW * 64, DKDV_WPE) void flash_dkdv_kernel(FP p) {
+    constexpr int BQ = NW * 16, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
-    const int64_t nkb = (p.Lk + BT - 1) / BT;
+    const int64_t nkb = (p.Lk + BQ - 1) / BQ;
     const int64_t bh = blockIdx.x / nkb, b = bh / p.heads, head = bh % p.heads;
-    const int64_t k0 = (int64_t)(blockIdx.x % nkb) * BT + wave * 16;      // this wave's 16 keys
+    const int64_t k0 = (int64_t)(blockIdx.x % nkb) * BQ + wave * 16;      // this wave's 16 keys
     const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
     const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
@@ -244,8 +398,8 @@ __global__ __launch_bounds__(256) void flash_dkdv_kernel(FP p) {
     const int ntiles = (int)((p.Lq + BT - 1) / BT);
     auto stage = [&](int t) {
         unsigned char* st = smem + (t & 1) * DKV_STAGE;
-        stage_tile64(Q, p.ldq, (int64_t)t * BT, p.Lq, st);
-        stage_tile64(DO, p.ldo, (int64_t)t * BT, p.Lq, st + TILE_BYTES);
+        stage_tile64<NT>(Q, p.ldq, (int64_t)t * BT, p.Lq, st);
+        stage_tile64<NT>(DO, p.ldo, (int64_t)t * BT, p.Lq, st + TILE_BYTES);
         if (tid < BT) {
             const int64_t qi = (int64_t)t * BT + tid;
             float* f = reinterpret_cast<float*>(st + 2 * TILE_BYTES);
@@ -308,13 +462,14 @@ __global__ __launch_bounds__(256) void flash_dkdv_kernel(FP p) {
 }
 
 // --------------------------------------------------------------------------------------------------- backward: dQ
-template <bool DROP>
-__global__ __launch_bounds__(256) void flash_dq_kernel(FP p) {
+template <bool DROP, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void flash_dq_kernel(FP p) {
+    constexpr int BQ = NW * 16, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
-    const int64_t nqb = (p.Lq + BT - 1) / BT;
+    const int64_t nqb = (p.Lq + BQ - 1) / BQ;
     const int64_t bh = blockIdx.x / nqb, b = bh / p.heads, head = bh % p.heads;
-    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BT + wave * 16;
+    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BQ + wave * 16;
     const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
     const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
@@ -337,9 +492,9 @@ __global__ __launch_bounds__(256) void flash_dq_kernel(FP p) {
     for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntiles = (int)((p.Lk + BT - 1) / BT);
     auto stage = [&](int t) {
-        unsigned char* st = smem + (t & 1) * FWD_STAGE;
-        stage_tile64(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
-        stage_tile64(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
+        unsigned char* st = smem + (t & 1) * DQ_STAGE;
+        stage_tile64<NT>(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
+        stage_tile64<NT>(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
         if (tid < BT) {
             const int64_t key = (int64_t)t * BT + tid;
             const bool ok = key < p.Lk && !(km && km[key]);
@@ -348,7 +503,7 @@ __global__ __launch_bounds__(256) void flash_dq_kernel(FP p) {
     };
     stage(0);
     for (int t = 0; t < ntiles; ++t) {
-        const unsigned char* st = smem + (t & 1) * FWD_STAGE;
+        const unsigned char* st = smem + (t & 1) * DQ_STAGE;
         __syncthreads();
         if (t + 1 < ntiles) stage(t + 1);
         const unsigned char* kt = st;
@@ -434,9 +589,15 @@ int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* l
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)o; p.lse = lse;
     p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk; p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv;
     p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
-    dim3 grid((unsigned)(cdiv(D.Lq, BT) * D.b * D.heads));
-    if (D.dropout) hipLaunchKernelGGL(flash_fwd_kernel<true>, grid, dim3(256), 2 * FWD_STAGE, st, p);
-    else hipLaunchKernelGGL(flash_fwd_kernel<false>, grid, dim3(256), 2 * FWD_STAGE, st, p);
+    if (D.Lq > 64) {        // 8 waves = 128 query rows per block
+        dim3 grid((unsigned)(cdiv(D.Lq, 128) * D.b * D.heads));
+        if (D.dropout) hipLaunchKernelGGL((flash_fwd_kernel<true, 8>), grid, dim3(512), 2 * FWD_STAGE, st, p);
+        else hipLaunchKernelGGL((flash_fwd_kernel<false, 8>), grid, dim3(512), 2 * FWD_STAGE, st, p);
+    } else {
+        dim3 grid((unsigned)(cdiv(D.Lq, 64) * D.b * D.heads));
+        if (D.dropout) hipLaunchKernelGGL((flash_fwd_kernel<true, 4>), grid, dim3(256), 2 * FWD_STAGE, st, p);
+        else hipLaunchKernelGGL((flash_fwd_kernel<false, 4>), grid, dim3(256), 2 * FWD_STAGE, st, p);
+    }
     return check_launch("flash_fwd");
 }
 
@@ -454,14 +615,24 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
     const int64_t rows = D.b * D.heads * D.Lq;
     hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, (const bf16_t*)o,
                        (const bf16_t*)dout, delta, D.heads, D.Lq, D.ldo, rows);
-    const dim3 gk((unsigned)(cdiv(D.Lk, BT) * D.b * D.heads)), gq((unsigned)(cdiv(D.Lq, BT) * D.b * D.heads));
+#define LAUNCH_BWD(DR, NWK, NWQ)                                                                                     \
+    do {                                                                                                            \
+        hipLaunchKernelGGL((flash_dkdv_kernel<DR, NWK>), dim3((unsigned)(cdiv(D.Lk, NWK * 16) * D.b * D.heads)),    \
+                           dim3(NWK * 64), 2 * DKV_STAGE, st, p);                                                   \
+        hipLaunchKernelGGL((flash_dq_kernel<DR, NWQ>), dim3((unsigned)(cdiv(D.Lq, NWQ * 16) * D.b * D.heads)),      \
+                           dim3(NWQ * 64), 2 * DQ_STAGE, st, p);                                                    \
+    } while (0)
+    #ifdef DKDV_NW4
+    const bool bigk = false, bigq = D.Lq > 64;
+#else
+    const bool bigk = D.Lk > 64, bigq = D.Lq > 64;
+#endif
     if (D.dropout) {
-        hipLaunchKernelGGL(flash_dkdv_kernel<true>, gk, dim3(256), 2 * DKV_STAGE, st, p);
-        hipLaunchKernelGGL(flash_dq_kernel<true>, gq, dim3(256), 2 * FWD_STAGE, st, p);
+        if (bigk && bigq) LAUNCH_BWD(true, 8, 8); else if (bigk) LAUNCH_BWD(true, 8, 4); else if (bigq) LAUNCH_BWD(true, 4, 8); else LAUNCH_BWD(true, 4, 4);
     } else {
-        hipLaunchKernelGGL(flash_dkdv_kernel<false>, gk, dim3(256), 2 * DKV_STAGE, st, p);
-        hipLaunchKernelGGL(flash_dq_kernel<false>, gq, dim3(256), 2 * FWD_STAGE, st, p);
+        if (bigk && bigq) LAUNCH_BWD(false, 8, 8); else if (bigk) LAUNCH_BWD(false, 8, 4); else if (bigq) LAUNCH_BWD(false, 4, 8); else LAUNCH_BWD(false, 4, 4);
     }
+#undef LAUNCH_BWD
     return check_launch("flash_bwd");
 }
 

@@ -30,6 +30,7 @@
 // TRANS = 0: C = A[M,K] B[N,K]^T (forward and dX).   TRANS = 1: C += A[K,M]^T B[K,N] (weight gradients, split-K with
 // f32 atomics).  Same epilogues as gemm.hip.
 #include "common.h"
+#include <type_traits>
 
 namespace leccr {
 namespace g256 {
@@ -249,6 +250,10 @@ __device__ __forceinline__ bf16x8 rd(const LaneAddr& la, uint32_t nt_base0, uint
 #define STAMP(i) do {} while (0)
 #endif
 #define WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// Lanes of one wave exchange data through LDS without a barrier (LDS operations of a wave execute in order); for the
+// compiler these are unsynchronised accesses, so without a fence it may reuse an earlier read of the same address or
+// sink the read into the writers' exec-masked block (seen in the .s: wrong results).  A compiler-only memory barrier.
+#define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
 
 // FLAGS (compile-time epilogue shape, so the per-item epilogue carries no runtime branches):
 constexpr int F_ATOMIC = 1, F_RES = 2, F_AUXOUT = 4, F_ACCUM = 8;
@@ -257,7 +262,8 @@ template <int TRANS, typename TC, int EPI, int FLAGS>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
     constexpr bool ATOMIC = (FLAGS & F_ATOMIC) != 0;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // in an SGPR: everything derived from it is scalar
     const int wr = wave >> 2, wc = wave & 3;          // wr doubles as the ping-pong group
 
     // persistent item assignment: XCD x (= block id % 8, a speed-only assumption) owns a contiguous range of items
@@ -403,15 +409,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             const bool has_bias = a.bias != nullptr && (!ATOMIC || cur.split == 0);
             // bias is consumed unconditionally right here: a load whose only uses sit behind the tail-tile branches would
             // stay "pending" in hipcc's scoreboard across the loop back edge and cost a vmcnt(0) in the K loop
+            f32x4 bv[4];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                f32x4 bvn = {0.f, 0.f, 0.f, 0.f};
+                bv[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (has_bias) {                      // uniform branch; tail columns read a clamped (valid) address
                     const int64_t nc = nb + ni * 16 < a.N ? nb + ni * 16 : a.N - 4;
-                    bvn = load4(a.bias + nc);
+                    bv[ni] = load4(a.bias + nc);
                 }
+            }
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = acc[ni][mi] * a.alpha + bvn;
+            for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    acc[ni][mi] = acc[ni][mi] * a.alpha + bv[ni];
+                    asm volatile("" : "+v"(acc[ni][mi]));      // here, not sunk into the store branches
+                }
             }
             if constexpr (sizeof(TC) == 2 && !ATOMIC) {
                 // bf16 output: transpose each 16 x 64 accumulator strip through a wave-private LDS buffer (8 rows at a
@@ -420,51 +433,124 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                 // instead of 8-byte pieces scattered over 16 rows (the store tail was issue-bound: 15-17 % of a
                 // K = 768 item, in-kernel stamps).
                 float* stg = reinterpret_cast<float*>(smem + 2 * SLOT) + wave * (8 * 68);
-                const int rrow = lane >> 3, rcol = (lane & 7) * 8;             // read side: row 0-7, 8 columns
+                // lane-derived epilogue addresses are re-derived per item from an opaque copy of the lane id: hoisted out
+                // of the item loop they live across the K loop, get spilled, and their reloads cost a scratch round
+                // trip each (with a vmcnt(0)) in every epilogue
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                const int rrow = lane_e >> 3, rcol = (lane_e & 7) * 8;         // read side: row 0-7, 8 columns
                 const int64_t ncol = n0 + wc * 64 + rcol;
                 const bool col_ok = interior || ncol < a.N;                    // N % 8 == 0 (dispatcher)
+                // The epilogue operand that is READ (the saved pre-activation of a d-activation epilogue, else the
+                // residual) is fetched for all 16 strips up front: loaded inside the strip loop each strip pays a full
+                // memory round trip (16 serial latencies per item - 30-40 % of a K = 768 item).
+                constexpr bool NEED_AUX = EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU;
+                constexpr bool PRE_RES = (FLAGS & F_RES) != 0 && !NEED_AUX;
+                // Two copies of the strip loop: interior tiles (the hot case) carry no per-lane bounds checks, so the
+                // code is straight-line and hipcc's waits on the prefetched operand are counted (vmcnt(N)); with the
+                // checks' branches in the way every strip waited vmcnt(0), i.e. for the previous strip's store as well.
+                auto strips = [&](auto check_tag) {
+                    constexpr bool CHECK = decltype(check_tag)::value;
+                    bf16x8 pre[(NEED_AUX || PRE_RES) ? 8 : 1];       // 8 strips per batch: two round trips per item
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
+                    for (int mi = 0; mi < 8; ++mi) {
+                        if constexpr (NEED_AUX || PRE_RES) {
+                            if ((mi & 3) == 0) {
+                                const bf16_t* pbase = reinterpret_cast<const bf16_t*>(NEED_AUX ? a.aux : a.residual);
+                                const int64_t pld = NEED_AUX ? a.ldaux : a.ldr;
 #pragma unroll
-                    for (int hp = 0; hp < 2; ++hp) {
-                        if (((lane & 15) >> 3) == hp) {
-#pragma unroll
-                            for (int ni = 0; ni < 4; ++ni)
-                                *reinterpret_cast<f32x4*>(stg + (lane & 7) * 68 + ni * 16 + (lane >> 4) * 4) = acc[ni][mi];
-                        }
-                        f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rrow * 68 + rcol);
-                        f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rrow * 68 + rcol + 4);
-                        const int64_t m = m0 + wr * 128 + mi * 16 + hp * 8 + rrow;
-                        if (!(col_ok && (interior || m < a.M))) continue;
-                        bf16_t* crow = reinterpret_cast<bf16_t*>(a.C) + m * a.ldc + ncol;
-                        if constexpr ((FLAGS & F_AUXOUT) != 0) {
-                            bf16_t* orow = reinterpret_cast<bf16_t*>(a.aux_out) + m * a.ldc + ncol;
-                            bf16x8 pv;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { pv[r] = (bf16_t)v0[r]; pv[4 + r] = (bf16_t)v1[r]; }
-                            *reinterpret_cast<bf16x8*>(orow) = pv;
-                        }
-                        if constexpr (EPI != LECCR_EPI_NONE) {
-                            f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
-                            if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) {
-                                const bf16x8 xv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.aux) + m * a.ldaux + ncol);
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) { x0[r] = (float)xv[r]; x1[r] = (float)xv[4 + r]; }
+                                for (int i = 0; i < 8; ++i) {
+                                    const int64_t m = m0 + wr * 128 + (mi + (i >> 1)) * 16 + (i & 1) * 8 + rrow;
+                                    const bool ok = !CHECK || (col_ok && m < a.M);
+                                    pre[i] = *reinterpret_cast<const bf16x8*>(pbase + (ok ? m * pld + ncol : 0));
+                                }
                             }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) { v0[r] = apply_epi<EPI>(v0[r], x0[r]); v1[r] = apply_epi<EPI>(v1[r], x1[r]); }
                         }
-                        if constexpr ((FLAGS & F_RES) != 0) {
-                            const bf16x8 rv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.residual) + m * a.ldr + ncol);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { v0[r] += (float)rv[r]; v1[r] += (float)rv[4 + r]; }
+                        for (int hp = 0; hp < 2; ++hp) {
+                            if (((lane & 15) >> 3) == hp) {
+#pragma unroll
+                                for (int ni = 0; ni < 4; ++ni)
+                                    *reinterpret_cast<f32x4*>(stg + (lane & 7) * 68 + ni * 16 + (lane >> 4) * 4) = acc[ni][mi];
+                            }
+                            WAVE_LDS_FENCE();        // the reads below fetch what OTHER lanes of the wave just wrote
+                            f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rrow * 68 + rcol);
+                            f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rrow * 68 + rcol + 4);
+                            WAVE_LDS_FENCE();
+                            const int64_t m = m0 + wr * 128 + mi * 16 + hp * 8 + rrow;
+                            const bool ok = !CHECK || (col_ok && m < a.M);
+                            bf16_t* crow = reinterpret_cast<bf16_t*>(a.C) + m * a.ldc + ncol;
+                            if constexpr ((FLAGS & F_AUXOUT) != 0) {
+                                bf16_t* orow = reinterpret_cast<bf16_t*>(a.aux_out) + m * a.ldc + ncol;
+                                bf16x8 pv;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { pv[r] = (bf16_t)v0[r]; pv[4 + r] = (bf16_t)v1[r]; }
+                                if (ok) *reinterpret_cast<bf16x8*>(orow) = pv;
+                            }
+                            if constexpr (EPI != LECCR_EPI_NONE) {
+                                f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
+                                if constexpr (NEED_AUX) {
+                                    const bf16x8 xv = pre[(mi & 3) * 2 + hp];
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) { x0[r] = (float)xv[r]; x1[r] = (float)xv[4 + r]; }
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { v0[r] = apply_epi<EPI>(v0[r], x0[r]); v1[r] = apply_epi<EPI>(v1[r], x1[r]); }
+                            }
+                            if constexpr ((FLAGS & F_RES) != 0) {
+                                bf16x8 rv;
+                                if constexpr (PRE_RES) rv = pre[(mi & 3) * 2 + hp];
+                                else rv = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(a.residual) + (ok ? m * a.ldr + ncol : 0));
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { v0[r] += (float)rv[r]; v1[r] += (float)rv[4 + r]; }
+                            }
+                            bf16x8 ov;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { ov[r] = (bf16_t)v0[r]; ov[4 + r] = (bf16_t)v1[r]; }
+                            if (ok) *reinterpret_cast<bf16x8*>(crow) = ov;
                         }
-                        bf16x8 ov;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { ov[r] = (bf16_t)v0[r]; ov[4 + r] = (bf16_t)v1[r]; }
-                        *reinterpret_cast<bf16x8*>(crow) = ov;
                     }
-                }
+                };
+                if (interior) strips(std::false_type{});
+                else strips(std::true_type{});
+            } else if constexpr (ATOMIC) {
+                // split-K partial sums: the same wave-private LDS transpose, read back with the COLUMN on the lane, so one
+                // global_atomic_add_f32 covers 256 contiguous bytes of one row.  (Straight from the accumulator layout an
+                // instruction touches 16 rows x 4 scattered dwords: 4x the 64-byte atomic requests at the memory side,
+                // whose ~1.3 TB/s is what bounds this tail - and a pending bias load made hipcc wait vmcnt(0), i.e. for
+                // the previous atomics' acknowledgement, before every group.)
+                float* stg = reinterpret_cast<float*>(smem + 2 * SLOT) + wave * (8 * 68);
+                int lane_e = lane;
+                asm volatile("" : "+v"(lane_e));
+                const int64_t ncol = n0 + wc * 64 + lane_e;
+                float* cbase = reinterpret_cast<float*>(a.C) + ncol;
+                auto strips = [&](auto check_tag) {
+                    constexpr bool CHECK = decltype(check_tag)::value;
+                    const bool col_ok = !CHECK || ncol < a.N;
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp) {
+                            if (((lane & 15) >> 3) == hp) {
+#pragma unroll
+                                for (int ni = 0; ni < 4; ++ni)
+                                    *reinterpret_cast<f32x4*>(stg + (lane & 7) * 68 + ni * 16 + (lane >> 4) * 4) = acc[ni][mi];
+                            }
+                            WAVE_LDS_FENCE();        // the reads below fetch what OTHER lanes of the wave just wrote
+                            float v[8];
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] = stg[r * 68 + lane_e];
+                            WAVE_LDS_FENCE();
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const int64_t m = m0 + wr * 128 + mi * 16 + hp * 8 + r;      // wave-uniform
+                                if (col_ok && (!CHECK || m < a.M)) atomicAdd(cbase + m * a.ldc, v[r]);
+                            }
+                        }
+                    }
+                };
+                if (interior) strips(std::false_type{});
+                else strips(std::true_type{});
             } else {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
@@ -478,11 +564,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                 for (int ni = 0; ni < 4; ++ni) {
                     if (!interior && nb + ni * 16 >= a.N) continue;
                     f32x4 v = acc[ni][mi];
-                    if constexpr (ATOMIC) {
-                        float* cp = reinterpret_cast<float*>(crow) + ni * 16;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) atomicAdd(cp + r, v[r]);
-                    } else {
+                    {
                         if constexpr ((FLAGS & F_AUXOUT) != 0) store4(orow + ni * 16, v);
                         if constexpr (EPI != LECCR_EPI_NONE) {
                             f32x4 ax = {0.f, 0.f, 0.f, 0.f};

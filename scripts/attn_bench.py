@@ -2,7 +2,8 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from leccr_amd import kernels as K
+from leccr_amd import kernels as K, _lib
+if os.environ.get('LECCR_LIB'): _lib.LIB_PATH = os.environ['LECCR_LIB']
 dev = 'cuda'
 def t(f, reps=5):
     for _ in range(2): f()
@@ -12,7 +13,7 @@ def t(f, reps=5):
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
-SH = [('vit %d' % L, 256, 12, L) for L in (512, 560, 576, 577, 578, 592, 608, 640)] if os.environ.get('SWEEP') else [('vit 577', 256, 12, 577), ('vit 576', 256, 12, 576), ('bert 32', 512, 12, 32), ('bert 64', 256, 12, 64)]
+SH = [('warm', 256, 12, 576)] + [('vit %d' % L, 256, 12, L) for L in (512, 560, 576, 577, 578, 592, 608, 640)] if os.environ.get('SWEEP') else [('warm', 256, 12, 576), ('vit 577', 256, 12, 577), ('vit 576', 256, 12, 576), ('bert 32', 512, 12, 32), ('bert 64', 256, 12, 64)]
 for name, b, h, L in SH:
     d = h * 64
     qkv = torch.randn(b, L, 3 * d, device=dev).bfloat16()
