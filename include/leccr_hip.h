@@ -111,7 +111,8 @@ int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, co
 int leccr_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                    int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
                    int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream);
-/* dq/dk/dv have the same strides as q/k/v.  delta [b, heads, Lq] f32 is workspace (rowsum(dO*O)). */
+/* dq/dk/dv have the same strides as q/k/v.  delta is f32 workspace of 2 * b * heads * roundup(Lq, 64) elements
+ * (per-query row constants of the backward: -rowsum(dO*O) and -lse/scale, padded so tiles load without clamping). */
 int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                    const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, int64_t b, int64_t heads,
                    int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,

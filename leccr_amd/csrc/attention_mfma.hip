@@ -36,6 +36,7 @@ struct FP {
     const float* delta;  // bwd
     const uint8_t* kmask;
     int64_t heads, Lq, Lk, ldq, ldk, ldv, ldo;
+    int64_t Lqp, nbh;    // bwd: padded query count and b*heads of the row-constant workspace
     float scale;
     DropCfg drop;
 };
@@ -356,20 +357,63 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
     }
 }
 
-// --------------------------------------------------------------------------------------------------- backward: dK, dV
-// LDS per stage: Q tile | dO tile | lse2[64] | delta[64]
-constexpr int DKV_STAGE = 2 * TILE_BYTES + 512;
-// dq kernel, LDS per stage: K tile | V tile | bias[64] f32
-constexpr int DQ_STAGE = 2 * TILE_BYTES + 256;
+// --------------------------------------------------------------------------------------------------- backward
+// Row constants (written by flash_rowconst_kernel into the `delta` workspace, [2][b*heads][Lqp], Lqp = Lq rounded up
+// to 64): rc0[q] = -rowsum(dO*O), rc1[q] = -lse[q] / scale; rows q >= Lq hold 0 and -inf.  They are the INITIAL
+// ACCUMULATORS of the dP and S products: S' = Q.K - lse/scale leaves p = exp2(c*S') (no subtraction, no row maximum;
+// -inf rows give p = 0) and dP' = dO.V - delta leaves dS = p*dP' directly.
+template <int IMM>
+__device__ __forceinline__ f32x4 lds_b128_f32(uint32_t addr) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return v;
+}
+#define LDS_WAIT4F(N, f) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]))
 
-#ifndef DKDV_WPE
-#define DKDV_WPE 4
-#endif
+__device__ __forceinline__ void glds_row64(const float* src, unsigned char* lds) {      // 64 floats, one per lane
+    __builtin_amdgcn_global_load_lds(GLB_PTR(src + (threadIdx.x & 63)), LDS_PTR(lds), 4, 0, 0);
+}
+
+#define READ_ROWS8(f, base)                          \
+    do {                                             \
+        f[0] = lds_b128<0>((base) + tl.row[0]);      \
+        f[1] = lds_b128<0>((base) + tl.row[1]);      \
+        f[2] = lds_b128<2048>((base) + tl.row[0]);   \
+        f[3] = lds_b128<2048>((base) + tl.row[1]);   \
+        f[4] = lds_b128<4096>((base) + tl.row[0]);   \
+        f[5] = lds_b128<4096>((base) + tl.row[1]);   \
+        f[6] = lds_b128<6144>((base) + tl.row[0]);   \
+        f[7] = lds_b128<6144>((base) + tl.row[1]);   \
+    } while (0)
+#define READ_TR8(f, base)                                  \
+    do {                                                   \
+        f[0] = lds_tr16_pair<0>((base) + tl.tr[0]);        \
+        f[1] = lds_tr16_pair<4096>((base) + tl.tr[0]);     \
+        f[2] = lds_tr16_pair<0>((base) + tl.tr[1]);        \
+        f[3] = lds_tr16_pair<4096>((base) + tl.tr[1]);     \
+        f[4] = lds_tr16_pair<0>((base) + tl.tr[2]);        \
+        f[5] = lds_tr16_pair<4096>((base) + tl.tr[2]);     \
+        f[6] = lds_tr16_pair<0>((base) + tl.tr[3]);        \
+        f[7] = lds_tr16_pair<4096>((base) + tl.tr[3]);     \
+    } while (0)
+
+// ---- dK, dV.  Block = NW waves x 16 keys of one (batch, head); sweeps 64-query tiles.
+// LDS per stage: Q tile | dO tile | rc1[64] | rc0[64]
+constexpr int DKV_STAGE = 2 * TILE_BYTES + 512;
+
+// Per tile and wave, one 32-register fragment buffer is refilled four times; each refill is issued right behind the
+// MFMAs that consumed the previous contents, so the reads run under those MFMAs (and under the partner waves' work):
+//   Q rows -> S' (8 MFMA) | dO rows -> dP' (8) | dO^T -> [p on the VALU] -> dV^T (8) | Q^T -> [dS on the VALU] -> dK^T (8)
+// Occupancy: the backward kernels want ~150 registers; forcing 128 (4 waves/SIMD) spills inside the tile loop and
+// runs 1.4-1.9x slower, so they are built for 3 waves/SIMD and launched as 4-wave blocks (3 blocks per CU;
+// measured best of {4-wave, 8-wave blocks} x {2, 3, 4 waves/SIMD} at L = 577).
+constexpr int BWD_WPE = 3;
 template <bool DROP, int NW>
-__global__ __launch_bounds__(NW * 64, DKDV_WPE) void flash_dkdv_kernel(FP p) {
+__global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dkdv_kernel(FP p) {
     constexpr int BQ = NW * 16, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, h4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t nkb = (p.Lk + BQ - 1) / BQ;
     const int64_t bh = blockIdx.x / nkb, b = bh / p.heads, head = bh % p.heads;
     const int64_t k0 = (int64_t)(blockIdx.x % nkb) * BQ + wave * 16;      // this wave's 16 keys
@@ -377,8 +421,8 @@ __global__ __launch_bounds__(NW * 64, DKDV_WPE) void flash_dkdv_kernel(FP p) {
     const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
     const bf16_t* Vp = p.v + b * p.Lk * p.ldv + head * HD;
-    const float* lse = p.lse + (b * p.heads + head) * p.Lq;
-    const float* dl = p.delta + (b * p.heads + head) * p.Lq;
+    const float* rc0 = p.delta + bh * p.Lqp;
+    const float* rc1 = p.delta + (p.nbh + bh) * p.Lqp;
     const float c = p.scale * kLog2e;
 
     bf16x8 kf[2], vf[2];
@@ -387,7 +431,8 @@ __global__ __launch_bounds__(NW * 64, DKDV_WPE) void flash_dkdv_kernel(FP p) {
     vf[0] = frag_global(Vp, p.ldv, k0, p.Lk, 0, lane);
     vf[1] = frag_global(Vp, p.ldv, k0, p.Lk, 1, lane);
     const int64_t key = k0 + (lane & 15);
-    const float kbias = (key < p.Lk && !(p.kmask && p.kmask[b * p.Lk + key])) ? 0.f : -INFINITY;
+    const bool dead = !(key < p.Lk && !(p.kmask && p.kmask[b * p.Lk + (key < p.Lk ? key : 0)]));
+    const bool any_dead = __ballot(dead) != 0ull;          // wave-uniform: only ragged / padded key blocks pay for it
 
     f32x4 dk[4], dv[4];
 #pragma unroll
@@ -395,59 +440,109 @@ __global__ __launch_bounds__(NW * 64, DKDV_WPE) void flash_dkdv_kernel(FP p) {
         dk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const int ntiles = (int)((p.Lq + BT - 1) / BT);
+    const int ntiles = (int)((p.Lq + BT - 1) / BT), nfull = (int)(p.Lq / BT);
+    StageSrc<NT> qsrc, dosrc;
+    qsrc.init(Q, p.ldq);
+    dosrc.init(DO, p.ldo);
     auto stage = [&](int t) {
         unsigned char* st = smem + (t & 1) * DKV_STAGE;
-        stage_tile64<NT>(Q, p.ldq, (int64_t)t * BT, p.Lq, st);
-        stage_tile64<NT>(DO, p.ldo, (int64_t)t * BT, p.Lq, st + TILE_BYTES);
-        if (tid < BT) {
-            const int64_t qi = (int64_t)t * BT + tid;
-            float* f = reinterpret_cast<float*>(st + 2 * TILE_BYTES);
-            f[tid] = qi < p.Lq ? lse[qi] * kLog2e : INFINITY;      // +inf -> P = 0 for rows past Lq
-            f[64 + tid] = qi < p.Lq ? dl[qi] : 0.f;
+        if (t < nfull) {
+            qsrc.issue((int64_t)t * BT * p.ldq, st);
+            dosrc.issue((int64_t)t * BT * p.ldo, st + TILE_BYTES);
+        } else {
+            stage_tile64<NT>(Q, p.ldq, (int64_t)t * BT, p.Lq, st);
+            stage_tile64<NT>(DO, p.ldo, (int64_t)t * BT, p.Lq, st + TILE_BYTES);
+        }
+        if (wave == 0) {                            // the workspace rows are padded to 64: no clamping
+            glds_row64(rc1 + (int64_t)t * BT, st + 2 * TILE_BYTES);
+            glds_row64(rc0 + (int64_t)t * BT, st + 2 * TILE_BYTES + 256);
         }
     };
+    const TileLane tl = make_tile_lane(lane);
+    const uint32_t smem_off = lds_u32(smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // retire the K/V fragment loads visibly (see flash_fwd_kernel)
+    asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(vf[0]), "+v"(vf[1]));
     stage(0);
     for (int t = 0; t < ntiles; ++t) {
-        const unsigned char* st = smem + (t & 1) * DKV_STAGE;
-        __syncthreads();
+        const uint32_t qt = smem_off + (t & 1) * DKV_STAGE, dot = qt + TILE_BYTES;
+        const uint32_t rcl = dot + TILE_BYTES + 16 * h4;          // rc1[16 j + 4 h4 ..] at + 64 j; rc0 256 B further
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
-        const unsigned char* qt = st;
-        const unsigned char* dot = st + TILE_BYTES;
-        const float* l2 = reinterpret_cast<const float*>(st + 2 * TILE_BYTES);
-        f32x4 s[4], dp[4];
+        // s[j][r], dp[j][r]: query = 16 j + 4 h4 + r of the tile, key = lane & 15
+        f32x4 s[4], dp[4], dl[4];
+        bf16x8 fa[8];
+        s[0] = lds_b128_f32<0>(rcl); s[1] = lds_b128_f32<64>(rcl); s[2] = lds_b128_f32<128>(rcl); s[3] = lds_b128_f32<192>(rcl);
+        if constexpr (DROP) {
+            dl[0] = lds_b128_f32<256>(rcl); dl[1] = lds_b128_f32<320>(rcl); dl[2] = lds_b128_f32<384>(rcl); dl[3] = lds_b128_f32<448>(rcl);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[j] = MFMA16(frag_rows(qt, j * 16, 0, lane), kf[0], s[j]);
-            s[j] = MFMA16(frag_rows(qt, j * 16, 1, lane), kf[1], s[j]);
-            dp[j] = MFMA16(frag_rows(dot, j * 16, 0, lane), vf[0], dp[j]);
-            dp[j] = MFMA16(frag_rows(dot, j * 16, 1, lane), vf[1], dp[j]);
+            for (int j = 0; j < 4; ++j) dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        } else {
+            dp[0] = lds_b128_f32<256>(rcl); dp[1] = lds_b128_f32<320>(rcl); dp[2] = lds_b128_f32<384>(rcl); dp[3] = lds_b128_f32<448>(rcl);
         }
-        // s[j][r]: query = 16 j + 4 h4 + r, key = lane&15
+        READ_ROWS8(fa, qt);
+        LDS_WAIT4F(0, s);
+        LDS_WAIT8(0, fa);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 lj = *reinterpret_cast<const f32x4*>(l2 + j * 16 + 4 * h4);
-            const f32x4 dj = *reinterpret_cast<const f32x4*>(l2 + 64 + j * 16 + 4 * h4);
+            s[j] = MFMA16(fa[2 * j], kf[0], s[j]);
+            s[j] = MFMA16(fa[2 * j + 1], kf[1], s[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        READ_ROWS8(fa, dot);
+        if constexpr (DROP) LDS_WAIT4F(0, dl); else LDS_WAIT4F(0, dp);
+        LDS_WAIT8(0, fa);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pr = exp2_fast(s[j][r] * c + kbias - lj[r]);
-                float dm = 1.f;
-                if constexpr (DROP)
-                    dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + (int64_t)t * BT + 16 * j + 4 * h4 + r) * p.Lk + key));
-                s[j][r] = pr * dm;                               // dV uses the dropped probabilities
-                dp[j][r] = pr * (dm * dp[j][r] - dj[r]);
-            }
+        for (int j = 0; j < 4; ++j) {
+            dp[j] = MFMA16(fa[2 * j], vf[0], dp[j]);
+            dp[j] = MFMA16(fa[2 * j + 1], vf[1], dp[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        READ_TR8(fa, dot);                          // dO^T, under the p computation
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[j][r] = exp2_fast(s[j][r] * c);
+        if (any_dead) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[j][r] = dead ? 0.f : s[j][r];
+        }
+        if constexpr (DROP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + (int64_t)t * BT + 16 * j + 4 * h4 + r) * p.Lk + key));
+                    dp[j][r] = s[j][r] * (dm * dp[j][r] + dl[j][r]);       // dl = -delta
+                    s[j][r] *= dm;                                         // dV uses the dropped probabilities
+                }
         }
         const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
-        const bf16x8 df0 = pack2(dp[0], dp[1]), df1 = pack2(dp[2], dp[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_WAIT8(0, fa);
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) {
-            dv[nd] = MFMA16(frag_tr(dot, nd * 16, 0, lane), pf0, dv[nd]);
-            dv[nd] = MFMA16(frag_tr(dot, nd * 16, 1, lane), pf1, dv[nd]);
-            dk[nd] = MFMA16(frag_tr(qt, nd * 16, 0, lane), df0, dk[nd]);
-            dk[nd] = MFMA16(frag_tr(qt, nd * 16, 1, lane), df1, dk[nd]);
+            dv[nd] = MFMA16(fa[2 * nd], pf0, dv[nd]);
+            dv[nd] = MFMA16(fa[2 * nd + 1], pf1, dv[nd]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        READ_TR8(fa, qt);                           // Q^T, under the dS computation
+        if constexpr (!DROP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[j][r] *= s[j][r];
+        }
+        const bf16x8 df0 = pack2(dp[0], dp[1]), df1 = pack2(dp[2], dp[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_WAIT8(0, fa);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) {
+            dk[nd] = MFMA16(fa[2 * nd], df0, dk[nd]);
+            dk[nd] = MFMA16(fa[2 * nd + 1], df1, dk[nd]);
         }
     }
     if (key < p.Lk) {
@@ -461,12 +556,17 @@ __global__ __launch_bounds__(NW * 64, DKDV_WPE) void flash_dkdv_kernel(FP p) {
     }
 }
 
-// --------------------------------------------------------------------------------------------------- backward: dQ
+// ---- dQ.  Block = NW waves x 16 queries; sweeps 64-key tiles.  LDS per stage: K tile | V tile.
+//   K rows -> S'^T (8 MFMA, accumulators start at rc1[query]) | V rows -> dP'^T (8, start at rc0[query]) |
+//   K^T -> [p, dS on the VALU] -> dQ^T (8)
+constexpr int DQ_STAGE = 2 * TILE_BYTES;
+
 template <bool DROP, int NW>
-__global__ __launch_bounds__(NW * 64, 4) void flash_dq_kernel(FP p) {
+__global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dq_kernel(FP p) {
     constexpr int BQ = NW * 16, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, h4 = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t nqb = (p.Lq + BQ - 1) / BQ;
     const int64_t bh = blockIdx.x / nqb, b = bh / p.heads, head = bh % p.heads;
     const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BQ + wave * 16;
@@ -483,60 +583,97 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_dq_kernel(FP p) {
     dof[0] = frag_global(DO, p.ldo, q0, p.Lq, 0, lane);
     dof[1] = frag_global(DO, p.ldo, q0, p.Lq, 1, lane);
     const int64_t qi = q0 + (lane & 15);
-    const int64_t qc = qi < p.Lq ? qi : p.Lq - 1;
-    const float lse2 = qi < p.Lq ? p.lse[(b * p.heads + head) * p.Lq + qc] * kLog2e : INFINITY;
-    const float dlt = p.delta[(b * p.heads + head) * p.Lq + qc];
+    const int64_t qc = qi < p.Lqp ? qi : p.Lqp - 1;           // padded rows hold (0, -inf): p = 0 for queries >= Lq
+    float nd_ = p.delta[bh * p.Lqp + qc];                      // -delta
+    float nl_ = p.delta[(p.nbh + bh) * p.Lqp + qc];            // -lse / scale
+    if (qi >= p.Lqp) { nd_ = 0.f; nl_ = -INFINITY; }
 
     f32x4 dq[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int ntiles = (int)((p.Lk + BT - 1) / BT);
+    const int ntiles = (int)((p.Lk + BT - 1) / BT), nfull = (int)(p.Lk / BT);
+    StageSrc<NT> ksrc, vsrc;
+    ksrc.init(Kp, p.ldk);
+    vsrc.init(Vp, p.ldv);
     auto stage = [&](int t) {
         unsigned char* st = smem + (t & 1) * DQ_STAGE;
-        stage_tile64<NT>(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
-        stage_tile64<NT>(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
-        if (tid < BT) {
-            const int64_t key = (int64_t)t * BT + tid;
-            const bool ok = key < p.Lk && !(km && km[key]);
-            reinterpret_cast<float*>(st + 2 * TILE_BYTES)[tid] = ok ? 0.f : -INFINITY;
+        if (t < nfull) {
+            ksrc.issue((int64_t)t * BT * p.ldk, st);
+            vsrc.issue((int64_t)t * BT * p.ldv, st + TILE_BYTES);
+        } else {
+            stage_tile64<NT>(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
+            stage_tile64<NT>(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
         }
     };
+    const TileLane tl = make_tile_lane(lane);
+    const uint32_t smem_off = lds_u32(smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(dof[0]), "+v"(dof[1]), "+v"(nd_), "+v"(nl_));
     stage(0);
     for (int t = 0; t < ntiles; ++t) {
-        const unsigned char* st = smem + (t & 1) * DQ_STAGE;
-        __syncthreads();
+        const uint32_t kt = smem_off + (t & 1) * DQ_STAGE, vt = kt + TILE_BYTES;
+        const uint32_t deadk = dead_keys(km, p.Lk, (int64_t)t * BT + 4 * h4, t >= nfull);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
-        const unsigned char* kt = st;
-        const unsigned char* vt = st + TILE_BYTES;
-        const float* bias = reinterpret_cast<const float*>(st + 2 * TILE_BYTES);
+        // s[j][r], dp[j][r]: key = 16 j + 4 h4 + r of the tile, query = lane & 15
         f32x4 s[4], dp[4];
+        bf16x8 fa[8];
+        READ_ROWS8(fa, kt);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            s[j] = MFMA16(frag_rows(kt, j * 16, 0, lane), qf[0], s[j]);
-            s[j] = MFMA16(frag_rows(kt, j * 16, 1, lane), qf[1], s[j]);
-            dp[j] = MFMA16(frag_rows(vt, j * 16, 0, lane), dof[0], dp[j]);
-            dp[j] = MFMA16(frag_rows(vt, j * 16, 1, lane), dof[1], dp[j]);
+            s[j] = f32x4{nl_, nl_, nl_, nl_};
+            dp[j] = f32x4{nd_, nd_, nd_, nd_};
         }
-        // s[j][r]: key = 16 j + 4 h4 + r, query = lane&15
+        LDS_WAIT8(0, fa);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 bj = *reinterpret_cast<const f32x4*>(bias + j * 16 + 4 * h4);
+            s[j] = MFMA16(fa[2 * j], qf[0], s[j]);
+            s[j] = MFMA16(fa[2 * j + 1], qf[1], s[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        READ_ROWS8(fa, vt);
+        LDS_WAIT8(0, fa);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pr = exp2_fast(s[j][r] * c + bj[r] - lse2);
-                float dm = 1.f;
-                if constexpr (DROP)
-                    dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + qi) * p.Lk + (int64_t)t * BT + 16 * j + 4 * h4 + r));
-                dp[j][r] = pr * (dm * dp[j][r] - dlt);
-            }
+        for (int j = 0; j < 4; ++j) {
+            dp[j] = MFMA16(fa[2 * j], dof[0], dp[j]);
+            dp[j] = MFMA16(fa[2 * j + 1], dof[1], dp[j]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        READ_TR8(fa, kt);                           // K^T, under the p / dS computation
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[j][r] = exp2_fast(s[j][r] * c);
+        if (deadk) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (deadk & (1u << (4 * j + r))) s[j][r] = 0.f;
+        }
+        if constexpr (DROP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + qi) * p.Lk + (int64_t)t * BT + 16 * j + 4 * h4 + r));
+                    dp[j][r] = s[j][r] * (dm * (dp[j][r] - nd_) + nd_);      // dP' = dP - delta was accumulated
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dp[j][r] *= s[j][r];
         }
         const bf16x8 df0 = pack2(dp[0], dp[1]), df1 = pack2(dp[2], dp[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_WAIT8(0, fa);
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd) {
-            dq[nd] = MFMA16(frag_tr(kt, nd * 16, 0, lane), df0, dq[nd]);
-            dq[nd] = MFMA16(frag_tr(kt, nd * 16, 1, lane), df1, dq[nd]);
+            dq[nd] = MFMA16(fa[2 * nd], df0, dq[nd]);
+            dq[nd] = MFMA16(fa[2 * nd + 1], df1, dq[nd]);
         }
     }
     if (qi < p.Lq) {
@@ -546,23 +683,31 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_dq_kernel(FP p) {
     }
 }
 
-// delta[b, h, q] = sum_d dO * O
-__global__ __launch_bounds__(256) void flash_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                          float* __restrict__ delta, int64_t heads, int64_t Lq,
-                                                          int64_t ldo, int64_t total) {
-    // 16 lanes per (b, h, q) row: 4 elements each
-    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 4;
-    const int sub = threadIdx.x & 15;
+// Row constants of the backward: rc0[bh][q] = -sum_d dO*O, rc1[bh][q] = -lse/scale, q < Lqp (padding: 0, -inf).
+// 8 lanes per (b, h, q) row, 16 bytes of O and dO each.
+__global__ __launch_bounds__(256) void flash_rowconst_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                             const float* __restrict__ lse, float* __restrict__ rc,
+                                                             int64_t heads, int64_t Lq, int64_t Lqp, int64_t ldo,
+                                                             int64_t nbh, float inv_scale) {
+    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;       // over nbh * Lqp
+    const int sub = threadIdx.x & 7;
+    const int64_t total = nbh * Lqp;
+    const int64_t bh = row / Lqp, qi = row % Lqp;
+    const bool live = row < total && qi < Lq;
     float s = 0.f;
-    if (row < total) {
-        const int64_t qi = row % Lq, head = (row / Lq) % heads, b = row / (Lq * heads);
-        const int64_t off = (b * Lq + qi) * ldo + head * HD + sub * 4;
-        const f32x4 a = load4(o + off), g = load4(dout + off);
-        s = a[0] * g[0] + a[1] * g[1] + a[2] * g[2] + a[3] * g[3];
+    if (live) {
+        const int64_t b = bh / heads, head = bh % heads;
+        const int64_t off = (b * Lq + qi) * ldo + head * HD + sub * 8;
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + off), g = *reinterpret_cast<const bf16x8*>(dout + off);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += (float)a[i] * (float)g[i];
     }
 #pragma unroll
-    for (int w = 8; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
-    if (row < total && sub == 0) delta[row] = s;
+    for (int w = 4; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
+    if (row < total && sub == 0) {
+        rc[row] = live ? -s : 0.f;
+        rc[total + row] = live ? -lse[bh * Lq + qi] * inv_scale : -INFINITY;
+    }
 }
 
 template <typename KFn>
@@ -612,9 +757,11 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
     p.dout = (const bf16_t*)dout; p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv;
     p.lse = const_cast<float*>(lse); p.delta = delta; p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk;
     p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv; p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
-    const int64_t rows = D.b * D.heads * D.Lq;
-    hipLaunchKernelGGL(flash_delta_kernel, dim3((unsigned)cdiv(rows * 16, 256)), dim3(256), 0, st, (const bf16_t*)o,
-                       (const bf16_t*)dout, delta, D.heads, D.Lq, D.ldo, rows);
+    p.Lqp = cdiv(D.Lq, BT) * BT;
+    p.nbh = D.b * D.heads;
+    hipLaunchKernelGGL(flash_rowconst_kernel, dim3((unsigned)cdiv(p.nbh * p.Lqp * 8, 256)), dim3(256), 0, st,
+                       (const bf16_t*)o, (const bf16_t*)dout, lse, delta, D.heads, D.Lq, p.Lqp, D.ldo, p.nbh,
+                       sqrtf((float)HD));
 #define LAUNCH_BWD(DR, NWK, NWQ)                                                                                     \
     do {                                                                                                            \
         hipLaunchKernelGGL((flash_dkdv_kernel<DR, NWK>), dim3((unsigned)(cdiv(D.Lk, NWK * 16) * D.b * D.heads)),    \
@@ -622,11 +769,7 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
         hipLaunchKernelGGL((flash_dq_kernel<DR, NWQ>), dim3((unsigned)(cdiv(D.Lq, NWQ * 16) * D.b * D.heads)),      \
                            dim3(NWQ * 64), 2 * DQ_STAGE, st, p);                                                    \
     } while (0)
-    #ifdef DKDV_NW4
-    const bool bigk = false, bigq = D.Lq > 64;
-#else
-    const bool bigk = D.Lk > 64, bigq = D.Lq > 64;
-#endif
+    const bool bigk = false, bigq = false;      // 4-wave blocks (see BWD_WPE)
     if (D.dropout) {
         if (bigk && bigq) LAUNCH_BWD(true, 8, 8); else if (bigk) LAUNCH_BWD(true, 8, 4); else if (bigq) LAUNCH_BWD(true, 4, 8); else LAUNCH_BWD(true, 4, 4);
     } else {

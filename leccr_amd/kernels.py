@@ -111,7 +111,8 @@ def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None
     dk = torch.empty_strided(k.shape, k.stride(), device=q.device, dtype=q.dtype) if dk is None else dk
     dv = torch.empty_strided(v.shape, v.stride(), device=q.device, dtype=q.dtype) if dv is None else dv
     assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
-    delta = torch.empty_like(lse)
+    # workspace: two rows of constants per (b, head, query), queries padded to a multiple of 64 (see leccr_hip.h)
+    delta = torch.empty(2 * b * heads * ((Lq + 63) // 64 * 64), dtype=torch.float32, device=q.device)
     check(lib().leccr_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(kmask), ptr(dq), ptr(dk),
                                ptr(dv), ptr(delta), b, heads, Lq, Lk, hd, q.stride(1), k.stride(1), v.stride(1),
                                o.stride(1), dtype_code(q), float(drop_p), int(seed), stream()), 'leccr_attn_bwd')
