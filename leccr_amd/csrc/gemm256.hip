@@ -255,6 +255,16 @@ __device__ __forceinline__ bf16x8 rd(const LaneAddr& la, uint32_t nt_base0, uint
 // sink the read into the writers' exec-masked block (seen in the .s: wrong results).  A compiler-only memory barrier.
 #define WAVE_LDS_FENCE() asm volatile("" ::: "memory")
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+#define ON(n, stmt) if constexpr (i == (n)) { stmt; }
+
+
 // FLAGS (compile-time epilogue shape, so the per-item epilogue carries no runtime branches):
 constexpr int F_ATOMIC = 1, F_RES = 2, F_AUXOUT = 4, F_ACCUM = 8;
 
@@ -267,9 +277,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
     const int wr = wave >> 2, wc = wave & 3;          // wr doubles as the ping-pong group
 
     // persistent item assignment: XCD x (= block id % 8, a speed-only assumption) owns a contiguous range of items
-#ifdef LECCR_G256_STAMPS
-    const unsigned long long blk_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int G = gridDim.x, bid = blockIdx.x;
     int first_item, stride, n_mine;
     if ((G & 7) == 0) {
@@ -296,37 +303,68 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
     const uint32_t smem_off = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // wave-uniform LDS destination of this wave's DMA pieces (M0): must be an SGPR or hipcc emits a waterfall loop
     const uint32_t wave_off = smem_off + (uint32_t)__builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63) * 16u;
-    Cursor cB;                                         // prefetch position: K-tile t+1 in the prologue, then t+2
+    Cursor cB;                                         // prefetch position (see the schedule below)
     Cursor cur;
     cur.j = 0; cur.kt = 0;
     decode<TRANS>(a, first_item, stride, cur);
     cB = cur;
-    advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);
 
-    // prologue: K-tiles 0 and 1 (8 + 8 pieces); vmcnt(8) retires tile 0, publish
-    issue_half<TRANS, 0>(a, so, cur, 0, wave_off);
-    issue_half<TRANS, 1>(a, so, cur, 0, wave_off);
-    issue_half<TRANS, 2>(a, so, cur, 0, wave_off);
-    issue_half<TRANS, 3>(a, so, cur, 0, wave_off);
-    issue_half<TRANS, 2>(a, so, cB, SLOT, wave_off);
-    issue_half<TRANS, 3>(a, so, cB, SLOT, wave_off);
-    issue_half<TRANS, 0>(a, so, cB, SLOT, wave_off);
-    issue_half<TRANS, 1>(a, so, cB, SLOT, wave_off);
-    advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);        // cB -> t+2
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    SEG_BARRIER();
-    if (wr == 1) SEG_BARRIER();                        // group 1 runs one segment behind group 0
+    if constexpr (TRANS == 1) {
+        // v2 schedule (see the K loop below): K-tiles 0 and 1 up front, group 1 one segment behind group 0
+        advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);
+        // prologue: K-tiles 0 and 1 (8 + 8 pieces); vmcnt(8) retires tile 0, publish
+        issue_half<TRANS, 0>(a, so, cur, 0, wave_off);
+        issue_half<TRANS, 1>(a, so, cur, 0, wave_off);
+        issue_half<TRANS, 2>(a, so, cur, 0, wave_off);
+        issue_half<TRANS, 3>(a, so, cur, 0, wave_off);
+        issue_half<TRANS, 2>(a, so, cB, SLOT, wave_off);
+        issue_half<TRANS, 3>(a, so, cB, SLOT, wave_off);
+        issue_half<TRANS, 0>(a, so, cB, SLOT, wave_off);
+        issue_half<TRANS, 1>(a, so, cB, SLOT, wave_off);
+        advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);        // cB -> t+2
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        SEG_BARRIER();
+        if (wr == 1) SEG_BARRIER();                        // group 1 runs one segment behind group 0
+    } else {
+        // prologue: K-tiles 0 and 1 (8 + 8 pieces); vmcnt(8) retires K-tile 0
+        issue_half<TRANS, 0>(a, so, cB, 0, wave_off);
+        issue_half<TRANS, 1>(a, so, cB, 0, wave_off);
+        issue_half<TRANS, 2>(a, so, cB, 0, wave_off);
+        issue_half<TRANS, 3>(a, so, cB, 0, wave_off);
+        advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);        // cB -> K-tile 1
+        issue_half<TRANS, 0>(a, so, cB, SLOT, wave_off);
+        issue_half<TRANS, 1>(a, so, cB, SLOT, wave_off);
+        issue_half<TRANS, 2>(a, so, cB, SLOT, wave_off);
+        issue_half<TRANS, 3>(a, so, cB, SLOT, wave_off);
+        advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);        // cB -> K-tile 2
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        SEG_BARRIER();
+    }
 
-#ifdef LECCR_G256_STAMPS
-    unsigned long long stamp_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
-#endif
-    const LaneAddr la = make_lane_addr(lane);
+    LaneAddr la = make_lane_addr(lane);
     // wave-uniform pieces of the fragment addresses: this wave's A half, its B half and its 64-row window inside it
     const uint32_t offA = smem_off + wr * HALF;
     const uint32_t offB = smem_off + (2 + (wc >> 1)) * HALF;
     const uint32_t bwin_nt = (wc & 1) * 64 * 128;          // NT: + 64 rows of 128 B
-    const uint32_t bx = la.tx ^ ((wc & 1) * 4 * 32);        // TN: the window is 4 column blocks of 32 B
+    const uint32_t bxs = (wc & 1) * 4 * 32;                 // TN: the window is 4 column blocks of 32 B
+#define bx (la.tx ^ bxs)
+
+    // Fragment registers: A rows 0-63 / 64-127 of the wave's half, B rows 0-31 / 32-63 of its window.
+    bf16x8 aLo[4][2], aHi[4][2], bL[2][2], bH[2][2];
+#define RD_A(S, ROW0, KS) rd<TRANS, ROW0, KS>(la, la.nt[0] + offA + (S), la.nt[1] + offA + (S), la.tbase + offA + (S), la.tx)
+#define RD_B(S, ROW0, KS) rd<TRANS, ROW0, KS>(la, la.nt[0] + offB + bwin_nt + (S), la.nt[1] + offB + bwin_nt + (S), la.tbase + offB + (S), bx)
+#define TIE4(f) "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1])
+#define TIE8(f) "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]), "+v"(f[2][0]), "+v"(f[2][1]), "+v"(f[3][0]), "+v"(f[3][1])
+    // first fragments of a K-tile outside the steady state: A rows 0-63 and the k-step-0 fragments of B rows 0-31
+    auto first_frags = [&](uint32_t slot) {
+        aLo[0][0] = RD_A(slot, 0, 0); aLo[0][1] = RD_A(slot, 0, 1); aLo[1][0] = RD_A(slot, 16, 0); aLo[1][1] = RD_A(slot, 16, 1);
+        aLo[2][0] = RD_A(slot, 32, 0); aLo[2][1] = RD_A(slot, 32, 1); aLo[3][0] = RD_A(slot, 48, 0); aLo[3][1] = RD_A(slot, 48, 1);
+        bL[0][0] = RD_B(slot, 0, 0); bL[1][0] = RD_B(slot, 16, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : TIE8(aLo), "+v"(bL[0][0]), "+v"(bL[1][0]));
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (TRANS == 0) first_frags(0);
+
     int t = 0;                                         // global K-tile counter of this block's stream (slot parity)
     for (int j = 0; j < n_mine; ++j) {
         f32x4 acc[4][8];                               // [ni][mi]
@@ -334,6 +372,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < 8; ++q) acc[i][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        if constexpr (TRANS == 1) {
+        // ---- v2 schedule (weight gradients, TN): LOAD / COMPUTE segments alternating between the two waves of a SIMD.
+        // (The software-pipelined NT schedule below needs 96 fragment registers; the transposed reads return register
+        //  PAIRS and the allocator spills ~80 registers inside the K loop with it - measured 3x slower.)
         bf16x8 af[4][2], b0v[2][2], b1v[2][2];
 
 #define MMA_QUAD(BF, NI0, MI0)                                                                                       \
@@ -352,53 +395,147 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             const uint32_t a0 = la.nt[0] + offA + so_, a1 = la.nt[1] + offA + so_, at = la.tbase + offA + so_;
             const uint32_t b0 = la.nt[0] + offB + so_ + bwin_nt, b1 = la.nt[1] + offB + so_ + bwin_nt;
             const uint32_t bt = la.tbase + offB + so_;
-#define RD_A(ROW0, KS) rd<TRANS, ROW0, KS>(la, a0, a1, at, la.tx)
-#define RD_B(ROW0, KS) rd<TRANS, ROW0, KS>(la, b0, b1, bt, bx)
+#define RD2_A(ROW0, KS) rd<TRANS, ROW0, KS>(la, a0, a1, at, la.tx)
+#define RD2_B(ROW0, KS) rd<TRANS, ROW0, KS>(la, b0, b1, bt, bx)
 
             // ---- L1: A rows 0-63 + B rows 0-31 (12 reads, no DMA) | C(0,0)
-            b0v[0][0] = RD_B(0, 0); b0v[0][1] = RD_B(0, 1); b0v[1][0] = RD_B(16, 0); b0v[1][1] = RD_B(16, 1);
-            af[0][0] = RD_A(0, 0); af[0][1] = RD_A(0, 1); af[1][0] = RD_A(16, 0); af[1][1] = RD_A(16, 1);
-            af[2][0] = RD_A(32, 0); af[2][1] = RD_A(32, 1); af[3][0] = RD_A(48, 0); af[3][1] = RD_A(48, 1);
+            b0v[0][0] = RD2_B(0, 0); b0v[0][1] = RD2_B(0, 1); b0v[1][0] = RD2_B(16, 0); b0v[1][1] = RD2_B(16, 1);
+            af[0][0] = RD2_A(0, 0); af[0][1] = RD2_A(0, 1); af[1][0] = RD2_A(16, 0); af[1][1] = RD2_A(16, 1);
+            af[2][0] = RD2_A(32, 0); af[2][1] = RD2_A(32, 1); af[3][0] = RD2_A(48, 0); af[3][1] = RD2_A(48, 1);
             WAIT_LDS();
-            STAMP(0);
             SEG_BARRIER();
-            STAMP(1);
             MMA_QUAD(b0v, 0, 0);
-            STAMP(2);
             SEG_BARRIER();
-            STAMP(3);
 
             // ---- L2: B rows 32-63 (4 reads; last read of this wave column's B half) | C(0,1)
-            b1v[0][0] = RD_B(32, 0); b1v[0][1] = RD_B(32, 1); b1v[1][0] = RD_B(48, 0); b1v[1][1] = RD_B(48, 1);
+            b1v[0][0] = RD2_B(32, 0); b1v[0][1] = RD2_B(32, 1); b1v[1][0] = RD2_B(48, 0); b1v[1][1] = RD2_B(48, 1);
             WAIT_LDS();
             SEG_BARRIER();
             MMA_QUAD(b1v, 2, 0);
             SEG_BARRIER();
 
             // ---- L3: A rows 64-127 (8 reads; last read of this wave row's A half) + issue B(t+2) | C(1,1)
-            af[0][0] = RD_A(64, 0); af[0][1] = RD_A(64, 1); af[1][0] = RD_A(80, 0); af[1][1] = RD_A(80, 1);
-            af[2][0] = RD_A(96, 0); af[2][1] = RD_A(96, 1); af[3][0] = RD_A(112, 0); af[3][1] = RD_A(112, 1);
+            af[0][0] = RD2_A(64, 0); af[0][1] = RD2_A(64, 1); af[1][0] = RD2_A(80, 0); af[1][1] = RD2_A(80, 1);
+            af[2][0] = RD2_A(96, 0); af[2][1] = RD2_A(96, 1); af[3][0] = RD2_A(112, 0); af[3][1] = RD2_A(112, 1);
             issue_half<TRANS, 2>(a, so, cB, so_, wave_off);
             issue_half<TRANS, 3>(a, so, cB, so_, wave_off);
             WAIT_LDS();
-            STAMP(4);
             SEG_BARRIER();
-            STAMP(5);
             MMA_QUAD(b1v, 2, 4);
             SEG_BARRIER();
-            STAMP(6);
 
             // ---- L4: no reads (B rows 0-31 are still in registers); issue A(t+2); the K-tile's one counted wait | C(1,0)
             issue_half<TRANS, 0>(a, so, cB, so_, wave_off);
             issue_half<TRANS, 1>(a, so, cB, so_, wave_off);
             advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);
-            STAMP(7);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // retires K-tile t+1 (8 loads); t+2 stays in flight
-            STAMP(8);
             SEG_BARRIER();
             MMA_QUAD(b0v, 0, 4);
             SEG_BARRIER();
-            STAMP(9);
+        }
+        } else {
+        // One K-tile = four quads of 16 MFMAs (k-step 0 of the quad's 8 accumulators, then k-step 1); every LDS read and
+        // DMA piece is issued BETWEEN MFMAs of the same wave, one per MFMA at most, from asm, in the order written
+        // (sched_barrier pins each step).  A fragment register is reloaded right after the last MFMA that needs its
+        // old contents has been ISSUED - there are no spare copies (A 64 + B 32 registers beside 128 accumulators):
+        //   Q1 (bL, aLo): reads bL[.][1](t) x2, bH(t) x4, aHi(t) x4                  (bL[.][1] awaited before k-step 1)
+        //   Q2 (bH, aLo): reads aHi(t) x4                                           -> wait; BARRIER: slot(t) is free
+        //   Q3 (bH, aHi):                                             DMA A(t+2) x4 -> vmcnt(4); BARRIER: t+1 visible
+        //   Q4 (bL, aHi): reads aLo(t+1) x8, then bL[.][0](t+1) x2    DMA B(t+2) x4 -> wait
+        // All 8 pieces of K-tile t+2 go out right after its slot is freed: the last one then has ~3 quads to land before
+        // the vmcnt wait (spread over all four quads the last pieces had < 1 quad and the wait stalled on HBM latency).
+        // (v2 alternated LOAD and COMPUTE segments between the two waves of a SIMD, 8 barriers per K-tile: its LOAD
+        //  segments - 12 ds_reads or 4 DMA pieces back to back - were 2x longer than the 256-cycle COMPUTE segments.)
+        auto quad = [&](auto ni0_tag, auto mi0_tag, bf16x8 (&bf)[2][2], bf16x8 (&af)[4][2], auto&& fill) {
+            constexpr int NI0 = decltype(ni0_tag)::value, MI0 = decltype(mi0_tag)::value;
+            static_for<0, 16>([&](auto ic) {
+                constexpr int idx = decltype(ic)::value, ks = idx >> 3, ni = (idx >> 2) & 1, mi = idx & 3;
+                acc[NI0 + ni][MI0 + mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni][ks], af[mi][ks], acc[NI0 + ni][MI0 + mi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fill(ic);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I2 = std::integral_constant<int, 2>;
+        using I4 = std::integral_constant<int, 4>;
+
+        for (int kt = 0; kt < a.nkt; ++kt, ++t) {
+            const bool last_of_item = kt + 1 == a.nkt;
+            const uint32_t sc = (t & 1) * SLOT, sn = SLOT - sc;        // this K-tile's slot, the next one's
+            // per-lane address pieces pass through an opaque asm each K-tile: the ~30 fragment addresses derived from them
+            // are then recomputed where used (1 VALU op) instead of being hoisted out of the loop and spilled
+            asm volatile("" : "+v"(la.nt[0]), "+v"(la.nt[1]), "+v"(la.tbase), "+v"(la.tx));
+            // ---- Q1
+            quad(I0{}, I0{}, bL, aLo, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ON(0, bL[0][1] = RD_B(sc, 0, 1))
+                ON(1, bL[1][1] = RD_B(sc, 16, 1))
+                ON(2, bH[0][0] = RD_B(sc, 32, 0))
+                ON(3, bH[0][1] = RD_B(sc, 32, 1))
+                ON(4, bH[1][0] = RD_B(sc, 48, 0))
+                ON(5, bH[1][1] = RD_B(sc, 48, 1))
+                ON(6, aHi[0][0] = RD_A(sc, 64, 0))
+                ON(7, aHi[0][1] = RD_A(sc, 64, 1); asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(bL[0][1]), "+v"(bL[1][1])))
+                ON(8, aHi[1][0] = RD_A(sc, 80, 0))
+                ON(9, aHi[1][1] = RD_A(sc, 80, 1))
+            });
+            asm volatile("s_waitcnt lgkmcnt(4)" : TIE4(bH));
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- Q2
+            quad(I2{}, I0{}, bH, aLo, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ON(0, aHi[2][0] = RD_A(sc, 96, 0))
+                ON(1, aHi[2][1] = RD_A(sc, 96, 1))
+                ON(2, aHi[3][0] = RD_A(sc, 112, 0))
+                ON(3, aHi[3][1] = RD_A(sc, 112, 1))
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" : TIE8(aHi));
+            SEG_BARRIER();                                                  // every wave is done reading slot(t)
+            // ---- Q3
+            quad(I2{}, I4{}, bH, aHi, [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                ON(3, (issue_half<TRANS, 0, 0, 1>(a, so, cB, sc, wave_off)))
+                ON(7, (issue_half<TRANS, 0, 1, 2>(a, so, cB, sc, wave_off)))
+                ON(11, (issue_half<TRANS, 1, 0, 1>(a, so, cB, sc, wave_off)))
+                ON(15, (issue_half<TRANS, 1, 1, 2>(a, so, cB, sc, wave_off)))
+            });
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                // this wave's pieces of K-tile t+1 have landed
+            SEG_BARRIER();                                                  // ... and everyone else's
+            // ---- Q4
+            if (!last_of_item) {
+                quad(I0{}, I4{}, bL, aHi, [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    ON(0, aLo[0][0] = RD_A(sn, 0, 0))
+                    ON(1, aLo[0][1] = RD_A(sn, 0, 1))
+                    ON(2, aLo[1][0] = RD_A(sn, 16, 0))
+                    ON(3, aLo[1][1] = RD_A(sn, 16, 1))
+                    ON(4, aLo[2][0] = RD_A(sn, 32, 0))
+                    ON(5, aLo[2][1] = RD_A(sn, 32, 1))
+                    ON(6, aLo[3][0] = RD_A(sn, 48, 0))
+                    ON(7, aLo[3][1] = RD_A(sn, 48, 1))
+                    ON(8, bL[0][0] = RD_B(sn, 0, 0))
+                    ON(9, bL[1][0] = RD_B(sn, 16, 0))
+                    ON(10, (issue_half<TRANS, 2, 0, 1>(a, so, cB, sc, wave_off)))
+                    ON(12, (issue_half<TRANS, 2, 1, 2>(a, so, cB, sc, wave_off)))
+                    ON(14, (issue_half<TRANS, 3, 0, 1>(a, so, cB, sc, wave_off)))
+                    ON(15, (issue_half<TRANS, 3, 1, 2>(a, so, cB, sc, wave_off)))
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" : TIE8(aLo), "+v"(bL[0][0]), "+v"(bL[1][0]));
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // the item's last K-tile: its epilogue needs the registers; the next item's first fragments are read after it
+                quad(I0{}, I4{}, bL, aHi, [&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    ON(3, (issue_half<TRANS, 2, 0, 1>(a, so, cB, sc, wave_off)))
+                    ON(7, (issue_half<TRANS, 2, 1, 2>(a, so, cB, sc, wave_off)))
+                    ON(11, (issue_half<TRANS, 3, 0, 1>(a, so, cB, sc, wave_off)))
+                    ON(15, (issue_half<TRANS, 3, 1, 2>(a, so, cB, sc, wave_off)))
+                });
+            }
+            advance<TRANS, 0, 3>(a, first_item, stride, n_mine, cB);        // cB -> K-tile t+3
+        }
+
         }
 
         // ---- epilogue segment of this item (the partner wave is in its last COMPUTE / first LOAD meanwhile)
@@ -582,27 +719,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             // a compiler-visible wait: every ordinary load of the epilogue is retired for hipcc's scoreboard, so the K
             // loop carries no conservative vmcnt(0) (costs the in-flight A(t+2), once per item, long landed by now)
             __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) expcnt(7) lgkmcnt(15)
-            SEG_BARRIER();
-            STAMP(10);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TRANS == 1) SEG_BARRIER();
         }
-        // move `cur` to the next item
+        // move `cur` to the next item and fetch the first fragments of its first K-tile (already visible: Q3's barrier)
         if (j + 1 < n_mine) {
             cur.j = j + 1;
             cur.kt = 0;
             decode<TRANS>(a, first_item, stride, cur);
+            if constexpr (TRANS == 0) first_frags((t & 1) * SLOT);
         }
     }
-#ifdef LECCR_G256_STAMPS
-    if (a.stamps && blockIdx.x == 17 && lane == 0 && (wave == 0 || wave == 4))
-        for (int i = 0; i < 12; ++i) a.stamps[(wave >> 2) * 12 + i] = stamp_sum[i];
-    if (a.stamps && tid == 0) {      // per-block wall-clock window (100 MHz) and XCC id
-        a.stamps[32 + blockIdx.x * 4 + 0] = blk_t0;
-        a.stamps[32 + blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
-        a.stamps[32 + blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID[3:0]
-        a.stamps[32 + blockIdx.x * 4 + 3] = first_item;
+    if constexpr (TRANS == 1) {
+        if (wr == 0) SEG_BARRIER();                    // group 0 waits out group 1's trailing segment
     }
-#endif
-    if (wr == 0) SEG_BARRIER();                        // group 0 waits out group 1's trailing segment
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches still target this block's LDS
 }
 

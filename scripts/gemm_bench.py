@@ -12,6 +12,7 @@ SH = [('qkv', 0, M, 2304, 768), ('out', 0, M, 768, 768), ('fc1', 0, M, 3072, 768
       ('bert dW fc1', 1, 3072, 768, 16384), ('sq 4096', 0, 4096, 4096, 4096), ('sq 8192', 0, 8192, 8192, 8192)]
 reps = int(os.environ.get('REPS', 5))
 from leccr_amd import _lib
+if os.environ.get('LECCR_LIB'): _lib.LIB_PATH = os.environ['LECCR_LIB']
 _lib.lib().leccr_set_gemm_variant(int(os.environ.get('VARIANT', 0)))
 print('variant', os.environ.get('VARIANT', 0))
 for name, tn, m, n, k in SH:

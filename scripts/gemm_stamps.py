@@ -3,13 +3,13 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from leccr_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libleccr_stamps.so')
+_lib.LIB_PATH = os.environ.get('LECCR_LIB', os.path.join(os.path.dirname(_lib.LIB_PATH), 'libleccr_stamps.so'))
 from leccr_amd import kernels as K
 lib = _lib.lib()
 lib.leccr_set_gemm_variant(2)
 lib.leccr_debug_set_stamps.argtypes = [C.c_void_p]
 names = ['L1 reads', 'bar', 'C00', 'bar', 'L2+C01+L3 (to L3 wait)', 'bar', 'C11+bar', 'L4 issue', 'vmcnt(8)', 'bar+C10+bar', 'epilogue', '-']
-for name, tn, m, n, k in [('NT 4096^3', 0, 4096, 4096, 4096), ('NT fc1', 0, 147712, 3072, 768), ('TN dW fc1', 1, 3072, 768, 147712), ('TN 2048^2', 1, 2048, 2048, 147712)]:
+for name, tn, m, n, k in [('NT 4096^3', 0, 4096, 4096, 4096), ('NT qkv', 0, 147712, 2304, 768), ('NT fc2', 0, 147712, 768, 3072), ('TN dW fc1', 1, 3072, 768, 147712)]:
     st = torch.zeros(32 + 256 * 4, dtype=torch.int64, device='cuda')
     lib.leccr_debug_set_stamps(st.data_ptr())
     if tn:
