@@ -145,6 +145,12 @@ def main():
         value = G * args.steps / dt
         gemm_ms, gemm_fl, gemm_n = ms[0] + ms[1], work[0] + work[1], n[0] + n[1]
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        tj = os.path.join(ROOT, 'profiles', 'r01_gemm256_hbm_traffic.json')
+        if os.path.exists(tj) and args.clip == 'ViT-B/16' and args.batch == 256 and args.dtype == 'bf16':
+            with open(tj) as fh:        # PMC counters cannot be read from inside the run: the committed rocprofv3 passes
+                tr = json.load(fh)      # of this same command (FETCH_SIZE x2 + WRITE_SIZE, per launch) are reported
+            traffic, traffic_src = round(tr['hbm_bytes_per_launch']), 'profiles/r01_gemm256_hbm_traffic.json'
         out = {
             'metric': 'image-text pairs/sec (train step)', 'value': round(value, 2), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
@@ -154,9 +160,10 @@ def main():
                        'global_batch': G, 'parallelism': f'dp{world}',
                        'step_tflops_algorithmic': round(F_PAIR_GFLOP * value / 1e3, 1) if args.clip == 'ViT-B/16' else None,
                        'losses': [round(float(l), 4) for l in losses]},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm_mfma_kernel (bf16 NT + TN weight-gradient instantiations)',
+            'roofline': {'bound': 'mfma', 'kernel': 'gemm256_kernel (bf16 256x256x64 MFMA GEMM: NT forward/dX + TN weight-gradient instantiations)',
                          'achieved': round(achieved, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                         'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': traffic_src,
                          'launches_per_step': gemm_n // max(1, args.steps),
                          'avg_launch_us': round(gemm_ms * 1e3 / max(1, gemm_n), 2),
                          'avg_launch_gflop': round(gemm_fl / max(1, gemm_n) / 1e9, 2),
