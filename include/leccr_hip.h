@@ -76,6 +76,8 @@ typedef struct leccr_gemm_params {
     int64_t ldr;
     float alpha;
     int32_t reserved;
+    float* colsum;               /* optional [N] f32: += column sums of the C written (the bias gradient when C is a
+                                    dY); currently one extra pass over C on the same stream */
 } leccr_gemm_params;
 
 int leccr_gemm(const leccr_gemm_params* p, void* stream);
@@ -87,13 +89,16 @@ int leccr_gemm(const leccr_gemm_params* p, void* stream);
  *      y = LN(x + add)); writes y (T), mean/rstd [rows] f32, and, if sum_out != NULL, x+add (T).
  * bwd: dx = LN'(dy) (+ dres if non-null), dgamma/dbeta ACCUMULATED (+=) into f32 [d] buffers.
  *      x_in must be the tensor that was normalised (x+add).
+ *      colsum_of != 0: additionally colsum[d] (f32) += column sums of dres (1) or of the dx written (2) - the bias
+ *      gradient of the Linear whose output gradient that tensor is (pre-LN blocks: dres; post-LN blocks: dx), so
+ *      the separate leccr_colsum pass over it is not needed.
  */
 int leccr_layernorm_fwd(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                         void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, int dtype,
                         void* stream);
 int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
-                        const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d, int dtype,
-                        void* stream);
+                        const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of,
+                        int64_t rows, int64_t d, int dtype, void* stream);
 
 /* ---- Attention --------------------------------------------------------------------------------------------
  * softmax(Q K^T / sqrt(hd) + key mask) V per (batch, head); no materialised score matrix.

@@ -21,7 +21,7 @@ class GemmParams(C.Structure):
     _fields_ = [('A', vp), ('B', vp), ('C', vp), ('M', i64), ('N', i64), ('K', i64), ('lda', i64), ('ldb', i64),
                 ('ldc', i64), ('ab_dtype', i32), ('c_dtype', i32), ('trans_a', i32), ('trans_b', i32), ('bias', vp),
                 ('epilogue', i32), ('accumulate', i32), ('aux', vp), ('ldaux', i64), ('aux_out', vp),
-                ('residual', vp), ('ldr', i64), ('alpha', f32), ('reserved', i32)]
+                ('residual', vp), ('ldr', i64), ('alpha', f32), ('reserved', i32), ('colsum', vp)]
 
 
 _SIGS = {
@@ -33,7 +33,7 @@ _SIGS = {
     'leccr_prof_read': ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
     'leccr_gemm': ([C.POINTER(GemmParams), vp], C.c_int),
     'leccr_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, vp], C.c_int),
-    'leccr_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),
+    'leccr_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, i64, C.c_int, vp], C.c_int),
     'leccr_attn_fwd': ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, f32, C.c_uint64, vp], C.c_int),
     'leccr_attn_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64,
                         C.c_int, f32, C.c_uint64, vp], C.c_int),

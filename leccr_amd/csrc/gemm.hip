@@ -349,6 +349,7 @@ namespace leccr {
 extern bool g_force_generic_attn;
 bool gemm256_wanted(const leccr_gemm_params& p);
 bool gemm256_legal(const leccr_gemm_params& p);
+bool gemm256_fuses_colsum(const leccr_gemm_params& p);
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
 static int g_gemm_variant = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel where legal
 }
@@ -370,6 +371,26 @@ extern "C" int leccr_set_force_generic(int on) {
     return LECCR_OK;
 }
 
+static int gemm_dispatch(const leccr_gemm_params& p, hipStream_t st, bool* colsum_fused) {
+    const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
+    if (mfma_ok(p)) {
+        ProfScope prof(p.trans_a == 0 ? PROF_GEMM_NT : PROF_GEMM_TN, flops, st);
+        if ((g_gemm_variant == 2 && gemm256_legal(p)) || (g_gemm_variant == 0 && gemm256_wanted(p))) {
+            *colsum_fused = gemm256_fuses_colsum(p);
+            return gemm256_launch(p, st);
+        }
+        if (p.trans_a == 0)
+            return p.c_dtype == LECCR_F32 ? launch_mfma<0, float>(p, st) : launch_mfma<0, bf16_t>(p, st);
+        return p.c_dtype == LECCR_F32 ? launch_mfma<1, float>(p, st) : launch_mfma<1, bf16_t>(p, st);
+    }
+    ProfScope prof(PROF_GEMM_GENERIC, flops, st);
+    if (p.ab_dtype == LECCR_F32) {
+        LECCR_REQUIRE(p.c_dtype == LECCR_F32, LECCR_EINVAL, "gemm: f32 operands need an f32 C");
+        return launch_generic<float, float>(p, st);
+    }
+    return p.c_dtype == LECCR_F32 ? launch_generic<bf16_t, float>(p, st) : launch_generic<bf16_t, bf16_t>(p, st);
+}
+
 extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     LECCR_REQUIRE(pp != nullptr, LECCR_EINVAL, "gemm: null params");
     const leccr_gemm_params& p = *pp;
@@ -384,19 +405,10 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
         LECCR_REQUIRE(p.aux != nullptr, LECCR_EINVAL, "gemm: derivative epilogue needs aux");
     if (p.M == 0 || p.N == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
-    const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
-    if (mfma_ok(p)) {
-        ProfScope prof(p.trans_a == 0 ? PROF_GEMM_NT : PROF_GEMM_TN, flops, st);
-        if ((g_gemm_variant == 2 && gemm256_legal(p)) || (g_gemm_variant == 0 && gemm256_wanted(p)))
-            return gemm256_launch(p, st);
-        if (p.trans_a == 0)
-            return p.c_dtype == LECCR_F32 ? launch_mfma<0, float>(p, st) : launch_mfma<0, bf16_t>(p, st);
-        return p.c_dtype == LECCR_F32 ? launch_mfma<1, float>(p, st) : launch_mfma<1, bf16_t>(p, st);
-    }
-    ProfScope prof(PROF_GEMM_GENERIC, flops, st);
-    if (p.ab_dtype == LECCR_F32) {
-        LECCR_REQUIRE(p.c_dtype == LECCR_F32, LECCR_EINVAL, "gemm: f32 operands need an f32 C");
-        return launch_generic<float, float>(p, st);
-    }
-    return p.c_dtype == LECCR_F32 ? launch_generic<bf16_t, float>(p, st) : launch_generic<bf16_t, bf16_t>(p, st);
+    LECCR_REQUIRE(!(p.colsum && p.accumulate), LECCR_EINVAL, "gemm: colsum with accumulate is not defined");
+    bool colsum_fused = false;
+    int rc = gemm_dispatch(p, st, &colsum_fused);
+    if (rc == LECCR_OK && p.colsum && !colsum_fused)     // paths without the fused epilogue: one pass over the C just written
+        rc = leccr_colsum(p.C, p.colsum, p.M, p.N, p.ldc, p.c_dtype, stream);
+    return rc;
 }

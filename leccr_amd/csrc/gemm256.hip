@@ -12,18 +12,17 @@
 //     (128 accumulator VGPRs), issued with swapped roles so a lane ends with 4 consecutive N of one row.
 //   * LDS 128 KiB = 2 slots x {A0, A1, B0, B1} half-tiles of 16 KiB (128 rows x 64 k), filled by
 //     global_load_lds_dwordx4 with the XOR swizzle applied to the SOURCE address (gemm.hip's images).
-//   * A K-tile is 4 quadrant steps per wave: LOAD (ds_reads of the quadrant's fragments + a share of the prefetch)
-//     then COMPUTE (16 MFMAs).  Waves 0-3 (M row 0) and 4-7 (M row 1) pair up on the 4 SIMDs and run ONE SEGMENT
-//     APART: while one wave of a SIMD computes, its partner loads.  Every segment ends in a raw s_barrier.
-//   * Rolling prefetch TWO K-tiles ahead with counted waits: a wave's LOAD segments read 12 / 4 / 8 / 0 fragments
-//     (the first B fragments stay in registers for the fourth quadrant), so B(t) is free after LOAD 2 and A(t) after
-//     LOAD 3; B(t+2) is issued in LOAD 3 and A(t+2) in LOAD 4 into the slot K-tile t is vacating; ONE
-//     `s_waitcnt vmcnt(8)` per K-tile (end of LOAD 4) retires K-tile t+1, never 0 in the loop.  Timeline (global
-//     segments of K-tile t; group 1 runs one segment late): B(t) last read segs 2/3, A(t) segs 4/5; B(t+2) issued
-//     segs 4/5, A(t+2) segs 6/7; the barrier closing seg 7 publishes t+1; first reads of t+1 at segs 8/9.
-//     (Measured alternative, in-kernel stamps: one DMA piece per segment instead of 4 per LOAD 3/4 was 3 % slower -
-//     a piece issued ahead of a COMPUTE segment's MFMAs delays them; the L1/TA path, ~16-28 B/clk/CU, is what bounds
-//     the K-tile at ~4400 cycles either way.)
+//   * A K-tile is 4 quadrant steps ("quads") of 16 MFMAs per wave.  Two schedules:
+//     NT (forward / dX, TRANS = 0) - software pipelined: every LDS fragment read and every DMA piece is issued between
+//       two MFMAs of the same wave (one per MFMA at most), a fragment register is reloaded right after the last MFMA
+//       that needs its old contents has issued, the 8 pieces of K-tile t+2 go out as soon as slot t is free, and there
+//       are two barriers per K-tile ("slot t free", "K-tile t+1 visible").  See the comment at the loop.
+//     TN (weight gradients, TRANS = 1) - LOAD (ds_reads + a share of the prefetch) and COMPUTE (16 MFMAs) segments;
+//       waves 0-3 (M row 0) and 4-7 (M row 1) pair up on the 4 SIMDs and run ONE SEGMENT APART, every segment ends in a
+//       raw s_barrier; rolling prefetch TWO K-tiles ahead with one counted `s_waitcnt vmcnt(8)` per K-tile.  (The
+//       pipelined loop needs 96 fragment registers; with the transposed reads' register pairs it spills.)
+//     In-kernel stamps: the alternating schedule runs ~4200 cycles per K-tile (LOAD segments 2x the COMPUTE segments),
+//     the pipelined one ~3800 at 4096^3, against the 2048-cycle MFMA floor.
 //   * The K-tile stream runs across the block's output tiles ("items"), so the epilogue of one item overlaps the
 //     partner wave's last COMPUTE and the loads of the next item.
 //
@@ -764,6 +763,12 @@ bool gemm256_legal(const leccr_gemm_params& p) {
     return p.M >= 256 && p.N >= 256 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.ldr & 7) == 0 && (p.ldaux & 7) == 0 &&
            p.lda < (1 << 24) && p.ldb < (1 << 24) && shape_compiled(p);
 }
+
+// Column sums of C (leccr_gemm_params.colsum) are NOT fused into this kernel: the pipelined NT loop sits at the 256-register
+// limit and the extra epilogue state (8 accumulators + the cross-lane reduction) tipped it into ~135 spills inside the K loop
+// (all NT GEMMs 2x slower); per-item global atomics were worse still (14,000 adders per address).  leccr_gemm runs the
+// colsum pass over C instead.
+bool gemm256_fuses_colsum(const leccr_gemm_params&) { return false; }
 
 bool gemm256_wanted(const leccr_gemm_params& p) {
     const int64_t tm = cdiv(p.M, g256::BM), tn = cdiv(p.N, g256::BN);

@@ -68,16 +68,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
                                                             T* __restrict__ dx, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int64_t rows, int d) {
+                                                            float* __restrict__ dbeta, float* __restrict__ colsum,
+                                                            int colsum_of, int64_t rows, int d) {
     __shared__ float red[NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 g[NCH], dg[NCH], db[NCH];
+    f32x4 g[NCH], dg[NCH], db[NCH], dc[NCH];     // dc: column sums of dres (colsum_of = 1) or of the dx written (2)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 4;
         g[i] = c < d ? load4(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -106,13 +108,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             const int c = (lane + 64 * i) * 4;
             if (c < d) {
                 f32x4 o = (gy[i] - s1 - xh[i] * s2) * rs;
-                if (dres) o += load4(dres + row * d + c);
+                if (dres) {
+                    const f32x4 r = load4(dres + row * d + c);
+                    o += r;
+                    if (colsum_of == 1) dc[i] += r;
+                }
+                if (colsum_of == 2) dc[i] += o;
                 store4(dx + row * d + c, o);
             }
         }
     }
     // reduce the 4 waves' partials through LDS (one wave at a time), then one f32 atomic per column
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (colsum_of ? 3 : 2); ++pass) {
         for (int w = 0; w < 4; ++w) {
             __syncthreads();
             if (wave == w) {
@@ -121,14 +128,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     const int c = (lane + 64 * i) * 4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float val = pass == 0 ? dg[i][j] : db[i][j];
+                        const float val = pass == 0 ? dg[i][j] : pass == 1 ? db[i][j] : dc[i][j];
                         red[c + j] = w == 0 ? val : red[c + j] + val;
                     }
                 }
             }
         }
         __syncthreads();
-        float* out = pass == 0 ? dgamma : dbeta;
+        float* out = pass == 0 ? dgamma : pass == 1 ? dbeta : colsum;
         for (int c = threadIdx.x; c < d; c += 256) atomicAdd(out + c, red[c]);
     }
 }
@@ -207,14 +214,14 @@ static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, c
 
 template <typename T>
 static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, const float* mean, const float* rstd,
-                           const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int64_t d,
-                           hipStream_t st) {
+                           const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of,
+                           int64_t rows, int64_t d, hipStream_t st) {
     int64_t nb = cdiv(rows, 4);
     if (nb > 1024) nb = 1024;
     dim3 grid((unsigned)nb);
 #define L(N)                                                                                                     \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma, mean, \
-                       rstd, (const T*)dres, (T*)dx, dgamma, dbeta, rows, (int)d)
+                       rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d)
     if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
     else if (d <= 2048) L(8); else L(16);
 #undef L
@@ -246,13 +253,15 @@ extern "C" int leccr_layernorm_fwd(const void* x, const void* add, const float* 
 
 extern "C" int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, const float* mean,
                                    const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
-                                   int64_t rows, int64_t d, int dtype, void* stream) {
+                                   float* colsum, int colsum_of, int64_t rows, int64_t d, int dtype, void* stream) {
     LECCR_REQUIRE(dy && x_in && gamma && mean && rstd && dx && dgamma && dbeta, LECCR_EINVAL, "layernorm_bwd: null pointer");
+    LECCR_REQUIRE(colsum_of == 0 || (colsum && (colsum_of == 2 || (colsum_of == 1 && dres))), LECCR_EINVAL,
+                  "layernorm_bwd: colsum_of=%d needs colsum (and dres for 1)", colsum_of);
     LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_bwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
     if (rows == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
-    DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st),
-               ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, d, st));
+    DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, st),
+               ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, st));
 }
 
 template <typename T>

@@ -21,7 +21,7 @@ def _rows2d(t):
 
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
-         out=None, out_dtype=None, accumulate=False, alpha=1.0):
+         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None):
     """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major."""
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -50,6 +50,9 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     p.aux_out = ptr(aux_out)
     p.residual, p.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
     p.alpha = alpha
+    if colsum is not None:
+        assert colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous() and not accumulate
+    p.colsum = ptr(colsum)
     check(lib().leccr_gemm(C.byref(p), stream()), 'leccr_gemm')
     return out
 
@@ -69,14 +72,18 @@ def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False):
     return y.view(x.shape), mean, rstd, (s.view(x.shape) if s is not None else None)
 
 
-def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None):
+def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None, colsum=None, colsum_of=0):
+    """colsum_of: 1 = colsum += column sums of dres, 2 = of the returned dx (fused bias gradient, see leccr_hip.h)."""
     dy2, rows, d, ld = _rows2d(dy)
     assert ld == d and x_in.is_contiguous()
     dx = torch.empty_like(dy2)
     if dres is not None:
         assert dres.is_contiguous() and dres.dtype == dy.dtype
+    if colsum_of:
+        assert colsum is not None and colsum.dtype == torch.float32 and colsum.numel() == d and colsum.is_contiguous()
     check(lib().leccr_layernorm_bwd(ptr(dy2), ptr(x_in), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-                                    ptr(dgamma), ptr(dbeta), rows, d, dtype_code(dy), stream()), 'leccr_layernorm_bwd')
+                                    ptr(dgamma), ptr(dbeta), ptr(colsum), int(colsum_of), rows, d, dtype_code(dy),
+                                    stream()), 'leccr_layernorm_bwd')
     return dx.view(dy.shape)
 
 

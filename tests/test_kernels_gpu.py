@@ -131,6 +131,17 @@ def test_layernorm(K, dtype, rows, d, eps):
     assert e <= 1e-4 * sc + 1e-5, ('dgamma', e, sc)
     e, sc = _err(db, bd.grad)
     assert e <= 1e-4 * sc + 1e-5, ('dbeta', e, sc)
+    # fused bias-gradient column sums: of the dres operand (pre-LN blocks) and of the dx written (post-LN blocks)
+    for which, want in ((1, dres.double().sum(0)), (2, (xin.grad + dres.double()).sum(0))):
+        cs = torch.ones(d, device=DEV)
+        dg2, db2 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        dx2 = K.layernorm_bwd(dy.to(DEV), s, g.to(DEV), mean, rstd, dg2, db2, dres=dres.to(DEV), colsum=cs,
+                              colsum_of=which)
+        assert torch.equal(dx2, dx)
+        e, sc = _err(dg2, dg.cpu().double())            # f32 atomics: summation order differs between launches
+        assert e <= 1e-4 * sc + 1e-5
+        e, sc = _err(cs - 1, want)                     # accumulates (+=) into the buffer
+        assert e <= (1e-4 if which == 1 or dtype == torch.float32 else _tol(dtype)) * sc + 1e-4, ('colsum', which, e, sc)
 
 
 def _ref_attn(q, k, v, heads, kmask):
@@ -427,6 +438,23 @@ def test_gemm256_nt(K, force256, M, N, K_, epi):
     if epi:
         e, s = _err(pre, u)
         assert e <= 1.2e-2 * s
+
+
+@pytest.mark.parametrize('M,N,K_', [(1154, 768, 256), (2000, 1024, 128), (300, 260, 64), (40, 24, 16)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
+def test_gemm_fused_colsum(K, dtype, M, N, K_):
+    """p.colsum += column sums of the C written: inside the 256-tile bf16 epilogue, or by a colsum pass elsewhere."""
+    a, b = _rand((M, K_), dtype, 190), _rand((N, K_), dtype, 191, 0.05)
+    pre = _rand((M, N), dtype, 192)
+    cs = torch.full((N,), 2.0, device=DEV)
+    out = K.gemm(a.to(DEV), b.to(DEV), epilogue=3, aux=pre.to(DEV), colsum=cs)          # 3 = DQUICKGELU
+    x = pre.double()
+    sg = torch.sigmoid(1.702 * x)
+    ref = (a.double() @ b.double().t()) * (sg * (1 + 1.702 * x * (1 - sg)))          # u * quick_gelu'(pre)
+    e, s = _err(out, ref)
+    assert e <= (1.2e-2 if dtype == torch.bfloat16 else 1e-4) * s
+    got, want = cs.cpu().double() - 2.0, ref.sum(0)
+    assert float((got - want).abs().max()) <= (2e-2 if dtype == torch.bfloat16 else 1e-4) * float(ref.abs().sum(0).max())
 
 
 @pytest.mark.parametrize('Kt,M,N', [(577 * 3, 768, 256), (20000, 768, 768), (64 * 300, 256, 512), (5000, 264, 520)])
