@@ -408,15 +408,18 @@ constexpr int DKV_STAGE = 2 * TILE_BYTES + 512;
 // runs 1.4-1.9x slower, so they are built for 3 waves/SIMD and launched as 4-wave blocks (3 blocks per CU;
 // measured best of {4-wave, 8-wave blocks} x {2, 3, 4 waves/SIMD} at L = 577).
 constexpr int BWD_WPE = 3;
-template <bool DROP, int NW>
-__global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dkdv_kernel(FP p) {
-    constexpr int BQ = NW * 16, NT = NW * 64;
+// KG = key groups (dkdv) / query groups (dq) of 16 per wave.  With KG = 2 every LDS fragment feeds two MFMAs instead of
+// one: the kernels are bound by LDS read bandwidth (40 KB per wave and tile at KG = 1), so halving the bytes per MFMA
+// is worth dropping to 2 waves per SIMD (~220 registers).
+template <bool DROP, int NW, int KG>
+__global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flash_dkdv_kernel(FP p) {
+    constexpr int BQ = NW * KG * 16, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t nkb = (p.Lk + BQ - 1) / BQ;
     const int64_t bh = blockIdx.x / nkb, b = bh / p.heads, head = bh % p.heads;
-    const int64_t k0 = (int64_t)(blockIdx.x % nkb) * BQ + wave * 16;      // this wave's 16 keys
+    const int64_t k0 = (int64_t)(blockIdx.x % nkb) * BQ + wave * (KG * 16);   // this wave's KG x 16 keys
     const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
     const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
@@ -425,21 +428,29 @@ __global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dkdv_kernel
     const float* rc1 = p.delta + (p.nbh + bh) * p.Lqp;
     const float c = p.scale * kLog2e;
 
-    bf16x8 kf[2], vf[2];
-    kf[0] = frag_global(Kp, p.ldk, k0, p.Lk, 0, lane);
-    kf[1] = frag_global(Kp, p.ldk, k0, p.Lk, 1, lane);
-    vf[0] = frag_global(Vp, p.ldv, k0, p.Lk, 0, lane);
-    vf[1] = frag_global(Vp, p.ldv, k0, p.Lk, 1, lane);
-    const int64_t key = k0 + (lane & 15);
-    const bool dead = !(key < p.Lk && !(p.kmask && p.kmask[b * p.Lk + (key < p.Lk ? key : 0)]));
-    const bool any_dead = __ballot(dead) != 0ull;          // wave-uniform: only ragged / padded key blocks pay for it
-
-    f32x4 dk[4], dv[4];
+    bf16x8 kf[KG][2], vf[KG][2];
+    int64_t key[KG];
+    bool dead[KG];
+    bool any_dead = false;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        dk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < KG; ++g) {
+        kf[g][0] = frag_global(Kp, p.ldk, k0 + 16 * g, p.Lk, 0, lane);
+        kf[g][1] = frag_global(Kp, p.ldk, k0 + 16 * g, p.Lk, 1, lane);
+        vf[g][0] = frag_global(Vp, p.ldv, k0 + 16 * g, p.Lk, 0, lane);
+        vf[g][1] = frag_global(Vp, p.ldv, k0 + 16 * g, p.Lk, 1, lane);
+        key[g] = k0 + 16 * g + (lane & 15);
+        dead[g] = !(key[g] < p.Lk && !(p.kmask && p.kmask[b * p.Lk + (key[g] < p.Lk ? key[g] : 0)]));
+        any_dead = any_dead || __ballot(dead[g]) != 0ull;      // wave-uniform: only ragged / padded key blocks pay
     }
+
+    f32x4 dk[KG][4], dv[KG][4];
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dk[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dv[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     const int ntiles = (int)((p.Lq + BT - 1) / BT), nfull = (int)(p.Lq / BT);
     StageSrc<NT> qsrc, dosrc;
     qsrc.init(Q, p.ldq);
@@ -461,7 +472,8 @@ __global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dkdv_kernel
     const TileLane tl = make_tile_lane(lane);
     const uint32_t smem_off = lds_u32(smem);
     __builtin_amdgcn_s_waitcnt(0x0F70);       // retire the K/V fragment loads visibly (see flash_fwd_kernel)
-    asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(vf[0]), "+v"(vf[1]));
+#pragma unroll
+    for (int g = 0; g < KG; ++g) asm volatile("" : "+v"(kf[g][0]), "+v"(kf[g][1]), "+v"(vf[g][0]), "+v"(vf[g][1]));
     stage(0);
     for (int t = 0; t < ntiles; ++t) {
         const uint32_t qt = smem_off + (t & 1) * DKV_STAGE, dot = qt + TILE_BYTES;
@@ -470,106 +482,121 @@ __global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dkdv_kernel
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
-        // s[j][r], dp[j][r]: query = 16 j + 4 h4 + r of the tile, key = lane & 15
-        f32x4 s[4], dp[4], dl[4];
+        // s[g][j][r], dp[g][j][r]: query = 16 j + 4 h4 + r of the tile, key = group g, lane & 15
+        f32x4 s[KG][4], dp[KG][4], dl[4];
         bf16x8 fa[8];
-        s[0] = lds_b128_f32<0>(rcl); s[1] = lds_b128_f32<64>(rcl); s[2] = lds_b128_f32<128>(rcl); s[3] = lds_b128_f32<192>(rcl);
-        if constexpr (DROP) {
-            dl[0] = lds_b128_f32<256>(rcl); dl[1] = lds_b128_f32<320>(rcl); dl[2] = lds_b128_f32<384>(rcl); dl[3] = lds_b128_f32<448>(rcl);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        } else {
-            dp[0] = lds_b128_f32<256>(rcl); dp[1] = lds_b128_f32<320>(rcl); dp[2] = lds_b128_f32<384>(rcl); dp[3] = lds_b128_f32<448>(rcl);
-        }
+        s[0][0] = lds_b128_f32<0>(rcl); s[0][1] = lds_b128_f32<64>(rcl); s[0][2] = lds_b128_f32<128>(rcl); s[0][3] = lds_b128_f32<192>(rcl);
+        dl[0] = lds_b128_f32<256>(rcl); dl[1] = lds_b128_f32<320>(rcl); dl[2] = lds_b128_f32<384>(rcl); dl[3] = lds_b128_f32<448>(rcl);
         READ_ROWS8(fa, qt);
-        LDS_WAIT4F(0, s);
+        LDS_WAIT4F(0, s[0]);
+        LDS_WAIT4F(0, dl);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = MFMA16(fa[2 * j], kf[0], s[j]);
-            s[j] = MFMA16(fa[2 * j + 1], kf[1], s[j]);
-        }
+        for (int g = KG - 1; g >= 0; --g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[g][j] = MFMA16(fa[2 * j], kf[g][0], s[0][j]);            // group 0 last: it overwrites the shared start value
+                s[g][j] = MFMA16(fa[2 * j + 1], kf[g][1], s[g][j]);
+            }
         __builtin_amdgcn_sched_barrier(0);
         READ_ROWS8(fa, dot);
-        if constexpr (DROP) LDS_WAIT4F(0, dl); else LDS_WAIT4F(0, dp);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dp[j] = MFMA16(fa[2 * j], vf[0], dp[j]);
-            dp[j] = MFMA16(fa[2 * j + 1], vf[1], dp[j]);
-        }
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dp[g][j] = MFMA16(fa[2 * j], vf[g][0], DROP ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dl[j]);      // dl = -delta
+                dp[g][j] = MFMA16(fa[2 * j + 1], vf[g][1], dp[g][j]);
+            }
         __builtin_amdgcn_sched_barrier(0);
         READ_TR8(fa, dot);                          // dO^T, under the p computation
+        bf16x8 pf[KG][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[j][r] = exp2_fast(s[j][r] * c);
-        if (any_dead) {
+        for (int g = 0; g < KG; ++g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s[j][r] = dead ? 0.f : s[j][r];
-        }
-        if constexpr (DROP) {
+                for (int r = 0; r < 4; ++r) s[g][j][r] = exp2_fast(s[g][j][r] * c);
+            if (any_dead) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + (int64_t)t * BT + 16 * j + 4 * h4 + r) * p.Lk + key));
-                    dp[j][r] = s[j][r] * (dm * dp[j][r] + dl[j][r]);       // dl = -delta
-                    s[j][r] *= dm;                                         // dV uses the dropped probabilities
-                }
+                    for (int r = 0; r < 4; ++r) s[g][j][r] = dead[g] ? 0.f : s[g][j][r];
+            }
+            if constexpr (DROP) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + (int64_t)t * BT + 16 * j + 4 * h4 + r) * p.Lk + key[g]));
+                        dp[g][j][r] = s[g][j][r] * (dm * dp[g][j][r] + dl[j][r]);
+                        s[g][j][r] *= dm;                                  // dV uses the dropped probabilities
+                    }
+            }
+            pf[g][0] = pack2(s[g][0], s[g][1]);
+            pf[g][1] = pack2(s[g][2], s[g][3]);
         }
-        const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
         __builtin_amdgcn_sched_barrier(0);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) {
-            dv[nd] = MFMA16(fa[2 * nd], pf0, dv[nd]);
-            dv[nd] = MFMA16(fa[2 * nd + 1], pf1, dv[nd]);
-        }
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) {
+                dv[g][nd] = MFMA16(fa[2 * nd], pf[g][0], dv[g][nd]);
+                dv[g][nd] = MFMA16(fa[2 * nd + 1], pf[g][1], dv[g][nd]);
+            }
         __builtin_amdgcn_sched_barrier(0);
         READ_TR8(fa, qt);                           // Q^T, under the dS computation
-        if constexpr (!DROP) {
+        bf16x8 df[KG][2];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+        for (int g = 0; g < KG; ++g) {
+            if constexpr (!DROP) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dp[j][r] *= s[j][r];
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[g][j][r] *= s[g][j][r];
+            }
+            df[g][0] = pack2(dp[g][0], dp[g][1]);
+            df[g][1] = pack2(dp[g][2], dp[g][3]);
         }
-        const bf16x8 df0 = pack2(dp[0], dp[1]), df1 = pack2(dp[2], dp[3]);
         __builtin_amdgcn_sched_barrier(0);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) {
-            dk[nd] = MFMA16(fa[2 * nd], df0, dk[nd]);
-            dk[nd] = MFMA16(fa[2 * nd + 1], df1, dk[nd]);
-        }
-    }
-    if (key < p.Lk) {
-        bf16_t* dkp = p.dk + (b * p.Lk + key) * p.ldk + head * HD;
-        bf16_t* dvp = p.dv + (b * p.Lk + key) * p.ldv + head * HD;
+        for (int g = 0; g < KG; ++g)
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) {
-            store4(dkp + nd * 16 + 4 * h4, dk[nd] * p.scale);
-            store4(dvp + nd * 16 + 4 * h4, dv[nd]);
+            for (int nd = 0; nd < 4; ++nd) {
+                dk[g][nd] = MFMA16(fa[2 * nd], df[g][0], dk[g][nd]);
+                dk[g][nd] = MFMA16(fa[2 * nd + 1], df[g][1], dk[g][nd]);
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        if (key[g] < p.Lk) {
+            bf16_t* dkp = p.dk + (b * p.Lk + key[g]) * p.ldk + head * HD;
+            bf16_t* dvp = p.dv + (b * p.Lk + key[g]) * p.ldv + head * HD;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) {
+                store4(dkp + nd * 16 + 4 * h4, dk[g][nd] * p.scale);
+                store4(dvp + nd * 16 + 4 * h4, dv[g][nd]);
+            }
         }
     }
 }
 
-// ---- dQ.  Block = NW waves x 16 queries; sweeps 64-key tiles.  LDS per stage: K tile | V tile.
-//   K rows -> S'^T (8 MFMA, accumulators start at rc1[query]) | V rows -> dP'^T (8, start at rc0[query]) |
+// ---- dQ.  Block = NW waves x KG x 16 queries; sweeps 64-key tiles.  LDS per stage: K tile | V tile.
+//   K rows -> S'^T (8 MFMA per group, accumulators start at rc1[query]) | V rows -> dP'^T (8, start at rc0[query]) |
 //   K^T -> [p, dS on the VALU] -> dQ^T (8)
 constexpr int DQ_STAGE = 2 * TILE_BYTES;
 
-template <bool DROP, int NW>
-__global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dq_kernel(FP p) {
-    constexpr int BQ = NW * 16, NT = NW * 64;
+template <bool DROP, int NW, int KG>
+__global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flash_dq_kernel(FP p) {
+    constexpr int BQ = NW * KG * 16, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, h4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t nqb = (p.Lq + BQ - 1) / BQ;
     const int64_t bh = blockIdx.x / nqb, b = bh / p.heads, head = bh % p.heads;
-    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BQ + wave * 16;
+    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BQ + wave * (KG * 16);
     const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
     const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
@@ -577,20 +604,27 @@ __global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dq_kernel(F
     const uint8_t* km = p.kmask ? p.kmask + b * p.Lk : nullptr;
     const float c = p.scale * kLog2e;
 
-    bf16x8 qf[2], dof[2];
-    qf[0] = frag_global(Q, p.ldq, q0, p.Lq, 0, lane);
-    qf[1] = frag_global(Q, p.ldq, q0, p.Lq, 1, lane);
-    dof[0] = frag_global(DO, p.ldo, q0, p.Lq, 0, lane);
-    dof[1] = frag_global(DO, p.ldo, q0, p.Lq, 1, lane);
-    const int64_t qi = q0 + (lane & 15);
-    const int64_t qc = qi < p.Lqp ? qi : p.Lqp - 1;           // padded rows hold (0, -inf): p = 0 for queries >= Lq
-    float nd_ = p.delta[bh * p.Lqp + qc];                      // -delta
-    float nl_ = p.delta[(p.nbh + bh) * p.Lqp + qc];            // -lse / scale
-    if (qi >= p.Lqp) { nd_ = 0.f; nl_ = -INFINITY; }
-
-    f32x4 dq[4];
+    bf16x8 qf[KG][2], dof[KG][2];
+    int64_t qi[KG];
+    float nd_[KG], nl_[KG];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < KG; ++g) {
+        qf[g][0] = frag_global(Q, p.ldq, q0 + 16 * g, p.Lq, 0, lane);
+        qf[g][1] = frag_global(Q, p.ldq, q0 + 16 * g, p.Lq, 1, lane);
+        dof[g][0] = frag_global(DO, p.ldo, q0 + 16 * g, p.Lq, 0, lane);
+        dof[g][1] = frag_global(DO, p.ldo, q0 + 16 * g, p.Lq, 1, lane);
+        qi[g] = q0 + 16 * g + (lane & 15);
+        const int64_t qc = qi[g] < p.Lqp ? qi[g] : p.Lqp - 1;         // padded rows hold (0, -inf): p = 0 for queries >= Lq
+        nd_[g] = p.delta[bh * p.Lqp + qc];                            // -delta
+        nl_[g] = p.delta[(p.nbh + bh) * p.Lqp + qc];                  // -lse / scale
+        if (qi[g] >= p.Lqp) { nd_[g] = 0.f; nl_[g] = -INFINITY; }
+    }
+
+    f32x4 dq[KG][4];
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[g][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int ntiles = (int)((p.Lk + BT - 1) / BT), nfull = (int)(p.Lk / BT);
     StageSrc<NT> ksrc, vsrc;
     ksrc.init(Kp, p.ldk);
@@ -608,7 +642,9 @@ __global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dq_kernel(F
     const TileLane tl = make_tile_lane(lane);
     const uint32_t smem_off = lds_u32(smem);
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(dof[0]), "+v"(dof[1]), "+v"(nd_), "+v"(nl_));
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+        asm volatile("" : "+v"(qf[g][0]), "+v"(qf[g][1]), "+v"(dof[g][0]), "+v"(dof[g][1]), "+v"(nd_[g]), "+v"(nl_[g]));
     stage(0);
     for (int t = 0; t < ntiles; ++t) {
         const uint32_t kt = smem_off + (t & 1) * DQ_STAGE, vt = kt + TILE_BYTES;
@@ -617,69 +653,85 @@ __global__ __launch_bounds__(NW * 64, DROP ? 2 : BWD_WPE) void flash_dq_kernel(F
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
-        // s[j][r], dp[j][r]: key = 16 j + 4 h4 + r of the tile, query = lane & 15
-        f32x4 s[4], dp[4];
+        // s[g][j][r], dp[g][j][r]: key = 16 j + 4 h4 + r of the tile, query = group g, lane & 15
+        f32x4 s[KG][4], dp[KG][4];
         bf16x8 fa[8];
         READ_ROWS8(fa, kt);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = f32x4{nl_, nl_, nl_, nl_};
-            dp[j] = f32x4{nd_, nd_, nd_, nd_};
-        }
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[g][j] = f32x4{nl_[g], nl_[g], nl_[g], nl_[g]};
+                dp[g][j] = f32x4{nd_[g], nd_[g], nd_[g], nd_[g]};
+            }
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = MFMA16(fa[2 * j], qf[0], s[j]);
-            s[j] = MFMA16(fa[2 * j + 1], qf[1], s[j]);
-        }
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[g][j] = MFMA16(fa[2 * j], qf[g][0], s[g][j]);
+                s[g][j] = MFMA16(fa[2 * j + 1], qf[g][1], s[g][j]);
+            }
         __builtin_amdgcn_sched_barrier(0);
         READ_ROWS8(fa, vt);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            dp[j] = MFMA16(fa[2 * j], dof[0], dp[j]);
-            dp[j] = MFMA16(fa[2 * j + 1], dof[1], dp[j]);
-        }
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dp[g][j] = MFMA16(fa[2 * j], dof[g][0], dp[g][j]);
+                dp[g][j] = MFMA16(fa[2 * j + 1], dof[g][1], dp[g][j]);
+            }
         __builtin_amdgcn_sched_barrier(0);
         READ_TR8(fa, kt);                           // K^T, under the p / dS computation
+        bf16x8 df[KG][2];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[j][r] = exp2_fast(s[j][r] * c);
-        if (deadk) {
+        for (int g = 0; g < KG; ++g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (deadk & (1u << (4 * j + r))) s[j][r] = 0.f;
+                for (int r = 0; r < 4; ++r) s[g][j][r] = exp2_fast(s[g][j][r] * c);
+            if (deadk) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (deadk & (1u << (4 * j + r))) s[g][j][r] = 0.f;
+            }
+            if constexpr (DROP) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + qi[g]) * p.Lk + (int64_t)t * BT + 16 * j + 4 * h4 + r));
+                        dp[g][j][r] = s[g][j][r] * (dm * (dp[g][j][r] - nd_[g]) + nd_[g]);      // dP' = dP - delta was accumulated
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dp[g][j][r] *= s[g][j][r];
+            }
+            df[g][0] = pack2(dp[g][0], dp[g][1]);
+            df[g][1] = pack2(dp[g][2], dp[g][3]);
         }
-        if constexpr (DROP) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + qi) * p.Lk + (int64_t)t * BT + 16 * j + 4 * h4 + r));
-                    dp[j][r] = s[j][r] * (dm * (dp[j][r] - nd_) + nd_);      // dP' = dP - delta was accumulated
-                }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dp[j][r] *= s[j][r];
-        }
-        const bf16x8 df0 = pack2(dp[0], dp[1]), df1 = pack2(dp[2], dp[3]);
         __builtin_amdgcn_sched_barrier(0);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) {
-            dq[nd] = MFMA16(fa[2 * nd], df0, dq[nd]);
-            dq[nd] = MFMA16(fa[2 * nd + 1], df1, dq[nd]);
-        }
-    }
-    if (qi < p.Lq) {
-        bf16_t* dqp = p.dq + (b * p.Lq + qi) * p.ldq + head * HD;
+        for (int g = 0; g < KG; ++g)
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) store4(dqp + nd * 16 + 4 * h4, dq[nd] * p.scale);
+            for (int nd = 0; nd < 4; ++nd) {
+                dq[g][nd] = MFMA16(fa[2 * nd], df[g][0], dq[g][nd]);
+                dq[g][nd] = MFMA16(fa[2 * nd + 1], df[g][1], dq[g][nd]);
+            }
+    }
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        if (qi[g] < p.Lq) {
+            bf16_t* dqp = p.dq + (b * p.Lq + qi[g]) * p.ldq + head * HD;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) store4(dqp + nd * 16 + 4 * h4, dq[g][nd] * p.scale);
+        }
     }
 }
 
@@ -762,19 +814,17 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
     hipLaunchKernelGGL(flash_rowconst_kernel, dim3((unsigned)cdiv(p.nbh * p.Lqp * 8, 256)), dim3(256), 0, st,
                        (const bf16_t*)o, (const bf16_t*)dout, lse, delta, D.heads, D.Lq, p.Lqp, D.ldo, p.nbh,
                        sqrtf((float)HD));
-#define LAUNCH_BWD(DR, NWK, NWQ)                                                                                     \
+#define LAUNCH_BWD(DR, KG)                                                                                              \
     do {                                                                                                            \
-        hipLaunchKernelGGL((flash_dkdv_kernel<DR, NWK>), dim3((unsigned)(cdiv(D.Lk, NWK * 16) * D.b * D.heads)),    \
-                           dim3(NWK * 64), 2 * DKV_STAGE, st, p);                                                   \
-        hipLaunchKernelGGL((flash_dq_kernel<DR, NWQ>), dim3((unsigned)(cdiv(D.Lq, NWQ * 16) * D.b * D.heads)),      \
-                           dim3(NWQ * 64), 2 * DQ_STAGE, st, p);                                                    \
+        hipLaunchKernelGGL((flash_dkdv_kernel<DR, 4, KG>), dim3((unsigned)(cdiv(D.Lk, 64 * KG) * D.b * D.heads)),   \
+                           dim3(256), 2 * DKV_STAGE, st, p);                                                        \
+        hipLaunchKernelGGL((flash_dq_kernel<DR, 4, KG>), dim3((unsigned)(cdiv(D.Lq, 64 * KG) * D.b * D.heads)),     \
+                           dim3(256), 2 * DQ_STAGE, st, p);                                                         \
     } while (0)
-    const bool bigk = false, bigq = false;      // 4-wave blocks (see BWD_WPE)
-    if (D.dropout) {
-        if (bigk && bigq) LAUNCH_BWD(true, 8, 8); else if (bigk) LAUNCH_BWD(true, 8, 4); else if (bigq) LAUNCH_BWD(true, 4, 8); else LAUNCH_BWD(true, 4, 4);
-    } else {
-        if (bigk && bigq) LAUNCH_BWD(false, 8, 8); else if (bigk) LAUNCH_BWD(false, 8, 4); else if (bigq) LAUNCH_BWD(false, 4, 8); else LAUNCH_BWD(false, 4, 4);
-    }
+    // 4-wave blocks (see BWD_WPE); two 16-row groups per wave when both sequences are long enough to fill 128-row blocks
+    if (D.dropout) LAUNCH_BWD(true, 1);
+    else if (D.Lq > 64 && D.Lk > 64) LAUNCH_BWD(false, 2);
+    else LAUNCH_BWD(false, 1);
 #undef LAUNCH_BWD
     return check_launch("flash_bwd");
 }
