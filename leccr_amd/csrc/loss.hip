@@ -21,6 +21,31 @@ __device__ __forceinline__ float dot_lds_glb(const float* __restrict__ a_lds, co
     return acc;
 }
 
+
+// The other operand's rows j0..j0+63 staged once per block in LDS (coalesced loads, row stride D + 4 floats so that the 16
+// lanes of a ds_read_b128 group hit distinct banks): lanes reading "their own row" straight from global touched 64
+// different cache lines per load instruction - at G = 2048 (8 ranks) that made these kernels several ms each.
+__device__ __forceinline__ void stage_rows64(const float* __restrict__ B, int j0, int G, int D, float* __restrict__ tile) {
+    const int ld = D + 4, q4 = D >> 2;
+    for (int e = threadIdx.x; e < 64 * q4; e += 256) {
+        const int r = e / q4, c = (e - r * q4) * 4;
+        const int j = j0 + r < G ? j0 + r : G - 1;
+        *reinterpret_cast<f32x4*>(tile + r * ld + c) = *reinterpret_cast<const f32x4*>(B + (int64_t)j * D + c);
+    }
+}
+
+__device__ __forceinline__ float dot_lds_lds(const float* __restrict__ a_lds, const float* __restrict__ b_lds, int D) {
+    float acc = 0.f;
+    for (int d = 0; d < D; d += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(a_lds + d), bv = *reinterpret_cast<const f32x4*>(b_lds + d);
+        acc = fmaf(av[0], bv[0], acc);
+        acc = fmaf(av[1], bv[1], acc);
+        acc = fmaf(av[2], bv[2], acc);
+        acc = fmaf(av[3], bv[3], acc);
+    }
+    return acc;
+}
+
 // ----------------------------------------------------------------------------------------------- sim_infonce
 // dir 0: rows of a vs all b ; dir 1: rows of b vs all a.   For row i: lse_i, pos_i = sum_j lab_ij logit_ij.
 // loss += scale * (lse_i - pos_i).   ws: [lse dir0 (G) | lse dir1 (G)]
@@ -31,20 +56,23 @@ __global__ __launch_bounds__(256) void sim_rowlse_kernel(const float* __restrict
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dir = blockIdx.y;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= G) return;
+    const int i_raw = blockIdx.x * 4 + wave;
+    const int i = i_raw < G ? i_raw : G - 1;          // no early exit: the block synchronises on the staged tiles
     const float* A = dir == 0 ? a : b;
     const float* B = dir == 0 ? b : a;
     float* ar = sm + wave * D;
+    float* tile = sm + 4 * D;
     for (int d = lane; d < D; d += 64) ar[d] = A[(int64_t)i * D + d];
-    __builtin_amdgcn_wave_barrier();
     const int64_t my = idx ? idx[i] : 0;
     float m = -INFINITY, l = 0.f, pos = 0.f, cnt = 0.f;
     for (int j0 = 0; j0 < G; j0 += 64) {
+        __syncthreads();
+        stage_rows64(B, j0, G, D, tile);
+        __syncthreads();
         const int j = j0 + lane;
         float s = -INFINITY;
         if (j < G) {
-            s = dot_lds_glb(ar, B + (int64_t)j * D, D) * inv_temp;
+            s = dot_lds_lds(ar, tile + lane * (D + 4), D) * inv_temp;
             const bool match = idx ? (idx[j] == my) : (j == i);
             if (match) {
                 pos += s;
@@ -55,6 +83,7 @@ __global__ __launch_bounds__(256) void sim_rowlse_kernel(const float* __restrict
         l = l * __expf(m - mn) + wave_sum(j < G ? __expf(s - mn) : 0.f);
         m = mn;
     }
+    if (i_raw >= G) return;
     pos = wave_sum(pos);
     cnt = wave_sum(cnt);
     if (lane == 0) {
@@ -76,8 +105,8 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int side = blockIdx.y;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= G) return;
+    const int i_raw = blockIdx.x * 4 + wave;
+    const int i = i_raw < G ? i_raw : G - 1;          // no early exit: the block synchronises on the staged tiles
     const float* A = side == 0 ? a : b;
     const float* B = side == 0 ? b : a;
     float* out = side == 0 ? da : db;
@@ -87,8 +116,9 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
     const float w_mine = side == 0 ? w_r : w_c, w_oth = side == 0 ? w_c : w_r;
     float* ar = sm + wave * (D + 64);
     float* gbuf = ar + D;
+    float* tile = sm + 4 * (D + 64);
+    const int ldt = D + 4;
     for (int d = lane; d < D; d += 64) ar[d] = A[(int64_t)i * D + d];
-    __builtin_amdgcn_wave_barrier();
     const int64_t my = idx ? idx[i] : 0;
     // label normaliser: cnt_i (the label matrix is symmetric: lab_ij = eq/cnt_i, lab_ji = eq/cnt_j, cnt_i == cnt_j on a match)
     float cnt = 0.f;
@@ -100,29 +130,32 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
     float dt = 0.f;
     for (int j0 = 0; j0 < G; j0 += 64) {
+        __syncthreads();
+        stage_rows64(B, j0, G, D, tile);
+        __syncthreads();
         const int j = j0 + lane;
         float g = 0.f;
         if (j < G) {
-            const float s = dot_lds_glb(ar, B + (int64_t)j * D, D) * inv_temp;
+            const float s = dot_lds_lds(ar, tile + lane * ldt, D) * inv_temp;
             const float lab = (idx ? (idx[j] == my) : (j == i)) ? 1.f / cnt : 0.f;
             if (w_mine != 0.f) g += w_mine * (__expf(s - li) - lab);
             if (w_oth != 0.f) g += w_oth * (__expf(s - lse_other[j]) - lab);  // unused direction: statistics never written
             dt -= g * s;
         }
         gbuf[lane] = g;
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         const int jn = G - j0 < 64 ? G - j0 : 64;
         for (int jj = 0; jj < jn; ++jj) {
             const float gj = gbuf[jj];
-            const float* br = B + (int64_t)(j0 + jj) * D;
+            const float* br = tile + jj * ldt;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int d = lane + 64 * q;
                 if (d < D) acc[q] = fmaf(gj, br[d], acc[q]);
             }
         }
-        __builtin_amdgcn_wave_barrier();
     }
+    if (i_raw >= G) return;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int d = lane + 64 * q;
@@ -257,6 +290,7 @@ __global__ void dstl_init_kernel(int* mm) {
     mm[3] = f2ord(-INFINITY);  // max sc
 }
 
+template <bool STAGED>
 __global__ __launch_bounds__(256) void dstl_scores_kernel(const float* __restrict__ v, const float* __restrict__ c,
                                                           const float* __restrict__ s, const float* __restrict__ t,
                                                           int G, int n, int D, float* __restrict__ tv,
@@ -264,11 +298,14 @@ __global__ __launch_bounds__(256) void dstl_scores_kernel(const float* __restric
                                                           int* __restrict__ mm) {
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = blockIdx.x * 4 + wave;
-    if (i >= G) return;
+    const int i_raw = blockIdx.x * 4 + wave;
+    if (!STAGED && i_raw >= G) return;
+    const int i = i_raw < G ? i_raw : G - 1;     // STAGED: no early exit, the block synchronises on the tiles
     float* tr = sm + wave * (2 + n) * D;  // t_i | s_i | c_i[0..n)
     float* sr = tr + D;
     float* cr = sr + D;
+    float* vtile = sm + 4 * (2 + n) * D;  // STAGED: rows j0..j0+63 of v and of s (row stride D + 4)
+    float* stile = vtile + 64 * (D + 4);
     for (int d = lane; d < D; d += 64) {
         tr[d] = t[(int64_t)i * D + d];
         sr[d] = s[(int64_t)i * D + d];
@@ -276,11 +313,27 @@ __global__ __launch_bounds__(256) void dstl_scores_kernel(const float* __restric
     for (int d = lane; d < n * D; d += 64) cr[d] = c[(int64_t)i * n * D + d];
     __builtin_amdgcn_wave_barrier();
     float mn_sv = INFINITY, mx_sv = -INFINITY, mn_sc = INFINITY, mx_sc = -INFINITY;
-    for (int j = lane; j < G; j += 64) {
-        const float a = dot_lds_glb(tr, v + (int64_t)j * D, D);   // logits_tv[i,j] = <t_i, v_j>
-        const float bsv = dot_lds_glb(sr, v + (int64_t)j * D, D); // logits_sv[i,j] = <s_i, v_j>
-        float best = -INFINITY;                                    // logits_sc[i,j] = max_n <c_i,n , s_j>
-        for (int q = 0; q < n; ++q) best = fmaxf(best, dot_lds_glb(cr + q * D, s + (int64_t)j * D, D));
+    for (int j0 = 0; j0 < G; j0 += 64) {
+        if constexpr (STAGED) {
+            __syncthreads();
+            stage_rows64(v, j0, G, D, vtile);
+            stage_rows64(s, j0, G, D, stile);
+            __syncthreads();
+        }
+        const int j = j0 + lane;
+        if (j >= G || i_raw >= G) continue;
+        float a, bsv, best = -INFINITY;
+        if constexpr (STAGED) {
+            const float* vr = vtile + lane * (D + 4);
+            const float* srow = stile + lane * (D + 4);
+            a = dot_lds_lds(tr, vr, D);                                // logits_tv[i,j] = <t_i, v_j>
+            bsv = dot_lds_lds(sr, vr, D);                              // logits_sv[i,j] = <s_i, v_j>
+            for (int q = 0; q < n; ++q) best = fmaxf(best, dot_lds_lds(cr + q * D, srow, D));   // max_n <c_i,n , s_j>
+        } else {
+            a = dot_lds_glb(tr, v + (int64_t)j * D, D);
+            bsv = dot_lds_glb(sr, v + (int64_t)j * D, D);
+            for (int q = 0; q < n; ++q) best = fmaxf(best, dot_lds_glb(cr + q * D, s + (int64_t)j * D, D));
+        }
         tv[(int64_t)i * G + j] = a;
         sv[(int64_t)i * G + j] = bsv;
         sc[(int64_t)i * G + j] = best;
@@ -289,6 +342,7 @@ __global__ __launch_bounds__(256) void dstl_scores_kernel(const float* __restric
         mn_sc = fminf(mn_sc, best);
         mx_sc = fmaxf(mx_sc, best);
     }
+    if (i_raw >= G) return;
     mn_sv = wave_min(mn_sv);
     mx_sv = wave_max(mx_sv);
     mn_sc = wave_min(mn_sc);
@@ -470,7 +524,9 @@ extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("sim_infonce memset");
     const float scale = both_dirs ? 0.5f / G : 1.f / G;
-    hipLaunchKernelGGL(sim_rowlse_kernel, dim3((unsigned)cdiv(G, 4), both_dirs ? 2 : 1), dim3(256), 4 * D * sizeof(float), st,
+    const size_t lds_f = (size_t)(4 * D + 64 * (D + 4)) * sizeof(float);      // 4 own rows + the staged 64-row tile
+    (void)hipFuncSetAttribute((const void*)sim_rowlse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(sim_rowlse_kernel, dim3((unsigned)cdiv(G, 4), both_dirs ? 2 : 1), dim3(256), lds_f, st,
                        a, b, idx, 1.f / temp, (int)G, (int)D, loss, ws, scale);
     return check_launch("sim_infonce_fwd");
 }
@@ -481,7 +537,9 @@ extern "C" int leccr_sim_infonce_bwd(const float* a, const float* b, const int64
     LECCR_REQUIRE(a && b && ws && da && db && G > 0 && D > 0 && D <= 512 && (D & 3) == 0, LECCR_EINVAL, "sim_infonce_bwd: bad argument (D <= 512)");
     hipStream_t st = as_stream(stream);
     const float w_r = gscale * (both_dirs ? 0.5f / G : 1.f / G), w_c = both_dirs ? w_r : 0.f;
-    hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(G, 4), 2), dim3(256), 4 * (D + 64) * sizeof(float), st, a, b, idx,
+    const size_t lds_b = (size_t)(4 * (D + 64) + 64 * (D + 4)) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)sim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(G, 4), 2), dim3(256), lds_b, st, a, b, idx,
                        1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp);
     return check_launch("sim_infonce_bwd");
 }
@@ -522,8 +580,15 @@ extern "C" int leccr_dstl_fwd(const float* v, const float* c, const float* s, co
     float* lse_tv = reinterpret_cast<float*>(mm + 4);
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("dstl memset");
     hipLaunchKernelGGL(dstl_init_kernel, dim3(1), dim3(1), 0, st, mm);
-    hipLaunchKernelGGL(dstl_scores_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 4 * (2 + n) * D * sizeof(float), st, v, c, s, t,
-                       (int)G, (int)n, (int)D, tv, lab, sc, mm);
+    const size_t own = (size_t)4 * (2 + n) * D * sizeof(float), staged = own + (size_t)2 * 64 * (D + 4) * sizeof(float);
+    if (staged <= 160 * 1024 && (D & 3) == 0) {       // both 64-row tiles fit next to the block's own rows
+        (void)hipFuncSetAttribute((const void*)dstl_scores_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(dstl_scores_kernel<true>, dim3((unsigned)cdiv(G, 4)), dim3(256), staged, st, v, c, s, t, (int)G, (int)n,
+                           (int)D, tv, lab, sc, mm);
+    } else {
+        hipLaunchKernelGGL(dstl_scores_kernel<false>, dim3((unsigned)cdiv(G, 4)), dim3(256), own, st, v, c, s, t, (int)G, (int)n,
+                           (int)D, tv, lab, sc, mm);
+    }
     hipLaunchKernelGGL(dstl_kl_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, tv, lab, sc, mm, alpha, (int)G, lse_tv, loss);
     return check_launch("dstl_fwd");
 }
