@@ -25,6 +25,7 @@ from leccr_amd.evaluation import evaluation_coarse, itm_eval          # noqa: F4
 from leccr_amd.models.model_retrieval_caption import RetrievalModel
 from leccr_amd.optim import create_optimizer
 from leccr_amd.parallel import attach_grad_sync
+from leccr_amd.pipeline import DeferredScalars, DevicePrefetcher
 from leccr_amd.scheduler import create_scheduler
 from leccr_amd.synthetic import MULTI30K_CFG, make_batch
 
@@ -44,22 +45,25 @@ def train(model, data_loader, optimizer, tokenizer, epoch, device, scheduler, co
     for name in ('loss_itc_vs', 'loss_itc_vt', 'loss_itc_st', 'loss_itc_c', 'loss_reg_c'):
         metric_logger.add_meter(name, utils.SmoothedValue(window_size=1, fmt='{value:.4f}'))
     header = 'Train Epoch: [{}]'.format(epoch)
-    for i, (image, text_ls, captions, idx, cap_idx) in enumerate(metric_logger.log_every(data_loader, 50, header)):
-        image = image.to(device, non_blocking=True)
-        idx = idx.to(device, non_blocking=True)
+    names = ('loss_itc_vs', 'loss_itc_vt', 'loss_itc_st', 'loss_itc_c', 'loss_reg_c')
+    deferred = DeferredScalars()          # loss scalars reach the logger one step late, without a host sync per step
+    batches = DevicePrefetcher(data_loader, device)       # batch k+1 is pinned + copied on a side stream during step k
+    for i, (image, text_ls, captions, idx, cap_idx) in enumerate(metric_logger.log_every(batches, 50, header)):
         text_inputs = [tokenizer(text, padding='longest', max_length=config['max_tokens'], return_tensors='pt').to(device)
                        for text in text_ls]
         captions = tokenizer(captions, padding='longest', max_length=config['max_tokens'], return_tensors='pt').to(device)
-        loss_itc_vs, loss_itc_vt, loss_itc_st, loss_itc_c, loss_reg_c = model(image, text_inputs, captions=captions,
-                                                                               idx=idx, epoch=epoch, cap_idx=cap_idx)
-        loss = loss_itc_vs + loss_itc_vt + loss_itc_st + loss_itc_c + loss_reg_c
+        losses = model(image, text_inputs, captions=captions, idx=idx, epoch=epoch, cap_idx=cap_idx)
+        loss = losses[0] + losses[1] + losses[2] + losses[3] + losses[4]
         optimizer.zero_grad()
         loss.backward()
         optimizer.step()
         scheduler.step()
-        vals = torch.stack([loss_itc_vs, loss_itc_vt, loss_itc_st, loss_itc_c, loss_reg_c]).detach().tolist()  # one sync
-        metric_logger.update(loss_itc_vs=vals[0], loss_itc_vt=vals[1], loss_itc_st=vals[2], loss_itc_c=vals[3],
-                             loss_reg_c=vals[4], lr=optimizer.param_groups[0]['lr'])
+        vals = deferred.push(list(losses))
+        if vals is not None:
+            metric_logger.update(lr=optimizer.param_groups[0]['lr'], **dict(zip(names, vals)))
+    vals = deferred.flush()
+    if vals is not None:
+        metric_logger.update(lr=optimizer.param_groups[0]['lr'], **dict(zip(names, vals)))
     metric_logger.synchronize_between_processes()
     print('Averaged stats:', metric_logger.global_avg())
     return {k: '{:.5f}'.format(meter.global_avg) for k, meter in metric_logger.meters.items()}

@@ -10,6 +10,7 @@ import datetime
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 from . import kernels as K
 
@@ -47,26 +48,69 @@ def itm_eval(scores_i2t, scores_t2i, txt2img, img2txt, device='cuda'):
             'img_sumr': img_sumr, 'sumr_avg': sumr_avg, 'sumr_sum': (txt_sumr + img_sumr)}
 
 
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def _gather_rows_varlen(rows, index, total):
+    """Every rank holds some rows of a [total, D] matrix (`rows` [k, D] with their global row numbers `index` [k]);
+    returns the complete matrix on every rank.  One size exchange + two padded all-gathers (RCCL on 'nccl')."""
+    rank, world = _world()
+    D = rows.shape[1]
+    k = torch.tensor([rows.shape[0]], device=rows.device, dtype=torch.int64)
+    sizes = [torch.zeros_like(k) for _ in range(world)]
+    dist.all_gather(sizes, k)
+    kmax = int(max(int(x) for x in sizes))
+    pad_r = torch.zeros(kmax, D, device=rows.device, dtype=rows.dtype)
+    pad_i = torch.full((kmax,), -1, device=rows.device, dtype=torch.int64)
+    pad_r[:rows.shape[0]] = rows
+    pad_i[:rows.shape[0]] = index
+    all_r = [torch.empty_like(pad_r) for _ in range(world)]
+    all_i = [torch.empty_like(pad_i) for _ in range(world)]
+    dist.all_gather(all_r, pad_r)
+    dist.all_gather(all_i, pad_i)
+    out = torch.empty(total, D, device=rows.device, dtype=rows.dtype)
+    for r, i, n in zip(all_r, all_i, sizes):
+        n = int(n)
+        out[i[:n]] = r[:n]
+    return out
+
+
 @torch.no_grad()
-def evaluation_coarse(model, data_loader, tokenizer, device, config):
+def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True):
     """image_Retrieval_caption.py:83-163: text features in chunks of batch_size_test_text, image features through the
     caption interaction, score = image_embeds @ text_embeds^T (one HIP GEMM, f32).  Returns (i2t, t2i) numpy arrays.
-    The reference's all_reduce of the (already complete) score matrix only scales it by W - dropped: ranking-invariant."""
+
+    Under torch.distributed the reference makes EVERY rank encode every text and image and then all-reduces the (already
+    complete) score matrix, which only scales it by W.  Here (shard=True) rank r encodes text chunks and image batches
+    r, r+W, r+2W, ...; the embeddings are all-gathered once and every rank forms the same score matrix: 1/W of the encoder
+    work per rank, identical scores."""
     model.eval()
+    rank, world = _world()
+    if not shard:
+        rank, world = 0, 1
     print('Computing features for evaluation...')
     start_time = time.time()
     texts = data_loader.dataset.text
     num_text = len(texts)
     text_bs = config['batch_size_test_text']
-    text_embeds = []
-    for i in range(0, num_text, text_bs):
+    text_embeds, text_rows = [], []
+    for c, i in enumerate(range(0, num_text, text_bs)):
+        if c % world != rank:
+            continue
         text = texts[i: min(num_text, i + text_bs)]
         ti = tokenizer(text, padding='max_length', truncation=True, max_length=config['max_tokens'],
                        return_tensors='pt').to(device)
         text_embeds.append(model.get_features(text_embeds=model.get_text_embeds(ti.input_ids, ti.attention_mask)))
-    text_embeds = torch.cat(text_embeds, dim=0)
-    image_embeds = []
-    for image, generated_captions, img_id in data_loader:
+        text_rows.append(torch.arange(i, i + len(text), device=device))
+    image_embeds, image_rows = [], []
+    n_img = 0
+    for c, (image, generated_captions, img_id) in enumerate(data_loader):
+        first, n_img = n_img, n_img + image.shape[0]
+        if c % world != rank:
+            continue
         image = image.to(device)
         image_feat, _ = model.get_vision_embeds(image)
         ci = tokenizer(generated_captions, padding='max_length', truncation=True, max_length=config['max_tokens'],
@@ -76,8 +120,17 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config):
         image_feat, _, _ = model.interaction_with_caption(image_embeds=image_feat, caption_embeds=caption_embed,
                                                           key_padding_mask=key_padding_mask)
         image_embeds.append(model.get_features(image_embeds=image_feat.transpose(0, 1).contiguous()))
-    image_embeds = torch.cat(image_embeds, dim=0)
-    score_matrix_i2t = K.gemm(image_embeds.float().contiguous(), text_embeds.float().contiguous())
+        image_rows.append(torch.arange(first, n_img, device=device))
+
+    def assemble(chunks, rows, total):
+        D = model.embed_dim
+        e = torch.cat(chunks, dim=0).float() if chunks else torch.zeros(0, D, device=device)
+        r = torch.cat(rows) if rows else torch.zeros(0, device=device, dtype=torch.int64)
+        return e.contiguous() if world == 1 else _gather_rows_varlen(e.contiguous(), r, total)
+
+    text_embeds = assemble(text_embeds, text_rows, num_text)
+    image_embeds = assemble(image_embeds, image_rows, n_img)
+    score_matrix_i2t = K.gemm(image_embeds.contiguous(), text_embeds.contiguous())
     score_matrix_t2i = score_matrix_i2t.t().contiguous()
     print('Evaluation time {}'.format(str(datetime.timedelta(seconds=int(time.time() - start_time)))))
     return score_matrix_i2t.cpu().numpy(), score_matrix_t2i.cpu().numpy()

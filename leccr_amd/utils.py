@@ -48,6 +48,8 @@ class SmoothedValue:
         return self.deque[-1]
 
     def __str__(self):
+        if not self.deque:          # nothing logged yet (the train loop reports losses one step late, see pipeline.py)
+            return '-'
         return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, value=self.value)
 
 

@@ -53,3 +53,46 @@ def test_two_rank_losses_and_gradients_match_reference_ddp():
     for r in (0, 1):
         n, bad = ret[r]
         assert n > 100 and not bad, (r, bad)
+
+
+def _eval_worker(rank, world, port, ret):
+    import types
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from leccr_amd.evaluation import evaluation_coarse
+    from tests.helpers import load_npz, weights
+    from tests.test_model_gpu import MODEL_VIT, TINY_BERT, build
+    z = load_npz('model_tiny_w1.npz')
+    model = build(dict(clip_geometry=MODEL_VIT, text_config=TINY_BERT, compute_dtype='fp32'), weights(z))
+    ids_s, m_s = torch.from_numpy(z['ids_s']), torch.from_numpy(z['mask_s'])
+    ids_c, m_c = torch.from_numpy(z['ids_c']), torch.from_numpy(z['mask_c'])
+    image = torch.from_numpy(z['image'])
+
+    class Tok:
+        def __call__(self, text, **kw):
+            ids, m = (ids_s, m_s) if text[0][0] == 't' else (ids_c, m_c)
+            sel = torch.tensor([int(t[1:]) for t in text])
+            o = types.SimpleNamespace(input_ids=ids[sel], attention_mask=m[sel])
+            o.to = lambda dev: types.SimpleNamespace(input_ids=o.input_ids.to(dev), attention_mask=o.attention_mask.to(dev))
+            return o
+
+    class Loader(list):
+        dataset = types.SimpleNamespace(text=[f't{i}' for i in range(8)])
+    # 3 image batches (3 + 3 + 2) and 3 text chunks (3 + 3 + 2): ragged shares per rank
+    loader = Loader([(image[a:b], [f'c{j}' for j in range(a, b)], None) for a, b in ((0, 3), (3, 6), (6, 8))])
+    cfg = {'batch_size_test_text': 3, 'max_tokens': 200}
+    i2t, t2i = evaluation_coarse(model, loader, Tok(), 'cuda', cfg)                 # sharded over the 2 ranks
+    full, _ = evaluation_coarse(model, loader, Tok(), 'cuda', cfg, shard=False)     # every rank encodes everything
+    ret[rank] = (i2t.shape, float(np.max(np.abs(i2t - full))), bool(np.array_equal(t2i, i2t.T)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_evaluation_matches_unsharded():
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_eval_worker, args=(2, 29653, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        shape, err, tr = ret[r]
+        assert shape == (8, 8) and err <= 1e-6 and tr, (r, shape, err, tr)

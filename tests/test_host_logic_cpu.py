@@ -139,3 +139,21 @@ def test_launcher_and_script_cli_match_the_reference_flags():
     t = task.build_parser().parse_args(['--config', 'c.yaml', '--bs', '128', '--epoch', '2', '--evaluate'])
     assert t.bs == 128 and t.evaluate and t.checkpoint == 'null' and t.distributed is True and t.seed == 42
     assert {'train', 'evaluation_coarse', 'itm_eval', 'main'} <= set(dir(task))
+
+
+def test_prefetcher_and_deferred_scalars_passthrough_on_cpu():
+    """leccr_amd.pipeline: same batches in the same order; scalars come back one push late; flush drains."""
+    from leccr_amd.pipeline import DeferredScalars, DevicePrefetcher
+    from leccr_amd.synthetic import make_batch
+    batches = [make_batch(2, res=32, L_t=8, L_c=8, vocab=100, seed=s) for s in range(3)]
+    loader = [(b['image'], b['text'], b['captions'], b['idx'], None) for b in batches]
+    out = list(DevicePrefetcher(loader, 'cpu'))
+    assert len(out) == 3 and len(DevicePrefetcher(loader, 'cpu')) == 3
+    for got, want in zip(out, loader):
+        assert torch.equal(got[0], want[0]) and torch.equal(got[3], want[3]) and got[4] is None
+        assert torch.equal(got[1][1].input_ids, want[1][1].input_ids) and type(got[2]) is type(want[2])
+    assert list(DevicePrefetcher([], 'cpu')) == []
+    d = DeferredScalars()
+    assert d.push([torch.tensor(1.0), torch.tensor(2.0)]) is None
+    assert d.push([torch.tensor(3.0), torch.tensor(4.0)]) == [1.0, 2.0]
+    assert d.flush() == [3.0, 4.0] and d.flush() is None
