@@ -157,3 +157,26 @@ def test_prefetcher_and_deferred_scalars_passthrough_on_cpu():
     assert d.push([torch.tensor(1.0), torch.tensor(2.0)]) is None
     assert d.push([torch.tensor(3.0), torch.tensor(4.0)]) == [1.0, 2.0]
     assert d.flush() == [3.0, 4.0] and d.flush() is None
+
+
+def test_bigfile_reader_matches_the_reference_semantics(tmp_path):
+    """leccr_amd.bigfile.BigFile on a generated store: de-duplication, unknown names dropped, row order, by-index reads."""
+    from leccr_amd.bigfile import BigFile
+    rows, dims = 37, 12
+    feats = np.random.RandomState(3).randn(rows, dims).astype(np.float32)
+    names = [f'video{i}_{i % 5}' for i in range(rows)]
+    (tmp_path / 'shape.txt').write_text(f'{rows} {dims}\n')
+    (tmp_path / 'id.txt').write_text(' '.join(names))
+    feats.tofile(tmp_path / 'feature.bin')
+    bf = BigFile(str(tmp_path))
+    assert bf.shape() == [rows, dims]
+    got_names, vecs = bf.read(['video30_0', 'video2_2', 'nope', 'video30_0', 'video17_2'])
+    assert got_names == ['video2_2', 'video17_2', 'video30_0']                 # increasing row number, unique, known only
+    assert np.array_equal(np.asarray(vecs, dtype=np.float32), feats[[2, 17, 30]])
+    assert bf.read_one('video5_0') == feats[5].tolist()
+    n2, arr = bf.read_array([36, 0, 36], isname=False)
+    assert n2 == [names[0], names[36]] and arr.dtype == np.float32 and np.array_equal(arr, feats[[0, 36]])
+    assert bf.read(['absent']) == ([], [])
+    (tmp_path / 'shape.txt').write_text(f'{rows + 1} {dims}\n')
+    with pytest.raises((AssertionError, ValueError)):
+        BigFile(str(tmp_path))
