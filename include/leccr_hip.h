@@ -208,13 +208,18 @@ int leccr_rank_of_gt(const float* scores, const int32_t* gt, int32_t* out, int64
  *   Adam update is NOT what HF does - HF applies  p += -step_size * m/denom  then  p += -lr*wd*p ; bias
  *   correction on.  One launch over a flat f32 arena; `wd_mask` [n_seg] gives per-segment weight decay via
  *   seg_end offsets (sorted, cumulative, in elements).
+ *   lp_bf16 (optional, n bf16): the bf16 compute copy of the updated parameters, written in the same pass;
+ *   seg_wd < 0 marks a segment the optimizer skips (its bf16 copy is still refreshed).
  * cast_bf16: dst_bf16[i] = src_f32[i];  transpose_bf16: dst[c,r] = bf16(src[r,c]) for an [R,C] f32 matrix.
  */
 int leccr_adamw(float* p, const float* g, float* m, float* v, int64_t n, const int64_t* seg_end,
                 const float* seg_wd, int64_t n_seg, float lr, float beta1, float beta2, float eps, int64_t step,
-                float gscale, void* stream);
+                float gscale, void* lp_bf16, void* stream);
 int leccr_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int leccr_transpose_cast(const float* src, void* dst, int64_t R, int64_t C, int dtype, void* stream);
+/* Many transposes in one launch.  table: n rows of 5 int64 {first tile index (cumulative, 32x32 tiles, row-major over
+ * ceil(R/32) x ceil(C/32)), src pointer (f32 [R,C]), dst pointer (bf16 [C,R]), R, C}, in device memory. */
+int leccr_transpose_cast_batched(const int64_t* table, int64_t n, int64_t total_tiles, void* stream);
 int leccr_axpy(const void* x, void* y, float a, int64_t n, int dtype, void* stream);   /* y += a*x */
 /* Elementwise dropout y[i] = keep(seed, i) ? x[i] / (1-p) : 0 (nn.Dropout at attention.py:29-37,92-100; HF
  * hidden_dropout_prob).  The same call on the incoming gradient is the backward.  y may alias x. */

@@ -56,9 +56,10 @@ _SIGS = {
     'leccr_capreg_fwd': ([vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_capreg_bwd': ([vp, f32, vp, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_rank_of_gt': ([vp, vp, vp, i64, i64, i64, i64, vp], C.c_int),
-    'leccr_adamw': ([vp, vp, vp, vp, i64, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp], C.c_int),
+    'leccr_adamw': ([vp, vp, vp, vp, i64, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp, vp], C.c_int),
     'leccr_cast_bf16': ([vp, vp, i64, vp], C.c_int),
     'leccr_transpose_cast': ([vp, vp, i64, i64, C.c_int, vp], C.c_int),
+    'leccr_transpose_cast_batched': ([vp, i64, i64, vp], C.c_int),
     'leccr_axpy': ([vp, vp, f32, i64, C.c_int, vp], C.c_int),
     'leccr_dropout': ([vp, vp, i64, f32, C.c_uint64, C.c_int, vp], C.c_int),
 }

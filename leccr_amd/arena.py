@@ -72,6 +72,7 @@ class ParamArena:
         self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
         self.lp = torch.zeros(self.numel, device=device, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
         self._transposed = []
+        self._tt_table, self._tt_tiles = None, 0
         self.touched = [False] * len(params)
         for i, (p, o) in enumerate(zip(params, self.offsets)):
             view = self.data[o:o + p.numel()].view(p.shape)
@@ -108,13 +109,23 @@ class ParamArena:
         self._transposed.append(holder)
 
     @torch.no_grad()
-    def refresh(self):
+    def refresh(self, adamw_wrote_lp=False):
         """Rebuild the low-precision compute copies from the f32 master weights (call once per optimizer step)."""
         if self.lp is None:
             return
-        K.cast_bf16(self.data, self.lp)
-        for h in self._transposed:
-            K.transpose_cast(h.data, h._lpt)
+        if not adamw_wrote_lp:
+            K.cast_bf16(self.data, self.lp)
+        if self._transposed:
+            if self._tt_table is None or self._tt_table.shape[0] != len(self._transposed):
+                rows, tiles = [], 0
+                for h in self._transposed:
+                    R, Cn = h.data.shape
+                    assert h.data.is_contiguous() and h.data.dtype == torch.float32
+                    rows.append([tiles, h.data.data_ptr(), h._lpt.data_ptr(), R, Cn])
+                    tiles += ((R + 31) // 32) * ((Cn + 31) // 32)
+                self._tt_table = torch.tensor(rows, dtype=torch.int64, device=self.data.device)
+                self._tt_tiles = tiles
+            K.transpose_cast_batched(self._tt_table, self._tt_tiles)       # one launch for all [in,out] copies
 
     # ------------------------------------------------------------------ gradients
     def zero_grad(self):
@@ -151,7 +162,7 @@ class ParamArena:
         self.step_count += 1
         seg_end, seg_wd = self._segments(decay_of)
         K.adamw(self.data, self.grad, self.state_m, self.state_v, seg_end, seg_wd, lr, betas[0], betas[1], eps,
-                self.step_count, gscale)
+                self.step_count, gscale, lp=self.lp)          # also rewrites the bf16 compute copy (bf16 mode)
 
 
 class _Packed:

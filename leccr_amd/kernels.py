@@ -301,10 +301,14 @@ def rank_of_gt(scores, gt):
     return out
 
 
-def adamw(p, g, m, v, seg_end, seg_wd, lr, beta1, beta2, eps, step, gscale=1.0):
+def adamw(p, g, m, v, seg_end, seg_wd, lr, beta1, beta2, eps, step, gscale=1.0, lp=None):
+    """lp: optional bf16 tensor of p's size that receives the bf16 copy of the updated parameters in the same pass."""
     n = p.numel()
+    if lp is not None:
+        assert lp.dtype == torch.bfloat16 and lp.numel() == n and lp.is_contiguous()
     check(lib().leccr_adamw(ptr(p), ptr(g), ptr(m), ptr(v), n, ptr(seg_end), ptr(seg_wd), seg_end.numel(), float(lr),
-                            float(beta1), float(beta2), float(eps), int(step), float(gscale), stream()), 'leccr_adamw')
+                            float(beta1), float(beta2), float(eps), int(step), float(gscale), ptr(lp), stream()),
+          'leccr_adamw')
 
 
 def cast_bf16(src, dst):
@@ -318,6 +322,13 @@ def transpose_cast(src, dst):
     assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst.numel() == R * Cn
     check(lib().leccr_transpose_cast(ptr(src), ptr(dst), R, Cn, dtype_code(dst), stream()), 'leccr_transpose_cast')
     return dst
+
+
+def transpose_cast_batched(table, total_tiles):
+    """table: int64 [n, 5] on the device (see leccr_hip.h)."""
+    assert table.dtype == torch.int64 and table.dim() == 2 and table.shape[1] == 5 and table.is_contiguous()
+    check(lib().leccr_transpose_cast_batched(ptr(table), table.shape[0], int(total_tiles), stream()),
+          'leccr_transpose_cast_batched')
 
 
 def axpy(x, y, a):

@@ -41,7 +41,7 @@ class ArenaAdamW(torch.optim.Optimizer):
             self.grad_sync()
         self.arena.mark_autograd_grads()
         self.arena.adamw_step(g['lr'], g['betas'], g['eps'], self._decay_of, self.grad_scale)
-        self.arena.refresh()
+        self.arena.refresh(adamw_wrote_lp=True)
 
     def state_dict(self):
         a = self.arena

@@ -412,6 +412,27 @@ def test_rank_of_gt_and_optimizer(K):
     wb = torch.empty(70 * 130, dtype=torch.bfloat16, device=DEV)
     K.cast_bf16(w.to(DEV).reshape(-1), wb)
     assert torch.equal(wb.cpu(), w.reshape(-1).to(torch.bfloat16))
+    # AdamW with the fused bf16 copy (n not a multiple of 4: scalar tail) and a skipped segment (wd < 0)
+    n2 = 1003
+    p2, g2 = _rand((n2 + 1,), torch.float32, 84)[:n2], _rand((n2,), torch.float32, 85)
+    base = torch.zeros(n2 + 5, device=DEV)                       # 16-byte aligned arena start
+    pd2 = base[:n2]; pd2.copy_(p2)
+    lp = torch.zeros(n2, dtype=torch.bfloat16, device=DEV)
+    md2, vd2 = torch.zeros(n2, device=DEV), torch.zeros(n2, device=DEV)
+    K.adamw(pd2, g2.to(DEV), md2, vd2, torch.tensor([400, n2], dtype=torch.int64, device=DEV),
+            torch.tensor([-1.0, 0.01], device=DEV), lr, b1, b2, eps, 1, lp=lp)
+    assert torch.equal(pd2[:400].cpu(), p2[:400]) and not torch.equal(pd2[400:].cpu(), p2[400:])     # first segment untouched
+    assert torch.equal(lp, pd2.to(torch.bfloat16))                                                     # copy covers both
+    # all [in,out] copies in one launch == one transpose_cast per matrix
+    mats = [_rand(shape, torch.float32, 86 + i).to(DEV) for i, shape in enumerate([(70, 130), (32, 32), (5, 257), (96, 64)])]
+    outs = [torch.empty(m_.shape[1], m_.shape[0], dtype=torch.bfloat16, device=DEV) for m_ in mats]
+    rows, tiles = [], 0
+    for m_, o_ in zip(mats, outs):
+        rows.append([tiles, m_.data_ptr(), o_.data_ptr(), m_.shape[0], m_.shape[1]])
+        tiles += ((m_.shape[0] + 31) // 32) * ((m_.shape[1] + 31) // 32)
+    K.transpose_cast_batched(torch.tensor(rows, dtype=torch.int64, device=DEV), tiles)
+    for m_, o_ in zip(mats, outs):
+        assert torch.equal(o_, m_.t().contiguous().to(torch.bfloat16))
 
 
 # ------------------------------------------------------------------------------------------ 256x256 persistent GEMM
