@@ -92,7 +92,10 @@ class XVLMBase(nn.Module):
         self.allgather = allgather
         self.init_params = []
         self.config = config
-        self.clip_encoder, vision_width = build_clip_encoder(config)
+        if getattr(self, '_with_clip_encoder', True):
+            self.clip_encoder, vision_width = build_clip_encoder(config)
+        else:                       # XVLMBase_video (models/xvlm_video.py:173-192): frame features in, no image tower
+            self.clip_encoder, vision_width = None, config['vision_width']
         self.text_encoder, text_width = build_text_encoder(config)
         self.vision_width, self.text_width = vision_width, text_width
         if use_contrastive_loss:
@@ -130,18 +133,21 @@ class XVLMBase(nn.Module):
         for n, p in self.named_parameters():
             p._leccr_unused = is_unused_parameter(n)
         self.arena = ParamArena(self, self.compute_dtype, dev)
-        self.clip_encoder.compute_dtype = self.compute_dtype
         self.text_encoder.compute_dtype = self.compute_dtype
         a = self.arena
-        vis = self.clip_encoder.visual
-        cw = vis.conv1.weight
-        cw._lp2d, cw._g2d = cw._lp.view(cw.shape[0], -1), cw._g.view(cw.shape[0], -1)
-        assert cw._lp2d.shape[1] % 64 == 0 or self.compute_dtype == torch.float32, \
-            'patch size whose 3*p*p is not a multiple of 64 needs K padding (ViT-L/14): not wired yet'
-        a.need_transposed(vis.proj)
+        vis_proj = None
+        if self.clip_encoder is not None:
+            self.clip_encoder.compute_dtype = self.compute_dtype
+            vis = self.clip_encoder.visual
+            cw = vis.conv1.weight
+            cw._lp2d, cw._g2d = cw._lp.view(cw.shape[0], -1), cw._g.view(cw.shape[0], -1)
+            assert cw._lp2d.shape[1] % 64 == 0 or self.compute_dtype == torch.float32, \
+                'patch size whose 3*p*p is not a multiple of 64 needs K padding (ViT-L/14): not wired yet'
+            vis_proj = vis.proj
+            a.need_transposed(vis_proj)
         for name, p in self.named_parameters():
             if p.dim() == 2 and not getattr(p, '_leccr_unused', False) and 'embeddings' not in name \
-                    and name != 'clip_encoder.visual.positional_embedding' and p is not vis.proj:
+                    and name != 'clip_encoder.visual.positional_embedding' and p is not vis_proj:
                 a.need_transposed(p)
         for layer in self.text_encoder.encoder.layer:
             a.need_transposed(layer._qkv_w)

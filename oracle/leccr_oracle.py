@@ -288,6 +288,74 @@ def retrieval_forward(sd, cfg, image, ids_s, mask_s, ids_t, mask_t, ids_c, mask_
     return l_vs + loss_cv, l_vt, l_st, l_c * cfg['weight_caption_loss'], loss_reg * cfg['weight_reg_loss']
 
 
+# --------------------------------------------------------------------------------------- video model
+def video_encode(sd, video, video_mask, heads=8):
+    """RetrievalModel.get_vision_embeds of the video model (models/video_model_retrieval_caption.py:30-34):
+    SelfAttention stack (models/attention.py:87-128 - the CrossAttentionLayer arithmetic with q = k = v = src) over the
+    frame features, padded frames masked as keys.  video [b,F,vw], video_mask [b,F] bool (True = real frame).
+    Returns (frame tokens [b,F,vw], key padding mask = ~video_mask)."""
+    kpm = ~video_mask.bool()
+    out, i = video, 0
+    while f'vid_encoder.layers.{i}.linear1.weight' in sd:          # each layer attends to ITS OWN input (q = k = v = src)
+        layer = {k: v for k, v in sd.items() if k.startswith(f'vid_encoder.layers.{i}.')}
+        one = {k.replace(f'layers.{i}.', 'layers.0.', 1): v for k, v in layer.items()}
+        out = cross_attention(one, 'vid_encoder.', out, out, kpm, heads)
+        i += 1
+    return out, kpm
+
+
+def video_interaction_with_caption(sd, video_embeds, caption_hidden, key_padding_mask, video_kpm):
+    """video_model_retrieval_caption.py:96-108: as the image model, except that crossattn2 (caption queries attending to
+    the frames) masks the padded frames; crossattn (frames attending to the caption queries) is unmasked."""
+    b = video_embeds.shape[0]
+    queries = sd['queries'].permute(1, 0, 2).expand(b, -1, -1)
+    cap = F.linear(caption_hidden, sd['caption_proj.weight'], sd['caption_proj.bias'])
+    ori_caption = cross_attention(sd, 'crossattn_query.', queries, cap, key_padding_mask)
+    after_video = cross_attention(sd, 'crossattn.', video_embeds, ori_caption)
+    after_caption = cross_attention(sd, 'crossattn2.', ori_caption, video_embeds, video_kpm)
+    return after_video, after_caption, ori_caption
+
+
+def video_get_features(sd, video_embeds, video_mask):
+    """XVLMBase_video.get_features, vis_pooling='mean' (models/xvlm_video.py:260-272): masked mean over the frames ->
+    vision_proj -> L2 normalise."""
+    m = video_mask.unsqueeze(-1).to(video_embeds.dtype)
+    pooled = (video_embeds * m).sum(1) / m.sum(1)
+    return F.normalize(F.linear(pooled, sd['vision_proj.weight'], sd['vision_proj.bias']), dim=-1)
+
+
+def video_caption_vision_loss(sd, ori_caption, ori_video, idx):
+    """caption_vision_loss of the video model (video_model_retrieval_caption.py:144-169): the image model's arithmetic on
+    the LOCAL batch (its all-gathers are commented out), padded frames included as they are."""
+    cap = F.normalize(F.linear(ori_caption, sd['cproj.weight'], sd['cproj.bias']), dim=1)
+    vid = F.normalize(F.linear(ori_video, sd['vproj.weight'], sd['vproj.bias']), dim=1)
+    sim = torch.einsum('icd,jvd->ijcv', cap, vid).mean(-1).mean(-1)
+    lab = soft_labels(idx.view(-1, 1))
+    return -(torch.log_softmax(sim, 1) * lab).sum(1).mean()
+
+
+def video_retrieval_forward(sd, cfg, video, video_mask, ids_s, mask_s, ids_t, mask_t, ids_c, mask_c, idx, text_heads):
+    """RetrievalModel.forward of the video model (video_model_retrieval_caption.py:180-227) -> the 5 weighted losses."""
+    vid, vkpm = video_encode(sd, video, video_mask)
+    with torch.no_grad():
+        cap_hidden = bert_forward(sd, 'text_encoder.', ids_c, mask_c, text_heads)
+    after_video, after_caption, ori_caption = video_interaction_with_caption(sd, vid, cap_hidden, ~mask_c.bool(), vkpm)
+    loss_cv = video_caption_vision_loss(sd, ori_caption, vid, idx) * cfg['weight_cv_loss']
+    loss_reg = caption_regularization(ori_caption)
+    feat_v = video_get_features(sd, after_video, video_mask)
+    feat_s = get_features(sd, text_embeds=bert_forward(sd, 'text_encoder.', ids_s, mask_s, text_heads))
+    feat_t = get_features(sd, text_embeds=bert_forward(sd, 'text_encoder.', ids_t, mask_t, text_heads))
+    temp = sd['temp']
+    l_vs = contrastive_loss(feat_v, feat_s, temp, idx)
+    l_vt = contrastive_loss(feat_v, feat_t, temp, idx)
+    l_st = contrastive_loss(feat_s, feat_t, temp, idx)
+    cq = F.linear(after_caption, sd['caption_proj1.weight'], sd['caption_proj1.bias'])
+    l_c = caption_contrastive_loss(cq, feat_s, temp) + caption_contrastive_loss(cq, feat_t, temp)
+    wd = cfg['weight_dstl_loss']
+    l_vt = l_vt * (1 - wd) + dstl_loss(feat_v, cq, feat_s, feat_t) * wd
+    return l_vs + loss_cv, l_vt, l_st, l_c * cfg['weight_caption_loss'], loss_reg * cfg['weight_reg_loss']
+
+
 # --------------------------------------------------------------------------------------- evaluation
 def itm_eval(scores_i2t, scores_t2i, txt2img, img2txt):
     """itm_eval (image_Retrieval_caption.py:261-317).  rank of a ground-truth item = number of strictly larger

@@ -323,6 +323,79 @@ def fixture_itm_eval():
     print('itm_eval', {k: v['result']['sumr_sum'] for k, v in cases.items()})
 
 
+# ----------------------------------------------------------------------------- video model (SURVEY.md 8c `video_step`)
+VIDEO_CFG = dict(TINY_CFG, vision_width=64, vision_layer=2)
+
+
+def import_reference_video():
+    """models/video_model_retrieval_caption.py does `from models import XVLMBase_video`, which models/__init__.py has
+    commented out, and xvlm_video.py imports models.box_ops (torchvision): pre-seed an empty box_ops module, import
+    xvlm_video and publish its class under the name the video model asks for."""
+    import_reference()
+    import models
+    if 'models.box_ops' not in sys.modules:
+        sys.modules['models.box_ops'] = types.ModuleType('models.box_ops')
+        models.box_ops = sys.modules['models.box_ops']
+    import models.xvlm_video as xvlm_video
+    models.XVLMBase_video = xvlm_video.XVLMBase_video
+    return xvlm_video
+
+
+def build_video_model(seed=41):
+    xvlm_video = import_reference_video()
+
+    def _bert(config=None):
+        from transformers import BertConfig, BertModel
+        return BertModel(BertConfig(**TINY_BERT)), TINY_BERT['hidden_size']
+
+    xvlm_video.build_text_encoder = _bert
+    from models.video_model_retrieval_caption import RetrievalModel
+    torch.manual_seed(seed)
+    model = RetrievalModel(dict(VIDEO_CFG))
+    model.init_caption_encoder()
+    randomize_(model, seed)
+    return model.eval()
+
+
+def make_video_batch(seed, b, frames=8):
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(b, frames, VIDEO_CFG['vision_width'], generator=g)
+    lens = torch.randint(3, frames + 1, (b,), generator=g)
+    lens[0], lens[1] = frames, 3                       # one full clip, one at the minimum; the rest ragged
+    vmask = torch.arange(frames)[None, :] < lens[:, None]          # True = real frame
+    ids_s, m_s = make_ids(g, b, 7, TINY_BERT['vocab_size'])
+    ids_t, m_t = make_ids(g, b, 9, TINY_BERT['vocab_size'])
+    ids_c, m_c = make_ids(g, b, 12, TINY_BERT['vocab_size'])
+    idx = torch.arange(b) + 100
+    idx[b - 1] = idx[1]
+    return dict(video=video, video_mask=vmask, ids_s=ids_s, mask_s=m_s, ids_t=ids_t, mask_t=m_t, ids_c=ids_c,
+                mask_c=m_c, idx=idx)
+
+
+def fixture_video_w1():
+    model = build_video_model()
+    batch = make_video_batch(52, 8)
+    with torch.no_grad():
+        v, vm = model.get_vision_embeds(batch['video'], batch['video_mask'])
+        c = model.get_caption_embeds(batch['ids_c'], batch['mask_c'])
+        a_img, a_cap, o_cap = model.interaction_with_caption(image_embeds=v, caption_embeds=c,
+                                                             key_padding_mask=~batch['mask_c'].bool(), video_mask=vm)
+        feat_v = model.get_features(a_img.transpose(0, 1).contiguous(), None,
+                                    vis_mask=batch['video_mask'].unsqueeze(-1))
+    losses = model(batch['video'], batch['video_mask'],
+                   [Enc(batch['ids_s'], batch['mask_s']), Enc(batch['ids_t'], batch['mask_t'])],
+                   captions=Enc(batch['ids_c'], batch['mask_c']), idx=batch['idx'])
+    sum(losses).backward()
+    out = {k: v_.numpy() for k, v_ in batch.items()}
+    out.update({'vision_embeds': v.numpy(), 'caption_hidden': c.numpy(), 'after_image': a_img.numpy(),
+                'after_caption': a_cap.numpy(), 'ori_caption': o_cap.numpy(), 'feat_v': feat_v.numpy(),
+                'losses': np.array([float(l) for l in losses], dtype=np.float64)})
+    out.update(sd_np(model))
+    out.update(grads_np(model))
+    np.savez_compressed(os.path.join(OUT, 'video_tiny_w1.npz'), **out)
+    print('video_tiny_w1 losses', out['losses'])
+
+
 def main():
     torch.set_num_threads(4)
     clip_model, xvlm = import_reference()
@@ -334,6 +407,7 @@ def main():
     fixture_model_w1(clip_model, xvlm)
     fixture_losses(clip_model, xvlm)
     fixture_itm_eval()
+    fixture_video_w1()
     dist.destroy_process_group()
     fixture_model_w2()
 

@@ -271,3 +271,110 @@ def test_training_script_synthetic_epoch(tmp_path):
     assert set(ck) == {'model', 'optimizer', 'lr_scheduler', 'config', 'epoch'}
     assert 'text_encoder.embeddings.word_embeddings.weight' in ck['model']
     assert model.arena.step_count == 3
+
+
+# ----------------------------------------------------------------------------------------- video model
+VIDEO_CFG = dict(TINY_CFG, vision_width=64, vision_layer=2)
+
+
+def build_video(cfg_extra, state=None, seed=0):
+    from leccr_amd.models.video_model_retrieval_caption import RetrievalModel
+    torch.manual_seed(seed)
+    cfg = dict(VIDEO_CFG)
+    cfg.update(cfg_extra)
+    m = RetrievalModel(cfg)
+    m.init_caption_encoder()
+    if state is not None:
+        msg = m.load_state_dict(state, strict=False)
+        assert not msg.unexpected_keys, msg.unexpected_keys
+        assert all(k.startswith('caption_encoder.') for k in msg.missing_keys), msg.missing_keys
+    return m.to(DEV).eval()
+
+
+def run_video(model, z):
+    g = lambda k: T(z[k]).to(DEV)
+    return model(g('video'), g('video_mask'), [Enc(g('ids_s'), g('mask_s')), Enc(g('ids_t'), g('mask_t'))],
+                 captions=Enc(g('ids_c'), g('mask_c')), idx=g('idx'))
+
+
+def test_video_reference_fixture_forward_backward_f32():
+    """The HIP-backed video RetrievalModel with the REFERENCE-captured weights (tests/golden/video_tiny_w1.npz, clips of
+    3..8 frames) reproduces the reference's stage outputs, five losses and parameter gradients."""
+    z = load_npz('video_tiny_w1.npz')
+    model = build_video(dict(text_config=TINY_BERT, compute_dtype='fp32'), weights(z))
+    vmask = T(z['video_mask']).to(DEV)
+    with torch.no_grad():
+        v, kpm = model.get_vision_embeds(T(z['video']).to(DEV), vmask)
+        assert kpm.dtype == torch.bool and torch.equal(kpm, ~vmask)
+        assert max_err(v, z['vision_embeds']) < 5e-5
+        c = model.get_caption_embeds(T(z['ids_c']).to(DEV), T(z['mask_c']).to(DEV))
+        a_vid, a_cap, o_cap = model.interaction_with_caption(image_embeds=v, caption_embeds=c,
+                                                             key_padding_mask=~T(z['mask_c']).to(DEV).bool(),
+                                                             video_mask=kpm)
+        assert max_err(a_vid, z['after_image']) < 5e-5
+        assert max_err(a_cap, z['after_caption']) < 5e-5
+        assert max_err(o_cap, z['ori_caption']) < 5e-5
+        fv = model.get_features(a_vid.transpose(0, 1).contiguous(), None, vis_mask=vmask.unsqueeze(-1))
+        assert max_err(fv, z['feat_v']) < 2e-5
+    losses = run_video(model, z)
+    got = np.array([float(l) for l in losses])
+    assert np.max(np.abs(got - z['losses'])) < 1e-4, (got, z['losses'])
+    model.arena.zero_grad()
+    sum(losses).backward()
+    named = dict(model.named_parameters())
+    bad, n = [], 0
+    for k, g in z.items():
+        if k.startswith('g/'):
+            n += 1
+            if not grad_close(named[k[2:]].grad, g, 2e-3, atol=2e-6):
+                bad.append((k, max_err(named[k[2:]].grad, g), float(np.abs(g).max())))
+    assert n > 90 and not bad, bad[:8]
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_video_production_kernels_vs_oracle(dtype):
+    """vision_width 512 (8 heads of 64: the MFMA attention and GEMM kernels), 8 frames, ragged clips, vs the CPU oracle."""
+    from oracle import leccr_oracle as O
+    model = build_video(dict(text_config=MID_BERT, compute_dtype=dtype, embed_dim=256, vision_width=512, vision_layer=2),
+                        seed=5)
+    with torch.no_grad():
+        model.queries.normal_(0, 0.5)
+    b, F = 16, 8
+    g = torch.Generator().manual_seed(11)
+    video = torch.randn(b, F, 512, generator=g)
+    lens = torch.randint(3, F + 1, (b,), generator=g)
+    lens[0] = F
+    vmask = torch.arange(F)[None] < lens[:, None]
+    tb = _mid_batch(b=b)
+    sd = {k: v.detach().cpu().float().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = {k: TINY_CFG[k] for k in ('weight_reg_loss', 'weight_caption_loss', 'weight_dstl_loss', 'weight_cv_loss')}
+    ref = O.video_retrieval_forward(sd, cfg, video, vmask, tb['ids_s'], tb['mask_s'], tb['ids_t'], tb['mask_t'], tb['ids_c'],
+                                    tb['mask_c'], tb['idx'], text_heads=2)
+    sum(ref).backward()
+    losses = model(video.to(DEV), vmask.to(DEV), [Enc(tb['ids_s'].to(DEV), tb['mask_s'].to(DEV)),
+                                                  Enc(tb['ids_t'].to(DEV), tb['mask_t'].to(DEV))],
+                   captions=Enc(tb['ids_c'].to(DEV), tb['mask_c'].to(DEV)), idx=tb['idx'].to(DEV))
+    tol = 1e-3 if dtype == 'fp32' else 5e-3
+    for a, r in zip(losses, ref):
+        assert abs(float(a) - float(r)) <= tol * max(1.0, abs(float(r))), (dtype, [float(x) for x in losses], [float(x) for x in ref])
+    model.arena.zero_grad()
+    sum(losses).backward()
+    rows, gmax = [], 0.0
+    for name, p in model.named_parameters():
+        r = sd[name].grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, name
+            continue
+        gg, r = p.grad.detach().cpu().double(), r.double()
+        rows.append((name, float((gg - r).norm()), float(r.norm()), float((gg * r).sum() / (gg.norm() * r.norm() + 1e-30))))
+        gmax = max(gmax, float(r.norm()))
+    assert len(rows) > 90
+    bad = []
+    for name, err, rn, cos in rows:
+        if rn < 1e-6 * gmax:
+            continue
+        rel = err / rn
+        ok = rel <= 1e-3 if dtype == 'fp32' else ((rel <= 0.15 and cos >= 0.985) if rn >= 1e-2 * gmax else (rel <= 0.7 and cos >= 0.8))
+        if not ok:
+            bad.append((name, rel, cos, rn))
+    assert not bad, bad[:8]

@@ -127,3 +127,49 @@ def test_itm_eval_bit_exact():
         assert set(res) == set(c['result'])
         for k, v in c['result'].items():
             assert float(res[k]) == v, (name, k, res[k], v)     # integer ranks -> exact percentages
+
+
+# ----------------------------------------------------------------------------------------- video model
+VIDEO_CFG = dict(TINY_CFG, vision_width=64, vision_layer=2)
+
+
+def _vbatch(z):
+    return dict(video=T(z['video']), video_mask=T(z['video_mask']), ids_s=T(z['ids_s']), mask_s=T(z['mask_s']),
+                ids_t=T(z['ids_t']), mask_t=T(z['mask_t']), ids_c=T(z['ids_c']), mask_c=T(z['mask_c']), idx=T(z['idx']))
+
+
+def test_video_interaction_and_features():
+    """Oracle vs the reference's video RetrievalModel (fixture video_tiny_w1.npz: ragged clips of 3..8 frames)."""
+    z = load_npz('video_tiny_w1.npz')
+    sd = weights(z)
+    b = _vbatch(z)
+    assert 3 <= int(b['video_mask'].sum(1).min()) < int(b['video_mask'].sum(1).max()) == 8
+    vid, vkpm = O.video_encode(sd, b['video'], b['video_mask'])
+    # padded frames are keys nobody attends to, but their own rows are still computed: compare every row
+    assert max_err(vid, z['vision_embeds']) < FWD_TOL
+    cap = O.bert_forward(sd, 'text_encoder.', b['ids_c'], b['mask_c'], heads=2)
+    a_vid, a_cap, o_cap = O.video_interaction_with_caption(sd, vid, cap, ~b['mask_c'].bool(), vkpm)
+    assert max_err(a_vid.transpose(0, 1), z['after_image']) < FWD_TOL
+    assert max_err(a_cap.transpose(0, 1), z['after_caption']) < FWD_TOL
+    assert max_err(o_cap.transpose(0, 1), z['ori_caption']) < FWD_TOL
+    assert max_err(O.video_get_features(sd, a_vid, b['video_mask']), z['feat_v']) < FWD_TOL
+
+
+def test_video_full_forward_backward_w1():
+    z = load_npz('video_tiny_w1.npz')
+    sd = weights(z, requires_grad=True)
+    b = _vbatch(z)
+    losses = O.video_retrieval_forward(sd, VIDEO_CFG, b['video'], b['video_mask'], b['ids_s'], b['mask_s'], b['ids_t'],
+                                       b['mask_t'], b['ids_c'], b['mask_c'], b['idx'], text_heads=2)
+    got = np.array([float(l) for l in losses])
+    assert np.max(np.abs(got - z['losses'])) < 1e-5, (got, z['losses'])
+    sum(losses).backward()
+    checked = 0
+    for k, v in z.items():
+        if k.startswith('g/'):
+            name = k[2:]
+            assert sd[name].grad is not None, name
+            assert grad_close(sd[name].grad, v, 5e-4), name
+            checked += 1
+    assert checked > 90
+    assert any(k.startswith('g/vid_encoder.layers.1.') for k in z) and not any(k.startswith('w/clip_encoder.') for k in z)
