@@ -134,3 +134,48 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
     score_matrix_t2i = score_matrix_i2t.t().contiguous()
     print('Evaluation time {}'.format(str(datetime.timedelta(seconds=int(time.time() - start_time)))))
     return score_matrix_i2t.cpu().numpy(), score_matrix_t2i.cpu().numpy()
+
+
+def _norm_score(s):
+    """video_Retrieval_caption_double_sim.py norm_score: (s - min) / max(s - min), over the whole matrix."""
+    s = s - s.min()
+    return s / s.max()
+
+
+@torch.no_grad()
+def evaluation_coarse_video(model, data_loader, tokenizer, device, config, alpha=0.9):
+    """video_Retrieval_caption_double_sim.py:94-190 ("double sim"): score = alpha * norm(video_feat . text_feat) +
+    (1 - alpha) * norm(max over the n caption queries of caption_feat . text_feat).  data_loader yields
+    (video [b,F,vw], video_mask [b,F] bool, generated captions, ids).  Both products are HIP GEMMs (f32); the reference's
+    closing all_reduce of the complete matrices only scales them by W (ranking-invariant) and is dropped."""
+    model.eval()
+    print('Computing features for evaluation...')
+    start_time = time.time()
+    texts = data_loader.dataset.text
+    text_bs = config['batch_size_test_text']
+    text_embeds = []
+    for i in range(0, len(texts), text_bs):
+        ti = tokenizer(texts[i: i + text_bs], padding='max_length', truncation=True, max_length=config['max_tokens'],
+                       return_tensors='pt').to(device)
+        text_embeds.append(model.get_features(text_embeds=model.get_text_embeds(ti.input_ids, ti.attention_mask)))
+    text_embeds = torch.cat(text_embeds, dim=0).float().contiguous()
+    image_embeds, caption_embeds = [], []
+    for video, mask_video, generated_captions, vid_id in data_loader:
+        video, mask_video = video.to(device), mask_video.to(device)
+        vis, kpm = model.get_vision_embeds(video, mask_video)
+        ci = tokenizer(generated_captions, padding='max_length', truncation=True, max_length=config['max_tokens'],
+                       return_tensors='pt').to(device)
+        cap = model.get_caption_embeds(ci.input_ids, ci.attention_mask)
+        a_vid, a_cap, _ = model.interaction_with_caption(image_embeds=vis, caption_embeds=cap,
+                                                         key_padding_mask=~ci.attention_mask.bool(), video_mask=kpm)
+        image_embeds.append(model.get_features(image_embeds=a_vid.transpose(0, 1).contiguous(),
+                                               vis_mask=mask_video.unsqueeze(-1)))
+        caption_embeds.append(model.caption_proj1(a_cap.transpose(0, 1).contiguous(), out_f32=True))      # [b, n, D]
+    image_embeds = torch.cat(image_embeds, dim=0).float().contiguous()
+    caption_embeds = torch.cat(caption_embeds, dim=0).float().contiguous()
+    nv, n, D = caption_embeds.shape
+    score = K.gemm(image_embeds, text_embeds)                                   # [Nv, Nt]
+    c_score = K.gemm(caption_embeds.view(nv * n, D), text_embeds).view(nv, n, -1).max(dim=1)[0]
+    i2t = alpha * _norm_score(score) + (1.0 - alpha) * _norm_score(c_score)
+    print('Evaluation time {}'.format(str(datetime.timedelta(seconds=int(time.time() - start_time)))))
+    return i2t.cpu().numpy(), i2t.t().contiguous().cpu().numpy()

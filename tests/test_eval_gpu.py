@@ -77,3 +77,40 @@ def test_evaluation_coarse_synthetic_loader():
     ref = (fv @ ft.t()).numpy()
     assert i2t.shape == (8, 8) and np.max(np.abs(i2t - ref)) < 1e-4 and np.array_equal(t2i, i2t.T)
     assert np.array_equal(np.argsort(-i2t, 1), np.argsort(-ref, 1))             # identical rankings
+
+
+def test_evaluation_coarse_video_double_sim():
+    """evaluation_coarse_video (video_Retrieval_caption_double_sim.py:94-190) == the same formula on the oracle's features."""
+    from leccr_amd.evaluation import evaluation_coarse_video
+    from oracle import leccr_oracle as O
+    from tests.helpers import load_npz, weights
+    from tests.test_model_gpu import TINY_BERT, build_video
+    z = load_npz('video_tiny_w1.npz')
+    sd = weights(z)
+    model = build_video(dict(text_config=TINY_BERT, compute_dtype='fp32'), sd)
+    ids_s, m_s = torch.from_numpy(z['ids_s']), torch.from_numpy(z['mask_s'])
+    ids_c, m_c = torch.from_numpy(z['ids_c']), torch.from_numpy(z['mask_c'])
+    video, vmask = torch.from_numpy(z['video']), torch.from_numpy(z['video_mask'])
+
+    class Tok:
+        def __call__(self, text, **kw):
+            ids, m = (ids_s, m_s) if text[0][0] == 't' else (ids_c, m_c)
+            sel = torch.tensor([int(t[1:]) for t in text])
+            o = types.SimpleNamespace(input_ids=ids[sel], attention_mask=m[sel])
+            o.to = lambda dev: types.SimpleNamespace(input_ids=o.input_ids.to(dev), attention_mask=o.attention_mask.to(dev))
+            return o
+
+    class Loader(list):
+        dataset = types.SimpleNamespace(text=[f't{i}' for i in range(8)])
+    loader = Loader([(video[a:b], vmask[a:b], [f'c{j}' for j in range(a, b)], None) for a, b in ((0, 3), (3, 8))])
+    i2t, t2i = evaluation_coarse_video(model, loader, Tok(), 'cuda', {'batch_size_test_text': 3, 'max_tokens': 200})
+    vid, vkpm = O.video_encode(sd, video, vmask)
+    cap = O.bert_forward(sd, 'text_encoder.', ids_c, m_c, 2)
+    a_vid, a_cap, _ = O.video_interaction_with_caption(sd, vid, cap, ~m_c.bool(), vkpm)
+    fv = O.video_get_features(sd, a_vid, vmask)
+    ft = O.get_features(sd, text_embeds=O.bert_forward(sd, 'text_encoder.', ids_s, m_s, 2))
+    cq = torch.nn.functional.linear(a_cap, sd['caption_proj1.weight'], sd['caption_proj1.bias'])       # [b, n, D]
+    norm = lambda s: (s - s.min()) / (s - s.min()).max()
+    ref = 0.9 * norm(fv @ ft.t()) + 0.1 * norm(torch.einsum('ind,jd->inj', cq, ft).max(1)[0])
+    assert i2t.shape == (8, 8) and np.max(np.abs(i2t - ref.numpy())) < 1e-4 and np.array_equal(t2i, i2t.T)
+    assert np.array_equal(np.argsort(-i2t, 1), np.argsort(-ref.numpy(), 1))

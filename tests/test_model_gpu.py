@@ -378,3 +378,21 @@ def test_video_production_kernels_vs_oracle(dtype):
         if not ok:
             bad.append((name, rel, cos, rn))
     assert not bad, bad[:8]
+
+
+def test_video_training_script_synthetic_epoch(tmp_path):
+    """video_Retrieval_caption_double_sim.main on synthetic VATEX-shaped batches (tiny geometry, ragged clips)."""
+    import video_Retrieval_caption_double_sim as task
+    import image_Retrieval_caption as image_task
+    cfg = dict(VIDEO_CFG)
+    cfg.update(text_config=TINY_BERT, compute_dtype='fp32', synthetic_frames=8, synthetic_L_t=9, synthetic_L_c=12,
+               synthetic_vocab=100, max_tokens=200, batch_size_train=16,
+               optimizer={'opt': 'adamW', 'lr': 1e-4, 'weight_decay': 0.01, 'lr_mult': 2},
+               schedular={'sched': 'linear', 'lr': 1e-4, 'epochs': 1, 'num_warmup_steps': 0.1})
+    args = image_task.build_parser().parse_args(['--synthetic', '--synthetic_steps', '3', '--bs', '16', '--epoch', '1',
+                                                 '--output_dir', str(tmp_path)])
+    model = task.main(args, cfg)
+    import json
+    log = [json.loads(l) for l in open(tmp_path / 'log.txt')]
+    assert log[0]['epoch'] == 0 and float(log[0]['train_loss_itc_vs']) > 0 and float(log[0]['train_loss_itc_c']) > 0
+    assert model.arena.step_count == 3 and any(n.startswith('vid_encoder.') for n, _ in model.named_parameters())
