@@ -124,7 +124,8 @@ int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    int dtype, float drop_p, uint64_t seed, void* stream);
 
 /* ---- ViT input stage --------------------------------------------------------------------------------------
- * patchify: image [b,3,R,R] f32 NCHW -> patches [b*g*g, Kp] (T), g = R/p, column order (c, py, px) = the
+ * patchify: image [b,3,R,R] f32 NCHW -> patches [b*g*g, Kp] (T), g = floor(R/p) (the R % p edge pixels are dropped, as
+ *   by the stride-p convolution: ViT-L/14 at 384), column order (c, py, px) = the
  *   flattening of conv1.weight [d,3,p,p]; columns 3p^2..Kp-1 are zero padding.  (clip/model.py:211,224-226)
  * vit_assemble: tok [b, N, d] = concat(class_embedding, patch_out[b, N-1, d]) + positional_embedding
  *   (clip/model.py:227-228); its backward scatters dtok into dpatch_out (T) and ACCUMULATES dcls [d], dpos [N,d] f32.

@@ -73,6 +73,7 @@ class ParamArena:
         self.lp = torch.zeros(self.numel, device=device, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
         self._transposed = []
         self._tt_table, self._tt_tiles = None, 0
+        self.post_refresh = []          # callables run after every refresh (derived copies outside the arena)
         self.touched = [False] * len(params)
         for i, (p, o) in enumerate(zip(params, self.offsets)):
             view = self.data[o:o + p.numel()].view(p.shape)
@@ -126,6 +127,8 @@ class ParamArena:
                 self._tt_table = torch.tensor(rows, dtype=torch.int64, device=self.data.device)
                 self._tt_tiles = tiles
             K.transpose_cast_batched(self._tt_table, self._tt_tiles)       # one launch for all [in,out] copies
+        for fn in self.post_refresh:
+            fn()
 
     # ------------------------------------------------------------------ gradients
     def zero_grad(self):

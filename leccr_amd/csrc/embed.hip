@@ -120,7 +120,7 @@ using namespace leccr;
 extern "C" int leccr_patchify(const float* image, void* patches, int64_t b, int64_t R, int64_t p, int64_t Kp,
                               int dtype, void* stream) {
     LECCR_REQUIRE(image && patches, LECCR_EINVAL, "patchify: null pointer");
-    LECCR_REQUIRE(p > 0 && R % p == 0 && Kp >= 3 * p * p && (Kp & 3) == 0, LECCR_EINVAL, "patchify: bad geometry");
+    LECCR_REQUIRE(p > 0 && R >= p && Kp >= 3 * p * p && (Kp & 3) == 0, LECCR_EINVAL, "patchify: bad geometry");    // R % p pixels at the right / bottom edge are not covered, as with the stride-p convolution
     if (b == 0) return LECCR_OK;
     const int g = (int)(R / p);
     hipStream_t st = as_stream(stream);

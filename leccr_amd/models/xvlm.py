@@ -141,8 +141,13 @@ class XVLMBase(nn.Module):
             vis = self.clip_encoder.visual
             cw = vis.conv1.weight
             cw._lp2d, cw._g2d = cw._lp.view(cw.shape[0], -1), cw._g.view(cw.shape[0], -1)
-            assert cw._lp2d.shape[1] % 64 == 0 or self.compute_dtype == torch.float32, \
-                'patch size whose 3*p*p is not a multiple of 64 needs K padding (ViT-L/14): not wired yet'
+            k0 = cw._lp2d.shape[1]
+            if k0 % 64 and self.compute_dtype == torch.bfloat16:
+                # ViT-L/14: 3*14*14 = 588 patch columns.  The MFMA GEMMs want K (forward) / N (weight gradient) in
+                # multiples of 64 / 8: a zero-padded [d, 640] bf16 copy of the weight, refreshed with the other compute copies
+                kp = (k0 + 63) // 64 * 64
+                cw._lp_pad = torch.zeros(cw.shape[0], kp, device=dev, dtype=torch.bfloat16)
+                a.post_refresh.append(lambda cw=cw, k0=k0: cw._lp_pad[:, :k0].copy_(cw._lp2d))
             vis_proj = vis.proj
             a.need_transposed(vis_proj)
         for name, p in self.named_parameters():

@@ -176,9 +176,12 @@ class PatchEmbedFn(torch.autograd.Function):
     def forward(ctx, image, conv_w, cls, pos, dtype):
         b, _, R, _ = image.shape
         d, _, p, _ = conv_w.shape
-        Kp = conv_w._lp2d.shape[1]
+        w2d = getattr(conv_w, '_lp_pad', None)          # zero-padded copy when 3*p*p is not a multiple of 64 (ViT-L/14)
+        if w2d is None:
+            w2d = conv_w._lp2d
+        Kp = w2d.shape[1]
         patches = K.patchify(image.contiguous(), p, Kp, dtype)
-        po = K.gemm(patches, conv_w._lp2d)
+        po = K.gemm(patches, w2d)
         tok = K.vit_assemble_fwd(po, cls.data, pos.data, b)
         ctx.save_for_backward(patches)
         ctx.p = (conv_w, cls, pos)
@@ -191,7 +194,12 @@ class PatchEmbedFn(torch.autograd.Function):
         dpo = K.vit_assemble_bwd(dtok.contiguous(), cls._g, pos._g)
         _mark(cls)
         _mark(pos)
-        K.gemm(dpo, patches, trans_a=True, trans_b=True, out=conv_w._g2d, accumulate=True)
+        if patches.shape[1] == conv_w._g2d.shape[1]:
+            K.gemm(dpo, patches, trans_a=True, trans_b=True, out=conv_w._g2d, accumulate=True)
+        else:                                       # padded patch rows: the padding columns' gradient is dropped
+            gpad = torch.zeros(conv_w._g2d.shape[0], patches.shape[1], device=dpo.device, dtype=torch.float32)
+            K.gemm(dpo, patches, trans_a=True, trans_b=True, out=gpad, accumulate=True)
+            conv_w._g2d.add_(gpad[:, :conv_w._g2d.shape[1]])
         _mark(conv_w)
         return None, None, None, None, None
 

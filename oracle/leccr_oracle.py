@@ -81,6 +81,7 @@ def vit_trunk(sd, pre, image):
     b = image.shape[0]
     g = image.shape[-1] // p
     # stride == kernel: the conv is a GEMM over non-overlapping patches
+    image = image[..., :g * p, :g * p]          # conv1 has stride p and no padding: R % p edge pixels are never read
     patches = image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
     x = patches @ w.reshape(d, -1).t()
     cls = sd[pre + 'class_embedding'].reshape(1, 1, d).expand(b, 1, d)

@@ -396,3 +396,37 @@ def test_video_training_script_synthetic_epoch(tmp_path):
     log = [json.loads(l) for l in open(tmp_path / 'log.txt')]
     assert log[0]['epoch'] == 0 and float(log[0]['train_loss_itc_vs']) > 0 and float(log[0]['train_loss_itc_c']) > 0
     assert model.arena.step_count == 3 and any(n.startswith('vid_encoder.') for n, _ in model.named_parameters())
+
+
+# ----------------------------------------------------------------------------------------- ViT-L/14-style patch rows
+L14_VIT = dict(MID_VIT, image_resolution=60, vision_patch_size=14)        # 3*14*14 = 588 columns; 60 % 14 = 4 edge pixels dropped
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_patch14_rows_are_k_padded_for_the_mfma_path(dtype):
+    """Patch size 14 (ViT-L/14): 588-wide patch rows.  bf16 runs the MFMA GEMMs on a zero-padded 640-wide copy of conv1 and
+    drops the padding columns of its gradient; the image edge the stride-14 convolution never sees is ignored."""
+    model = build(dict(clip_geometry=L14_VIT, text_config=MID_BERT, compute_dtype=dtype, embed_dim=256,
+                       clip_text_tower=False), seed=9)
+    with torch.no_grad():
+        model.queries.normal_(0, 0.5)
+    batch = _mid_batch(res=60)
+    ref_losses, sd = _oracle_step(model, batch, text_heads=2)
+    losses = model(batch['image'].to(DEV), [Enc(batch['ids_s'].to(DEV), batch['mask_s'].to(DEV)),
+                                            Enc(batch['ids_t'].to(DEV), batch['mask_t'].to(DEV))],
+                   captions=Enc(batch['ids_c'].to(DEV), batch['mask_c'].to(DEV)), idx=batch['idx'].to(DEV))
+    cw = model.clip_encoder.visual.conv1.weight
+    assert cw.shape[1:] == (3, 14, 14) and (hasattr(cw, '_lp_pad') == (dtype == 'bf16'))
+    if dtype == 'bf16':
+        assert cw._lp_pad.shape == (cw.shape[0], 640) and float(cw._lp_pad[:, 588:].abs().max()) == 0
+    tol = 1e-3 if dtype == 'fp32' else 5e-3
+    for a, r in zip(losses, ref_losses):
+        assert abs(float(a) - r) <= tol * max(1.0, abs(r)), (dtype, [float(x) for x in losses], ref_losses)
+    model.arena.zero_grad()
+    sum(losses).backward()
+    for name in ('clip_encoder.visual.conv1.weight', 'clip_encoder.visual.positional_embedding',
+                 'clip_encoder.visual.transformer.resblocks.0.attn.in_proj_weight'):
+        g = dict(model.named_parameters())[name].grad.detach().cpu().double()
+        r = sd[name].grad.double()
+        rel = float((g - r).norm() / r.norm())
+        assert rel <= (1e-3 if dtype == 'fp32' else 0.15), (name, rel)
