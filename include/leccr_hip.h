@@ -178,7 +178,7 @@ int leccr_sim_infonce_fwd(const float* a, const float* b, const int64_t* idx, fl
                           int both_dirs, float* loss, float* ws, void* stream);
 int leccr_sim_infonce_bwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
                           int both_dirs, const float* ws, float gscale, float* da, float* db, float* dtemp,
-                          void* stream);
+                          int64_t row0, int64_t nrows, void* stream);
 int leccr_capsim_fwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D, float* loss,
                      int32_t* argmax, float* ws, void* stream);
 int leccr_capsim_bwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D,
@@ -187,7 +187,11 @@ int leccr_capsim_bwd(const float* c, const float* t, float temp, int64_t b, int6
 int leccr_dstl_fwd(const float* v, const float* c, const float* s, const float* t, float alpha, int64_t G,
                    int64_t n, int64_t D, float* loss, float* ws, void* stream);
 int leccr_dstl_bwd(const float* v, const float* t, int64_t G, int64_t D, const float* ws, float gscale, float* dv,
-                   float* dt, void* stream);
+                   float* dt, int64_t row0, int64_t nrows, void* stream);
+/* sim_infonce_bwd / dstl_bwd write the gradient rows [row0, row0 + nrows) only (and sim_infonce_bwd adds only those rows'
+ * share to dtemp): under data parallelism the gathered operands' gradient is kept for the rank's own rows alone
+ * (AllGather backward, models/xvlm.py:62-67), so a rank passes its shard and skips (W-1)/W of the backward work.
+ * (0, G) = everything. */
 int leccr_cvpool_fwd(const void* x, float* pooled, float* inv_norm, int64_t b, int64_t L, int64_t d, int dtype,
                      void* stream);
 int leccr_cvpool_bwd(const void* x, const float* inv_norm, const float* dpooled, void* dx, int64_t b, int64_t L,

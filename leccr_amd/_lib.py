@@ -46,11 +46,11 @@ _SIGS = {
     'leccr_l2norm_fwd': ([vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),
     'leccr_l2norm_bwd': ([vp, vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),
     'leccr_sim_infonce_fwd': ([vp, vp, vp, f32, i64, i64, C.c_int, vp, vp, vp], C.c_int),
-    'leccr_sim_infonce_bwd': ([vp, vp, vp, f32, i64, i64, C.c_int, vp, f32, vp, vp, vp, vp], C.c_int),
+    'leccr_sim_infonce_bwd': ([vp, vp, vp, f32, i64, i64, C.c_int, vp, f32, vp, vp, vp, i64, i64, vp], C.c_int),
     'leccr_capsim_fwd': ([vp, vp, f32, i64, i64, i64, vp, vp, vp, vp], C.c_int),
     'leccr_capsim_bwd': ([vp, vp, f32, i64, i64, i64, vp, vp, f32, vp, vp, vp, vp], C.c_int),
     'leccr_dstl_fwd': ([vp, vp, vp, vp, f32, i64, i64, i64, vp, vp, vp], C.c_int),
-    'leccr_dstl_bwd': ([vp, vp, i64, i64, vp, f32, vp, vp, vp], C.c_int),
+    'leccr_dstl_bwd': ([vp, vp, i64, i64, vp, f32, vp, vp, i64, i64, vp], C.c_int),
     'leccr_cvpool_fwd': ([vp, vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_cvpool_bwd': ([vp, vp, vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_capreg_fwd': ([vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),

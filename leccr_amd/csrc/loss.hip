@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
                                                       const int64_t* __restrict__ idx, float inv_temp, int G, int D,
                                                       const float* __restrict__ ws, float w_r, float w_c,
                                                       float* __restrict__ da, float* __restrict__ db,
-                                                      float* __restrict__ dtemp) {
+                                                      float* __restrict__ dtemp, int row0, int row_end) {
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int side = blockIdx.y;
-    const int i_raw = blockIdx.x * 4 + wave;
-    const int i = i_raw < G ? i_raw : G - 1;          // no early exit: the block synchronises on the staged tiles
+    const int i_raw = row0 + blockIdx.x * 4 + wave;   // only rows [row0, row_end) get their gradient (the caller's shard)
+    const int i = i_raw < row_end ? i_raw : row_end - 1;          // no early exit: the block synchronises on the staged tiles
     const float* A = side == 0 ? a : b;
     const float* B = side == 0 ? b : a;
     float* out = side == 0 ? da : db;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
             }
         }
     }
-    if (i_raw >= G) return;
+    if (i_raw >= row_end) return;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int d = lane + 64 * q;
@@ -403,11 +403,12 @@ __global__ __launch_bounds__(256) void dstl_kl_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void dstl_bwd_kernel(const float* __restrict__ v, const float* __restrict__ t, int G,
                                                        int D, const float* __restrict__ tv,
                                                        const float* __restrict__ lab, const float* __restrict__ lse_tv,
-                                                       float w, float* __restrict__ dv, float* __restrict__ dt) {
+                                                       float w, float* __restrict__ dv, float* __restrict__ dt,
+                                                       int row0, int row_end) {
     const int lane = threadIdx.x & 63;
     const int side = blockIdx.y;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= G) return;
+    const int r = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);      // only the caller's shard of rows
+    if (r >= row_end) return;
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int o = 0; o < G; ++o) {
         const int i = side == 0 ? r : o, j = side == 0 ? o : r;
@@ -533,14 +534,15 @@ extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64
 
 extern "C" int leccr_sim_infonce_bwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
                                      int both_dirs, const float* ws, float gscale, float* da, float* db, float* dtemp,
-                                     void* stream) {
+                                     int64_t row0, int64_t nrows, void* stream) {
     LECCR_REQUIRE(a && b && ws && da && db && G > 0 && D > 0 && D <= 512 && (D & 3) == 0, LECCR_EINVAL, "sim_infonce_bwd: bad argument (D <= 512)");
+    LECCR_REQUIRE(row0 >= 0 && nrows > 0 && row0 + nrows <= G, LECCR_EINVAL, "sim_infonce_bwd: row range outside [0, G)");
     hipStream_t st = as_stream(stream);
     const float w_r = gscale * (both_dirs ? 0.5f / G : 1.f / G), w_c = both_dirs ? w_r : 0.f;
     const size_t lds_b = (size_t)(4 * (D + 64) + 64 * (D + 4)) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)sim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(G, 4), 2), dim3(256), lds_b, st, a, b, idx,
-                       1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp);
+    hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(nrows, 4), 2), dim3(256), lds_b, st, a, b, idx,
+                       1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp, (int)row0, (int)(row0 + nrows));
     return check_launch("sim_infonce_bwd");
 }
 
@@ -594,14 +596,15 @@ extern "C" int leccr_dstl_fwd(const float* v, const float* c, const float* s, co
 }
 
 extern "C" int leccr_dstl_bwd(const float* v, const float* t, int64_t G, int64_t D, const float* ws, float gscale, float* dv,
-                              float* dt, void* stream) {
+                              float* dt, int64_t row0, int64_t nrows, void* stream) {
     LECCR_REQUIRE(v && t && ws && dv && dt && G > 0 && D > 0 && D <= 512, LECCR_EINVAL, "dstl_bwd: bad argument");
+    LECCR_REQUIRE(row0 >= 0 && nrows > 0 && row0 + nrows <= G, LECCR_EINVAL, "dstl_bwd: row range outside [0, G)");
     hipStream_t st = as_stream(stream);
     const float* tv = ws;
     const float* lab = ws + G * G;
     const float* lse_tv = ws + 3 * G * G + 4;
-    hipLaunchKernelGGL(dstl_bwd_kernel, dim3((unsigned)cdiv(G, 4), 2), dim3(256), 0, st, v, t, (int)G, (int)D, tv, lab, lse_tv,
-                       gscale / G, dv, dt);
+    hipLaunchKernelGGL(dstl_bwd_kernel, dim3((unsigned)cdiv(nrows, 4), 2), dim3(256), 0, st, v, t, (int)G, (int)D, tv, lab, lse_tv,
+                       gscale / G, dv, dt, (int)row0, (int)(row0 + nrows));
     return check_launch("dstl_bwd");
 }
 

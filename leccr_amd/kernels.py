@@ -212,11 +212,14 @@ def sim_infonce_fwd(a, b, idx, temp, both_dirs=True):
     return loss, ws
 
 
-def sim_infonce_bwd(a, b, idx, temp, ws, gscale, both_dirs=True, dtemp=None):
+def sim_infonce_bwd(a, b, idx, temp, ws, gscale, both_dirs=True, dtemp=None, rows=None):
+    """rows = (row0, nrows): only those rows of da / db are computed (the rest is zero) and dtemp gets their share only."""
     G, D = a.shape
-    da, db = torch.empty_like(a), torch.empty_like(b)
+    r0, nr = rows if rows is not None else (0, G)
+    da, db = (torch.empty_like(a), torch.empty_like(b)) if nr == G else (torch.zeros_like(a), torch.zeros_like(b))
     check(lib().leccr_sim_infonce_bwd(ptr(a), ptr(b), ptr(idx), float(temp), G, D, int(both_dirs), ptr(ws),
-                                      float(gscale), ptr(da), ptr(db), ptr(dtemp), stream()), 'leccr_sim_infonce_bwd')
+                                      float(gscale), ptr(da), ptr(db), ptr(dtemp), int(r0), int(nr), stream()),
+          'leccr_sim_infonce_bwd')
     return da, db
 
 
@@ -250,10 +253,11 @@ def dstl_fwd(v, c, s, t, alpha):
     return loss, ws
 
 
-def dstl_bwd(v, t, ws, gscale):
+def dstl_bwd(v, t, ws, gscale, rows=None):
     G, D = v.shape
-    dv, dt = torch.empty_like(v), torch.empty_like(t)
-    check(lib().leccr_dstl_bwd(ptr(v), ptr(t), G, D, ptr(ws), float(gscale), ptr(dv), ptr(dt), stream()),
+    r0, nr = rows if rows is not None else (0, G)
+    dv, dt = (torch.empty_like(v), torch.empty_like(t)) if nr == G else (torch.zeros_like(v), torch.zeros_like(t))
+    check(lib().leccr_dstl_bwd(ptr(v), ptr(t), G, D, ptr(ws), float(gscale), ptr(dv), ptr(dt), int(r0), int(nr), stream()),
           'leccr_dstl_bwd')
     return dv, dt
 

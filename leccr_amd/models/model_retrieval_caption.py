@@ -5,7 +5,7 @@ import torch.nn as nn
 from .. import ops
 from .attention import CrossAttention
 from .layers import Linear
-from .xvlm import XVLMBase, _dist_info, gather_rows
+from .xvlm import XVLMBase, _dist_info, gather_rows, local_rows
 
 
 class RetrievalModel(XVLMBase):
@@ -69,7 +69,7 @@ class RetrievalModel(XVLMBase):
         pc = ops.CvPoolFn.apply(self.cproj(ori_caption, wgrad_scale=float(world)))
         pv = ops.CvPoolFn.apply(self.vproj(ori_image, wgrad_scale=float(world)))
         idx_all = gather_rows(idx.view(-1, 1)).view(-1).contiguous()
-        return ops.SimInfoNCEFn.apply(gather_rows(pc), gather_rows(pv), None, idx_all, False, 1.0)
+        return ops.SimInfoNCEFn.apply(gather_rows(pc), gather_rows(pv), None, idx_all, False, 1.0, local_rows(pc.size(0)))
 
     # ------------------------------------------------------------------ reference API (LND at the boundary)
     def caption_regularization(self, caption_embeds):
@@ -87,7 +87,7 @@ class RetrievalModel(XVLMBase):
         v = gather_rows(image_embeds.float())
         c = gather_rows(caption_embeds.transpose(0, 1).float().contiguous())
         s, t = gather_rows(text_embeds_s.float()), gather_rows(text_embeds_t.float())
-        return ops.DstlFn.apply(v, c, s, t, alpha)
+        return ops.DstlFn.apply(v, c, s, t, alpha, local_rows(image_embeds.size(0)))
 
     def caption_vision_loss(self, caption, image, idx):
         """model_retrieval_caption.py:118-143; caption [n, b, vw] (LND), image [b, N, vw]."""
@@ -137,7 +137,7 @@ class RetrievalModel(XVLMBase):
             ops.CapSimFn.apply(cq, text_feat_t, self.temp, tval)
 
         loss_dstl = ops.DstlFn.apply(gather_rows(image_feat), gather_rows(cq.contiguous()), gather_rows(text_feat_s),
-                                     gather_rows(text_feat_t), 0.8) * self.weight_dstl_loss
+                                     gather_rows(text_feat_t), 0.8, local_rows(image_feat.size(0))) * self.weight_dstl_loss
         loss_itc_vt = loss_itc_vt * (1 - self.weight_dstl_loss) + loss_dstl
         return (loss_itc_vs + loss_cv, loss_itc_vt, loss_itc_st, loss_itc_c * self.weight_caption_loss,
                 loss_reg_c * self.weight_reg_loss)

@@ -10,7 +10,7 @@ import torch
 from .. import ops
 from .attention import SelfAttention
 from .model_retrieval_caption import RetrievalModel as _ImageRetrievalModel
-from .xvlm import _dist_info, gather_rows
+from .xvlm import _dist_info, gather_rows, local_rows
 
 
 class RetrievalModel(_ImageRetrievalModel):
@@ -98,7 +98,7 @@ class RetrievalModel(_ImageRetrievalModel):
         loss_itc_c = ops.CapSimFn.apply(cq, text_feat_s, self.temp, tval) + \
             ops.CapSimFn.apply(cq, text_feat_t, self.temp, tval)
         loss_dstl = ops.DstlFn.apply(gather_rows(image_feat), gather_rows(cq.contiguous()), gather_rows(text_feat_s),
-                                     gather_rows(text_feat_t), 0.8) * self.weight_dstl_loss
+                                     gather_rows(text_feat_t), 0.8, local_rows(image_feat.size(0))) * self.weight_dstl_loss
         loss_itc_vt = loss_itc_vt * (1 - self.weight_dstl_loss) + loss_dstl
         return (loss_itc_vs + loss_cv, loss_itc_vt, loss_itc_st, loss_itc_c * self.weight_caption_loss,
                 loss_reg_c * self.weight_reg_loss)

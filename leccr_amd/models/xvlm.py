@@ -52,6 +52,12 @@ def gather_rows(t):
     return t if world == 1 else allgather(t, rank, world)
 
 
+def local_rows(b):
+    """(row0, nrows) of this rank's b rows inside an all-gathered [W*b, ...] tensor, or None on a single rank."""
+    rank, world = _dist_info()
+    return None if world == 1 else (rank * b, b)
+
+
 def build_mlp(input_dim, output_dim):
     """xvlm.py:74-80 (itm_head: allocated by the reference, never used on the LECCR path)."""
     return nn.Sequential(nn.Linear(input_dim, input_dim * 2), nn.LayerNorm(input_dim * 2), nn.GELU(),
@@ -206,4 +212,4 @@ class XVLMBase(nn.Module):
             idx = idx.view(-1, 1)
             assert idx.size(0) == image_feat.size(0)
             idx_all = gather_rows(idx).view(-1).contiguous()
-        return ops.SimInfoNCEFn.apply(a, b, self.temp, idx_all, True, tval)
+        return ops.SimInfoNCEFn.apply(a, b, self.temp, idx_all, True, tval, local_rows(image_feat.size(0)))

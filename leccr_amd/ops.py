@@ -462,22 +462,28 @@ class SimInfoNCEFn(torch.autograd.Function):
     """get_contrastive_loss's compute (models/xvlm.py:273-292) on already gathered f32 features."""
 
     @staticmethod
-    def forward(ctx, a, b, temp, idx, both_dirs, tval=None):
+    def forward(ctx, a, b, temp, idx, both_dirs, tval=None, local_rows=None):
+        """local_rows = (row0, nrows): a and b are all-gathered and only those rows are this rank's (AllGather keeps the
+        local slice of the gradient, xvlm.py:62-67): the backward computes just them - 1/W of its work."""
         a, b = a.contiguous(), b.contiguous()
         if tval is None:
             tval = float(temp) if temp is not None else 1.0
         loss, ws = K.sim_infonce_fwd(a, b, idx, tval, both_dirs)
         ctx.save_for_backward(a, b, ws)
-        ctx.meta = (tval, idx, both_dirs, temp is not None)
+        ctx.meta = (tval, idx, both_dirs, temp is not None, local_rows)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         a, b, ws = ctx.saved_tensors
-        tval, idx, both_dirs, has_temp = ctx.meta
+        tval, idx, both_dirs, has_temp, rows = ctx.meta
         dtemp = torch.zeros(1, device=a.device, dtype=torch.float32) if has_temp else None
-        da, db = K.sim_infonce_bwd(a, b, idx, tval, ws, float(g), both_dirs, dtemp)
-        return da, db, (dtemp[0] if has_temp else None), None, None, None
+        da, db = K.sim_infonce_bwd(a, b, idx, tval, ws, float(g), both_dirs, dtemp, rows)
+        if has_temp and rows is not None and rows[1] != a.shape[0]:
+            # temp sits after the gather: every rank must hold the FULL dL/dtemp (DDP then averages identical values).
+            # The row shards' shares add up to it over the ranks, so W x share survives the mean.
+            dtemp = dtemp * (a.shape[0] / rows[1])
+        return da, db, (dtemp[0] if has_temp else None), None, None, None, None
 
 
 class CapSimFn(torch.autograd.Function):
@@ -504,17 +510,18 @@ class DstlFn(torch.autograd.Function):
     """dstl_loss's compute (model_retrieval_caption.py:100-116) on gathered f32 features; grads to v and t only."""
 
     @staticmethod
-    def forward(ctx, v, c, s, t, alpha):
+    def forward(ctx, v, c, s, t, alpha, local_rows=None):
         v, c, s, t = v.contiguous(), c.contiguous(), s.contiguous(), t.contiguous()
         loss, ws = K.dstl_fwd(v, c, s, t, alpha)
         ctx.save_for_backward(v, t, ws)
+        ctx.rows = local_rows
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         v, t, ws = ctx.saved_tensors
-        dv, dt = K.dstl_bwd(v, t, ws, float(g))
-        return dv, None, None, dt, None
+        dv, dt = K.dstl_bwd(v, t, ws, float(g), ctx.rows)
+        return dv, None, None, dt, None, None
 
 
 class CvPoolFn(torch.autograd.Function):

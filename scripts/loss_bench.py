@@ -24,8 +24,9 @@ for W in (1, 2, 4, 8):
     tl = nrm(torch.randn(256, D, device=dev)).requires_grad_(True)
     pc = torch.randn(G, vw, device=dev, requires_grad=True)
     pv = torch.randn(G, vw, device=dev, requires_grad=True)
-    def itc(): ops.SimInfoNCEFn.apply(a, b, temp, idx, True, 0.07).backward()
-    def cv(): ops.SimInfoNCEFn.apply(pc, pv, None, idx, False, 1.0).backward()
+    lr = None if W == 1 else (0, 256)          # this rank's rows of the gathered batch
+    def itc(): ops.SimInfoNCEFn.apply(a, b, temp, idx, True, 0.07, lr).backward()
+    def cv(): ops.SimInfoNCEFn.apply(pc, pv, None, idx, False, 1.0, lr).backward()
     def cap(): ops.CapSimFn.apply(cq_loc, tl, temp, 0.07).backward()
-    def dstl(): ops.DstlFn.apply(a, cq, a, b, 0.4).backward()
+    def dstl(): ops.DstlFn.apply(a, cq, a, b, 0.4, lr).backward()
     print(f'W={W} G={G}: itc {t(itc):7.3f} ms (x3/step) | cv {t(cv):7.3f} | capsim(local) {t(cap):7.3f} (x2) | dstl {t(dstl):7.3f}', flush=True)

@@ -311,6 +311,18 @@ def test_sim_infonce(K, G, D, use_idx, both):
     for name, got, r in (('da', da, ad.grad), ('db', db, bd.grad), ('dtemp', dtemp[0], td.grad)):
         e, s = _err(got, r)
         assert e <= 1e-4 * s + 1e-7, (name, e, s)
+    # row shards (data parallelism keeps the rank's own rows of the gathered gradient): each shard reproduces its rows of
+    # the full result and leaves the others zero; the dtemp shares add up to the full dtemp
+    if G >= 8:
+        cuts = [0, G // 3, G // 3 + 1, G]
+        dt_sum = 0.0
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            dts = torch.zeros(1, device=DEV)
+            das, dbs = K.sim_infonce_bwd(a.to(DEV), b.to(DEV), ia, temp, ws, 1.7, both, dts, rows=(r0, r1 - r0))
+            assert torch.equal(das[r0:r1], da[r0:r1]) and torch.equal(dbs[r0:r1], db[r0:r1])
+            assert float(das[:r0].abs().sum() + das[r1:].abs().sum() + dbs[:r0].abs().sum() + dbs[r1:].abs().sum()) == 0
+            dt_sum += float(dts)
+        assert abs(dt_sum - float(dtemp)) <= 1e-4 * abs(float(dtemp)) + 1e-6
 
 
 @pytest.mark.parametrize('b,n,D', [(6, 4, 16), (70, 4, 256), (256, 2, 256)])
@@ -347,6 +359,10 @@ def test_dstl(K, G, n, D):
     for name, got, r in (('dv', dv, vd.grad), ('dt', dt, tdd.grad)):
         e, sc = _err(got, r)
         assert e <= 2e-4 * sc + 1e-8, (name, e, sc)
+    r0, nr = G // 4, G // 2
+    dvs, dts = K.dstl_bwd(v.to(DEV), t.to(DEV), ws, 0.3, rows=(r0, nr))
+    assert torch.equal(dvs[r0:r0 + nr], dv[r0:r0 + nr]) and torch.equal(dts[r0:r0 + nr], dt[r0:r0 + nr])
+    assert float(dvs[:r0].abs().sum() + dvs[r0 + nr:].abs().sum() + dts[:r0].abs().sum() + dts[r0 + nr:].abs().sum()) == 0
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
