@@ -106,8 +106,13 @@ def main():
     from leccr_amd.scheduler import create_scheduler
     from leccr_amd.synthetic import make_batch
     import ctypes as C
-    rank, world, local = init_distributed_mode('nccl')
+    # RCCL ('nccl') over xGMI, one rank per GPU.  LECCR_BENCH_BACKEND=gloo is a rehearsal aid only: it lets two ranks share
+    # the single GPU of a development box to exercise this N > 1 control flow (not a measurement configuration).
+    backend = os.environ.get('LECCR_BENCH_BACKEND', 'nccl')
+    rank, world, local = init_distributed_mode(backend)
     assert world == args.gpus or world == 1, (world, args.gpus)
+    if backend != 'nccl':
+        local = local % max(1, torch.cuda.device_count())
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     model, cfg = build_model(args, device)

@@ -18,7 +18,7 @@ def init_distributed_mode(backend=None):
         return 0, 1, 0
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ.get('LOCAL_RANK', 0))
     if torch.cuda.is_available():
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local % torch.cuda.device_count())     # (ranks outnumber GPUs only in gloo rehearsals)
     if not dist.is_initialized():
         dist.init_process_group(backend=backend or ('nccl' if torch.cuda.is_available() else 'gloo'),
                                 init_method='env://', world_size=world, rank=rank)
