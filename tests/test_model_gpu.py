@@ -460,3 +460,47 @@ def test_short_training_run_bf16_tracks_fp32():
     assert np.all(np.isfinite(f)) and np.all(np.isfinite(h))
     assert f[-1] < 0.8 * f[0], f                                # the step actually trains
     assert np.max(np.abs(h - f) / np.abs(f)) < 0.05, (f, h)     # bf16 stays within 5 % of the fp32 trajectory
+
+
+def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """Save {model, optimizer, lr_scheduler} after 2 steps (the reference's checkpoint dict, image_Retrieval_caption.py:
+    478-499), load into a fresh model / optimizer / scheduler, take step 3: same parameters as 3 uninterrupted steps."""
+    from leccr_amd.optim import create_optimizer
+    from leccr_amd.scheduler import create_scheduler
+    z = load_npz('model_tiny_w1.npz')
+    sched_cfg = dict(sched='linear', lr=1e-3, epochs=1, step_per_epoch=10, num_warmup_steps=0.2)
+
+    def fresh():
+        m = build(dict(clip_geometry=MODEL_VIT, text_config=TINY_BERT, compute_dtype='fp32'), weights(z))
+        o = create_optimizer(dict(lr=1e-3, weight_decay=0.01, lr_mult=2), m)
+        return m, o, create_scheduler(dict(sched_cfg), o)
+
+    def step(m, o, s):
+        losses = run(m, z)
+        o.zero_grad()
+        sum(losses).backward()
+        o.step()
+        s.step()
+
+    ma, oa, sa = fresh()
+    for _ in range(3):
+        step(ma, oa, sa)
+    mb, ob, sb = fresh()
+    for _ in range(2):
+        step(mb, ob, sb)
+    path = tmp_path / 'ck.pth'
+    torch.save({'model': mb.state_dict(), 'optimizer': ob.state_dict(), 'lr_scheduler': sb.state_dict(), 'epoch': 0}, path)
+    mc, oc, sc = fresh()
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    mc.load_state_dict(ck['model'], strict=False)
+    oc.load_state_dict(ck['optimizer'])
+    sc.load_state_dict(ck['lr_scheduler'])
+    assert oc.arena.step_count == 2 and abs(oc.param_groups[0]['lr'] - ob.param_groups[0]['lr']) < 1e-12
+    step(mc, oc, sc)
+    moved = 0
+    for (n, pa), (_, pc) in zip(ma.named_parameters(), mc.named_parameters()):
+        # Adam normalises the update: f32 summation-order noise in a near-zero gradient moves an element by a small
+        # fraction of lr (1e-3); everything beyond that would be a state that did not survive the round trip
+        assert max_err(pc, pa.detach().cpu().numpy()) <= 2e-5, n
+        moved += int(not torch.equal(pa.detach().cpu(), torch.from_numpy(np.asarray(z['w/' + n]))) if ('w/' + n) in z else 0)
+    assert moved > 100
