@@ -431,39 +431,71 @@ __global__ __launch_bounds__(256) void dstl_bwd_kernel(const float* __restrict__
 
 // ----------------------------------------------------------------------------------------------- cvpool / capreg
 // x [b, L, d]: per (b, column): S = sum_l x, nrm = max(sqrt(sum_l x^2), 1e-12); pooled = S / (L nrm)
+// F.normalize(dim = 1) over the TOKEN axis followed by the mean over tokens, per (sample, column):
+// pooled[b,c] = (sum_l x[b,l,c]) / max(||x[b,:,c]||, eps) / L.   Block = one sample x 256 columns; a thread owns 4
+// consecutive columns (one 8/16-byte access) and every 4th token, the 4 token slices meet in LDS.  (One thread per column
+// walking all L tokens serially ran at a quarter of the HBM rate.)
 template <typename T>
 __global__ __launch_bounds__(256) void cvpool_fwd_kernel(const T* __restrict__ x, float* __restrict__ pooled,
                                                          float* __restrict__ inv_norm, int L, int d) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[2][4][256];
+    const int cg = threadIdx.x & 63, ls = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + cg * 4;
     const int64_t bi = blockIdx.y;
-    if (col >= d) return;
-    const T* p = x + bi * L * (int64_t)d + col;
-    float S = 0.f, Q = 0.f;
-    for (int l = 0; l < L; ++l) {
-        const float v = to_f32(p[(int64_t)l * d]);
-        S += v;
-        Q = fmaf(v, v, Q);
+    f32x4 S = {0.f, 0.f, 0.f, 0.f}, Q = S;
+    if (col < d) {
+        const T* p = x + bi * L * (int64_t)d + col;
+        for (int l = ls; l < L; l += 4) {
+            const f32x4 v = load4(p + (int64_t)l * d);
+            S += v;
+            Q += v * v;
+        }
     }
-    const float inv = 1.f / fmaxf(sqrtf(Q), 1e-12f);
-    inv_norm[bi * d + col] = inv;
-    pooled[bi * d + col] = S * inv / L;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][ls][cg * 4 + j] = S[j];
+        red[1][ls][cg * 4 + j] = Q[j];
+    }
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < d) {
+        const int t = threadIdx.x;
+        const float s = red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t];
+        const float q = red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t];
+        const float inv = 1.f / fmaxf(sqrtf(q), 1e-12f);
+        inv_norm[bi * d + c] = inv;
+        pooled[bi * d + c] = s * inv / L;
+    }
 }
 
-// dx_l = dpooled/L * (inv - S x_l inv^3)      (the clamp branch has zero measure on the path)
 template <typename T>
 __global__ __launch_bounds__(256) void cvpool_bwd_kernel(const T* __restrict__ x, const float* __restrict__ inv_norm,
                                                          const float* __restrict__ dpooled, T* __restrict__ dx, int L,
                                                          int d) {
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float red[4][256];
+    const int cg = threadIdx.x & 63, ls = threadIdx.x >> 6;
+    const int col = blockIdx.x * 256 + cg * 4;
     const int64_t bi = blockIdx.y;
-    if (col >= d) return;
+    const bool live = col < d;
     const T* p = x + bi * L * (int64_t)d + col;
     T* o = dx + bi * L * (int64_t)d + col;
-    float S = 0.f;
-    for (int l = 0; l < L; ++l) S += to_f32(p[(int64_t)l * d]);
-    const float inv = inv_norm[bi * d + col], g = dpooled[bi * d + col] / L;
-    const float k = S * inv * inv * inv;
-    for (int l = 0; l < L; ++l) o[(int64_t)l * d] = from_f32<T>(g * (inv - k * to_f32(p[(int64_t)l * d])));
+    f32x4 S = {0.f, 0.f, 0.f, 0.f};
+    if (live)
+        for (int l = ls; l < L; l += 4) S += load4(p + (int64_t)l * d);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[ls][cg * 4 + j] = S[j];
+    __syncthreads();
+    if (!live) return;
+    f32x4 inv, g, k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = cg * 4 + j;
+        const float s = red[0][t] + red[1][t] + red[2][t] + red[3][t];
+        inv[j] = inv_norm[bi * d + col + j];
+        g[j] = dpooled[bi * d + col + j] / L;
+        k[j] = s * inv[j] * inv[j] * inv[j];
+    }
+    for (int l = ls; l < L; l += 4) store4(o + (int64_t)l * d, g * (inv - k * load4(p + (int64_t)l * d)));
 }
 
 // caption_regularization: loss = (sum_b |sum_p c_hat[b,p]|^2 - b n) / (b n^2).  One wave per sample, d <= 4096, n <= 8.
@@ -610,7 +642,7 @@ extern "C" int leccr_dstl_bwd(const float* v, const float* t, int64_t G, int64_t
 
 extern "C" int leccr_cvpool_fwd(const void* x, float* pooled, float* inv_norm, int64_t b, int64_t L, int64_t d, int dtype,
                                 void* stream) {
-    LECCR_REQUIRE(x && pooled && inv_norm && L > 0 && d > 0, LECCR_EINVAL, "cvpool_fwd: bad argument");
+    LECCR_REQUIRE(x && pooled && inv_norm && L > 0 && d > 0 && (d & 3) == 0, LECCR_EINVAL, "cvpool_fwd: bad argument (d % 4)");
     if (b == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     dim3 grid((unsigned)cdiv(d, 256), (unsigned)b);
@@ -622,7 +654,7 @@ extern "C" int leccr_cvpool_fwd(const void* x, float* pooled, float* inv_norm, i
 
 extern "C" int leccr_cvpool_bwd(const void* x, const float* inv_norm, const float* dpooled, void* dx, int64_t b, int64_t L,
                                 int64_t d, int dtype, void* stream) {
-    LECCR_REQUIRE(x && inv_norm && dpooled && dx && L > 0 && d > 0, LECCR_EINVAL, "cvpool_bwd: bad argument");
+    LECCR_REQUIRE(x && inv_norm && dpooled && dx && L > 0 && d > 0 && (d & 3) == 0, LECCR_EINVAL, "cvpool_bwd: bad argument (d % 4)");
     if (b == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     dim3 grid((unsigned)cdiv(d, 256), (unsigned)b);
