@@ -1,0 +1,126 @@
+// Micro-benchmark of the 256x256x64 K-tile instruction mix on one CU-filling grid (diagnostic, not part of the library):
+// per wave and iteration  N_MFMA matrix instructions + 24 ds_read_b128 + 8 LDS-DMA pieces + 2 barriers, 8 waves per block,
+// one block per CU.  Variants isolate what bounds the loop.   hipcc --offload-arch=gfx950 -O3 ktile_mix.hip -o ktile_mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) int int4_t;
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
+    int4_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(IMM));
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// MODE: 0 = 64 x mfma_16x16x32, 1 = 32 x mfma_32x32x16.   READS / DMA / BARS switch the fillers off.
+template <int MODE, bool READS, bool DMA, bool BARS>
+__global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, float* __restrict__ out, int iters, size_t span) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t rd = lbase + (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4) + wave * 2048;
+    const uint32_t wave_off = lbase + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
+    const char* g = src + ((size_t)blockIdx.x * 65536 + (size_t)tid * 16) % span;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    f32x4 acc4[32];
+    f32x16 acc16[8];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc4[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc16[i][j] = 0.f;
+    bf16x8 fa[8], fb[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = lds_b128<0>(rd + i * 2048);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fb[i] = lds_b128<64>(rd + i * 2048);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t slot = (it & 1) * 65536;
+        constexpr int NM = MODE == 0 ? 64 : 32;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) {
+            if constexpr (MODE == 0) acc4[i & 31] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i & 3], fa[i & 7], acc4[i & 31], 0, 0, 0);
+            else acc16[i & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i & 3], fa[i & 7], acc16[i & 7], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int STEP = NM / 32;                       // fillers spread evenly: 24 reads + 8 pieces over the MFMAs
+            if (i % STEP == 0) {
+                const int f = i / STEP;                         // 0..31
+                if (READS && f < 24) {
+                    if (f < 16) fa[f & 7] = lds_b128<0>(rd + slot + (f & 7) * 2048 + (f >> 3) * 64);
+                    else fb[f & 3] = lds_b128<32>(rd + slot + (f & 3) * 2048 + ((f >> 2) & 1) * 64);
+                }
+                if (DMA && f >= 24) {
+                    __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)(f - 24) * 8192), LDS_PTR((void*)(size_t)(wave_off + (65536 - slot) + (f - 24) * 8192)), 16, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (BARS && (i == NM / 2 - 1 || i == NM * 3 / 4 - 1)) {
+                if (i == NM / 2 - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        g += 65536;
+        if (g >= src + span - 131072) g -= span - 262144;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += acc4[i][0];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc16[i][0];
+    if (s == 12345.f) out[tid] = s;
+    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(out)[256] = __builtin_amdgcn_s_memtime() - t0;
+}
+
+template <int MODE, bool R, bool D, bool B>
+static void run(const char* name, const char* src, float* out, size_t span) {
+    auto k = mix<MODE, R, D, B>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(256), dim3(512), 131072, 0, src, out, 50, span);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(256), dim3(512), 131072, 0, src, out, iters, span);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us_per_tile = ms * 1e3 / iters;
+    const double tf = 2.0 * 256 * 256 * 64 * 256 / (us_per_tile * 1e-6) / 1e12;
+    unsigned long long cyc = 0;
+    hipMemcpy(&cyc, reinterpret_cast<unsigned long long*>(out) + 256, 8, hipMemcpyDeviceToHost);
+    printf("%-44s %7.3f us/K-tile  %5.0f shader cycles/K-tile (clock %.2f GHz)   %6.0f TF/s-equivalent\n", name, us_per_tile,
+           (double)cyc / iters, (double)cyc / (ms * 1e6), tf);
+}
+
+int main() {
+    const size_t span = 512ull << 20;
+    char* src; float* out;
+    hipMalloc(&src, span); hipMalloc(&out, 8192);
+    hipMemset(src, 0, span);
+    run<0, false, false, false>("16x16x32 x64, MFMA only", src, out, span);
+    run<1, false, false, false>("32x32x16 x32, MFMA only", src, out, span);
+    run<0, true, false, false>("16x16x32 + 24 reads", src, out, span);
+    run<1, true, false, false>("32x32x16 + 24 reads", src, out, span);
+    run<0, true, true, false>("16x16x32 + reads + 8 DMA", src, out, span);
+    run<1, true, true, false>("32x32x16 + reads + 8 DMA", src, out, span);
+    run<0, true, true, true>("16x16x32 + reads + DMA + 2 barriers", src, out, span);
+    run<1, true, true, true>("32x32x16 + reads + DMA + 2 barriers", src, out, span);
+    run<0, false, true, true>("16x16x32 + DMA + barriers (no reads)", src, out, span);
+    run<1, false, true, true>("32x32x16 + DMA + barriers (no reads)", src, out, span);
+    return 0;
+}
