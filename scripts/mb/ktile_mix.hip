@@ -20,7 +20,11 @@ __device__ __forceinline__ bf16x8 lds_b128(uint32_t addr) {
 }
 
 // MODE: 0 = 64 x mfma_16x16x32, 1 = 32 x mfma_32x32x16.   READS / DMA / BARS switch the fillers off.
-template <int MODE, bool READS, bool DMA, bool BARS>
+// STAG: 0 = every wave issues its 8 pieces in filler slots 24..31; 1 = waves 0-3 use slots 8..15, waves 4-7 slots 24..31
+//       (the two waves of a SIMD never issue pieces in the same stretch); 2 = all 8 pieces back to back at slot 24;
+//       3 = register staging instead of LDS-DMA: 8 global_load_dwordx4 in slots 24..31, their 8 ds_write_b128 in slots 8..15
+//       of the next iteration
+template <int MODE, bool READS, bool DMA, bool BARS, int STAG = 0>
 __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, float* __restrict__ out, int iters, size_t span) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -39,6 +43,9 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, floa
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc16[i][j] = 0.f;
     bf16x8 fa[8], fb[4];
+    int4_t stg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) stg[i] = int4_t{0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 8; ++i) fa[i] = lds_b128<0>(rd + i * 2048);
 #pragma unroll
@@ -59,14 +66,24 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, floa
                     if (f < 16) fa[f & 7] = lds_b128<0>(rd + slot + (f & 7) * 2048 + (f >> 3) * 64);
                     else fb[f & 3] = lds_b128<32>(rd + slot + (f & 3) * 2048 + ((f >> 2) & 1) * 64);
                 }
-                if (DMA && f >= 24) {
-                    __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)(f - 24) * 8192), LDS_PTR((void*)(size_t)(wave_off + (65536 - slot) + (f - 24) * 8192)), 16, 0, 0);
+                if constexpr (DMA) {
+                    auto piece = [&](int pi) {
+                        __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)pi * 8192), LDS_PTR((void*)(size_t)(wave_off + (65536 - slot) + pi * 8192)), 16, 0, 0);
+                    };
+                    if (STAG == 0 && f >= 24) piece(f - 24);
+                    if (STAG == 1 && ((wave < 4 && f >= 8 && f < 16) || (wave >= 4 && f >= 24))) piece(f & 7);
+                    if (STAG == 2 && f == 24) { for (int pi = 0; pi < 8; ++pi) piece(pi); }
+                    if constexpr (STAG == 3) {
+                        if (f >= 24) stg[f - 24] = *reinterpret_cast<const int4_t*>(g + (size_t)(f - 24) * 8192);
+                        if (f == 8) asm volatile("s_waitcnt vmcnt(0)" : "+v"(stg[0]), "+v"(stg[1]), "+v"(stg[2]), "+v"(stg[3]), "+v"(stg[4]), "+v"(stg[5]), "+v"(stg[6]), "+v"(stg[7]));
+                        if (f >= 8 && f < 16) asm volatile("ds_write_b128 %0, %1" :: "v"(wave_off + lane * 16 + slot + (f - 8) * 8192), "v"(stg[f - 8]) : "memory");
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (BARS && (i == NM / 2 - 1 || i == NM * 3 / 4 - 1)) {
                 if (i == NM / 2 - 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (STAG != 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -85,9 +102,9 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, floa
     if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(out)[256] = __builtin_amdgcn_s_memtime() - t0;
 }
 
-template <int MODE, bool R, bool D, bool B>
+template <int MODE, bool R, bool D, bool B, int STAG = 0>
 static void run(const char* name, const char* src, float* out, size_t span) {
-    auto k = mix<MODE, R, D, B>;
+    auto k = mix<MODE, R, D, B, STAG>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     const int iters = 2000;
     hipEvent_t e0, e1;
@@ -120,6 +137,12 @@ int main() {
     run<1, true, true, false>("32x32x16 + reads + 8 DMA", src, out, span);
     run<0, true, true, true>("16x16x32 + reads + DMA + 2 barriers", src, out, span);
     run<1, true, true, true>("32x32x16 + reads + DMA + 2 barriers", src, out, span);
+    run<0, true, true, true, 1>("16x16x32 full mix, DMA staggered by wave group", src, out, span);
+    run<1, true, true, true, 1>("32x32x16 full mix, DMA staggered by wave group", src, out, span);
+    run<0, true, true, true, 2>("16x16x32 full mix, 8 pieces back to back", src, out, span);
+    run<0, true, true, true, 3>("16x16x32 full mix, register-staged loads", src, out, span);
+    run<1, true, true, true, 3>("32x32x16 full mix, register-staged loads", src, out, span);
+    run<0, true, true, false, 3>("16x16x32 reads + register-staged, no barriers", src, out, span);
     run<0, false, true, true>("16x16x32 + DMA + barriers (no reads)", src, out, span);
     run<1, false, true, true>("32x32x16 + DMA + barriers (no reads)", src, out, span);
     return 0;
