@@ -8,8 +8,8 @@ dev = 'cuda'
 M = 256 * 577
 SH = [('qkv', 0, M, 2304, 768), ('out', 0, M, 768, 768), ('fc1', 0, M, 3072, 768), ('fc2', 0, M, 768, 3072),
       ('dW qkv', 1, 2304, 768, M), ('dW out', 1, 768, 768, M), ('dW fc1', 1, 3072, 768, M), ('dW fc2', 1, 768, 3072, M),
-      ('bert qkv', 0, 16384, 2304, 768), ('bert fc1', 0, 16384, 3072, 768), ('bert fc2', 0, 16384, 768, 3072),
-      ('bert dW fc1', 1, 3072, 768, 16384), ('sq 4096', 0, 4096, 4096, 4096), ('sq 8192', 0, 8192, 8192, 8192)]
+      ('bert out', 0, 16384, 768, 768), ('bert qkv', 0, 16384, 2304, 768), ('bert fc1', 0, 16384, 3072, 768), ('bert fc2', 0, 16384, 768, 3072),
+      ('bert dW fc1', 1, 3072, 768, 16384), ('bert dW out', 1, 768, 768, 16384), ('cap qkv', 0, 16384, 1536, 768), ('sq 4096', 0, 4096, 4096, 4096), ('sq 8192', 0, 8192, 8192, 8192)]
 reps = int(os.environ.get('REPS', 5))
 from leccr_amd import _lib
 if os.environ.get('LECCR_LIB'): _lib.LIB_PATH = os.environ['LECCR_LIB']

@@ -102,6 +102,80 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, floa
     if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(out)[256] = __builtin_amdgcn_s_memtime() - t0;
 }
 
+
+// The alternative block shape for the same 256x256x64 K-tile: 4 waves (one per SIMD), wave tile 128x128 = 16 accumulators of
+// v_mfma_f32_32x32x16_bf16 (256 accumulator registers), per wave and iteration 64 MFMAs + 32 ds_read_b128 + 16 DMA pieces.
+template <bool READS, bool DMA, int BARS>
+__global__ __launch_bounds__(256) void mix4(const char* __restrict__ src, float* __restrict__ out, int iters, size_t span) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t rd = lbase + (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4) + wave * 2048;
+    const uint32_t wave_off = lbase + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
+    const char* g = src + ((size_t)blockIdx.x * 65536 + (size_t)tid * 16) % span;
+    f32x16 acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+    bf16x8 fa[8], fb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { fa[i] = lds_b128<0>(rd + i * 2048); fb[i] = lds_b128<64>(rd + i * 2048); }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int it = 0; it < iters; ++it) {
+        const uint32_t slot = (it & 1) * 65536;
+#pragma unroll
+        for (int i = 0; i < 64; ++i) {
+            acc[i & 15] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i & 7], fa[(i >> 1) & 7], acc[i & 15], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (READS && i < 32) {
+                if (i < 16) fa[i & 7] = lds_b128<0>(rd + slot + (i & 7) * 2048 + (i >> 3) * 64);
+                else fb[i & 7] = lds_b128<32>(rd + slot + (i & 7) * 2048 + ((i >> 3) & 1) * 64);
+            }
+            if (DMA && i >= 32 && (i & 1) == 0) {
+                const int pi = (i - 32) >> 1;                       // 16 pieces of 256 threads x 16 B = 4 KiB each
+                __builtin_amdgcn_global_load_lds(GLB_PTR(g + (size_t)pi * 4096), LDS_PTR((void*)(size_t)(wave_off + (65536 - slot) + pi * 4096)), 16, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if ((BARS >= 1 && i == 31) || (BARS == 2 && i == 47)) {
+                if (i == 31 && BARS == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                else if (i == 31) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // one barrier: slot free + next tile landed
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        g += 65536;
+        if (g >= src + span - 131072) g -= span - 262144;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += acc[i][0];
+    if (s == 12345.f) out[tid] = s;
+    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(out)[256] = 0;
+}
+
+template <bool R, bool D, int B>
+static void run4(const char* name, const char* src, float* out, size_t span) {
+    auto k = mix4<R, D, B>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    const int iters = 2000;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k, dim3(256), dim3(256), 131072, 0, src, out, 50, span);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(256), dim3(256), 131072, 0, src, out, iters, span);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double us_per_tile = ms * 1e3 / iters;
+    printf("%-44s %7.3f us/K-tile  %6.0f TF/s-equivalent\n", name, us_per_tile, 2.0 * 256 * 256 * 64 * 256 / (us_per_tile * 1e-6) / 1e12);
+}
+
 template <int MODE, bool R, bool D, bool B, int STAG = 0>
 static void run(const char* name, const char* src, float* out, size_t span) {
     auto k = mix<MODE, R, D, B, STAG>;
@@ -145,5 +219,10 @@ int main() {
     run<0, true, true, false, 3>("16x16x32 reads + register-staged, no barriers", src, out, span);
     run<0, false, true, true>("16x16x32 + DMA + barriers (no reads)", src, out, span);
     run<1, false, true, true>("32x32x16 + DMA + barriers (no reads)", src, out, span);
+    run4<false, false, 0>("4 waves: 32x32x16 x64, MFMA only", src, out, span);
+    run4<true, false, 0>("4 waves: + 32 reads", src, out, span);
+    run4<true, true, 0>("4 waves: + reads + 16 DMA", src, out, span);
+    run4<true, true, 2>("4 waves: + reads + DMA + 2 barriers", src, out, span);
+    run4<true, true, 1>("4 waves: + reads + DMA + 1 barrier (vmcnt 0)", src, out, span);
     return 0;
 }
