@@ -36,7 +36,10 @@ int leccr_set_force_generic(int on);           /* 1: route every op through the 
 /* Optional timing of the GEMM / attention launches with hipEvents recorded on the launch stream (bench.py's
  * roofline leg).  read(): ms[5], work[5] (algorithmic FLOPs), launches[5] indexed
  * {gemm_mfma_nt, gemm_mfma_tn, gemm_generic, attn_fwd, attn_bwd}; synchronises on the recorded events. */
-int leccr_set_gemm_variant(int v);             /* 0 auto (default), 1 force the 128x128 kernel, 2 force the 256x256 kernel */
+int leccr_set_gemm_variant(int v);             /* 0 auto (default), 1 force the 128x128 kernel, 2 / 3 force the 8-wave /
+                                                * 4-wave 256x256 kernel where it is legal */
+int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_gemm launched: 0 generic, 1 MFMA 128x128,
+                                                * 2 MFMA 256x256 (8 waves), 3 MFMA 256x256 (4 waves); tests use it */
 int leccr_prof_enable(int on);
 int leccr_prof_read(double* ms, double* work, int64_t* launches);
 

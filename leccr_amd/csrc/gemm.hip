@@ -351,7 +351,11 @@ bool gemm256_wanted(const leccr_gemm_params& p);
 bool gemm256_legal(const leccr_gemm_params& p);
 bool gemm256_fuses_colsum(const leccr_gemm_params& p);
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
-static int g_gemm_variant = 0;  // 0 auto, 1 force the 128x128 kernel, 2 force the 256x256 kernel where legal
+bool gemm256w4_legal(const leccr_gemm_params& p);
+int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st);
+// 0 auto, 1 force the 128x128 kernel, 2 force the 8-wave 256x256 kernel where legal, 3 force the 4-wave 256x256 kernel where legal
+static int g_gemm_variant = 0;
+static int g_last_kernel = 0;
 }
 
 namespace leccr { void gemm256_set_stamps(void* p); }
@@ -359,6 +363,8 @@ extern "C" int leccr_debug_set_stamps(void* p) {      // diagnostic builds (-DLE
     leccr::gemm256_set_stamps(p);
     return LECCR_OK;
 }
+
+extern "C" int leccr_last_gemm_kernel(void) { return g_last_kernel; }
 
 extern "C" int leccr_set_gemm_variant(int v) {
     g_gemm_variant = v;
@@ -375,15 +381,22 @@ static int gemm_dispatch(const leccr_gemm_params& p, hipStream_t st, bool* colsu
     const double flops = 2.0 * (double)p.M * (double)p.N * (double)p.K;
     if (mfma_ok(p)) {
         ProfScope prof(p.trans_a == 0 ? PROF_GEMM_NT : PROF_GEMM_TN, flops, st);
-        if ((g_gemm_variant == 2 && gemm256_legal(p)) || (g_gemm_variant == 0 && gemm256_wanted(p))) {
+        if (g_gemm_variant == 3 && gemm256w4_legal(p)) {
+            g_last_kernel = 3;
+            return gemm256w4_launch(p, st);
+        }
+        if (((g_gemm_variant == 2 || g_gemm_variant == 3) && gemm256_legal(p)) || (g_gemm_variant == 0 && gemm256_wanted(p))) {
             *colsum_fused = gemm256_fuses_colsum(p);
+            g_last_kernel = 2;
             return gemm256_launch(p, st);
         }
+        g_last_kernel = 1;
         if (p.trans_a == 0)
             return p.c_dtype == LECCR_F32 ? launch_mfma<0, float>(p, st) : launch_mfma<0, bf16_t>(p, st);
         return p.c_dtype == LECCR_F32 ? launch_mfma<1, float>(p, st) : launch_mfma<1, bf16_t>(p, st);
     }
     ProfScope prof(PROF_GEMM_GENERIC, flops, st);
+    g_last_kernel = 0;
     if (p.ab_dtype == LECCR_F32) {
         LECCR_REQUIRE(p.c_dtype == LECCR_F32, LECCR_EINVAL, "gemm: f32 operands need an f32 C");
         return launch_generic<float, float>(p, st);

@@ -38,7 +38,7 @@ constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 16384;            // bytes per half-tile
 constexpr int SLOT = 4 * HALF;         // A0 A1 B0 B1
 constexpr int NTHREADS = 512;
-constexpr int LDS_BYTES = 2 * SLOT + 8 * (8 * 68 * 4);      // operand slots + per-wave epilogue staging (8 rows x 68 f32)
+constexpr int LDS_BYTES = 2 * SLOT + 8 * (16 * 64 * 4);     // operand slots + per-wave epilogue staging (16 rows x 64 f32): 160 KiB
 
 struct Args {
     const bf16_t* A;
@@ -365,6 +365,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
     if constexpr (TRANS == 0) first_frags(0);
 
     int t = 0;                                         // global K-tile counter of this block's stream (slot parity)
+#ifdef LECCR_G256_STAMPS
+    unsigned long long sk_ = 0, se_ = 0, sf_ = 0;
+    const unsigned long long start_ = __builtin_amdgcn_s_memrealtime(), c0_ = __builtin_amdgcn_s_memtime();
+    unsigned long long ts_ = start_;
+#endif
     for (int j = 0; j < n_mine; ++j) {
         f32x4 acc[4][8];                               // [ni][mi]
 #pragma unroll
@@ -538,6 +543,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
         }
 
         // ---- epilogue segment of this item (the partner wave is in its last COMPUTE / first LOAD meanwhile)
+#ifdef LECCR_G256_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t1_ = __builtin_amdgcn_s_memrealtime();
+        sk_ += t1_ - ts_;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         {
             const int64_t m0 = cur.m0, n0 = cur.n0;
             const bool interior = m0 + BM <= a.M && n0 + BN <= a.N;
@@ -568,13 +579,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                 // (C, aux, aux_out, residual) is 16 bytes per lane and a wave instruction covers 8 full 128-byte rows,
                 // instead of 8-byte pieces scattered over 16 rows (the store tail was issue-bound: 15-17 % of a
                 // K = 768 item, in-kernel stamps).
-                float* stg = reinterpret_cast<float*>(smem + 2 * SLOT) + wave * (8 * 68);
+                float* stg = reinterpret_cast<float*>(smem + 2 * SLOT) + wave * (16 * 64);
                 // lane-derived epilogue addresses are re-derived per item from an opaque copy of the lane id: hoisted out
                 // of the item loop they live across the K loop, get spilled, and their reloads cost a scratch round
                 // trip each (with a vmcnt(0)) in every epilogue
                 int lane_e = lane;
                 asm volatile("" : "+v"(lane_e));
-                const int rrow = lane_e >> 3, rcol = (lane_e & 7) * 8;         // read side: row 0-7, 8 columns
+                const int rrow = lane_e >> 3, rcol = (lane_e & 7) * 8;         // read side: rows rrow and rrow + 8, 8 columns
                 const int64_t ncol = n0 + wc * 64 + rcol;
                 const bool col_ok = interior || ncol < a.N;                    // N % 8 == 0 (dispatcher)
                 // The epilogue operand that is READ (the saved pre-activation of a d-activation epilogue, else the
@@ -582,12 +593,42 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                 // memory round trip (16 serial latencies per item - 30-40 % of a K = 768 item).
                 constexpr bool NEED_AUX = EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU;
                 constexpr bool PRE_RES = (FLAGS & F_RES) != 0 && !NEED_AUX;
+                // The staging buffer holds one whole 16 x 64 strip (rows of 16 chunks of 16 bytes, chunk ^= row): every lane
+                // writes its 4 accumulators of the strip, then reads 8 columns of rows rrow and rrow + 8.  LDS operations of
+                // a wave execute in order, so the strips are software-pipelined without any wait between them: write(mi+2) is
+                // issued right behind read(mi+1), and the only waits are for the data of read(mi) while read(mi+1) is already
+                // in flight (the serial write -> read -> store round trip per half strip was 3.5 us of a 24 us K = 768 item).
+                const int wrow = lane_e & 15, wq = lane_e >> 4;
+                float* wbase = stg + wrow * 64;
+                const float* rbase0 = stg + rrow * 64;
+                const float* rbase1 = stg + (rrow + 8) * 64;
+                const int rc = (lane_e & 7) * 2;                                  // first of this lane's two chunks
+                auto put = [&](int mi) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(wbase + (((ni * 4 + wq) ^ wrow) << 2)) = acc[ni][mi];
+                    WAVE_LDS_FENCE();
+                };
+                auto get = [&](f32x4 (&v)[4]) {
+                    v[0] = *reinterpret_cast<const f32x4*>(rbase0 + ((rc ^ rrow) << 2));
+                    v[1] = *reinterpret_cast<const f32x4*>(rbase0 + (((rc + 1) ^ rrow) << 2));
+                    v[2] = *reinterpret_cast<const f32x4*>(rbase1 + ((rc ^ (rrow + 8)) << 2));
+                    v[3] = *reinterpret_cast<const f32x4*>(rbase1 + (((rc + 1) ^ (rrow + 8)) << 2));
+                    WAVE_LDS_FENCE();
+                };
                 // Two copies of the strip loop: interior tiles (the hot case) carry no per-lane bounds checks, so the
                 // code is straight-line and hipcc's waits on the prefetched operand are counted (vmcnt(N)); with the
                 // checks' branches in the way every strip waited vmcnt(0), i.e. for the previous strip's store as well.
                 auto strips = [&](auto check_tag) {
                     constexpr bool CHECK = decltype(check_tag)::value;
-                    bf16x8 pre[(NEED_AUX || PRE_RES) ? 8 : 1];       // 8 strips per batch: two round trips per item
+                    bf16x8 pre[(NEED_AUX || PRE_RES) ? 8 : 1];       // 8 half strips per batch: two round trips per item
+                    f32x4 vbuf[2][4];
+                    const int64_t mrow = m0 + wr * 128 + rrow;       // this lane's row of strip 0, half 0
+                    bf16_t* cptr = reinterpret_cast<bf16_t*>(a.C) + mrow * a.ldc + ncol;
+                    bf16_t* optr = reinterpret_cast<bf16_t*>(a.aux_out) + mrow * a.ldc + ncol;
+                    const int64_t step8 = 8 * a.ldc;
+                    put(0);
+                    get(vbuf[0]);
+                    put(1);
 #pragma unroll
                     for (int mi = 0; mi < 8; ++mi) {
                         if constexpr (NEED_AUX || PRE_RES) {
@@ -596,32 +637,25 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                                 const int64_t pld = NEED_AUX ? a.ldaux : a.ldr;
 #pragma unroll
                                 for (int i = 0; i < 8; ++i) {
-                                    const int64_t m = m0 + wr * 128 + (mi + (i >> 1)) * 16 + (i & 1) * 8 + rrow;
+                                    const int64_t m = mrow + (mi + (i >> 1)) * 16 + (i & 1) * 8;
                                     const bool ok = !CHECK || (col_ok && m < a.M);
                                     pre[i] = *reinterpret_cast<const bf16x8*>(pbase + (ok ? m * pld + ncol : 0));
                                 }
                             }
                         }
+                        if (mi + 1 < 8) get(vbuf[(mi + 1) & 1]);
+                        if (mi + 2 < 8) put(mi + 2);
 #pragma unroll
                         for (int hp = 0; hp < 2; ++hp) {
-                            if (((lane & 15) >> 3) == hp) {
-#pragma unroll
-                                for (int ni = 0; ni < 4; ++ni)
-                                    *reinterpret_cast<f32x4*>(stg + (lane & 7) * 68 + ni * 16 + (lane >> 4) * 4) = acc[ni][mi];
-                            }
-                            WAVE_LDS_FENCE();        // the reads below fetch what OTHER lanes of the wave just wrote
-                            f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + rrow * 68 + rcol);
-                            f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + rrow * 68 + rcol + 4);
-                            WAVE_LDS_FENCE();
-                            const int64_t m = m0 + wr * 128 + mi * 16 + hp * 8 + rrow;
+                            f32x4 v0 = vbuf[mi & 1][2 * hp], v1 = vbuf[mi & 1][2 * hp + 1];
+                            const int64_t m = mrow + mi * 16 + hp * 8;
                             const bool ok = !CHECK || (col_ok && m < a.M);
-                            bf16_t* crow = reinterpret_cast<bf16_t*>(a.C) + m * a.ldc + ncol;
                             if constexpr ((FLAGS & F_AUXOUT) != 0) {
-                                bf16_t* orow = reinterpret_cast<bf16_t*>(a.aux_out) + m * a.ldc + ncol;
                                 bf16x8 pv;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { pv[r] = (bf16_t)v0[r]; pv[4 + r] = (bf16_t)v1[r]; }
-                                if (ok) *reinterpret_cast<bf16x8*>(orow) = pv;
+                                if (ok) *reinterpret_cast<bf16x8*>(optr) = pv;
+                                optr += step8;
                             }
                             if constexpr (EPI != LECCR_EPI_NONE) {
                                 f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
@@ -643,7 +677,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                             bf16x8 ov;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { ov[r] = (bf16_t)v0[r]; ov[4 + r] = (bf16_t)v1[r]; }
-                            if (ok) *reinterpret_cast<bf16x8*>(crow) = ov;
+                            if (ok) *reinterpret_cast<bf16x8*>(cptr) = ov;
+                            cptr += step8;
                         }
                     }
                 };
@@ -721,6 +756,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (TRANS == 1) SEG_BARRIER();
         }
+#ifdef LECCR_G256_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long t2_ = __builtin_amdgcn_s_memrealtime();
+        se_ += t2_ - t1_;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // move `cur` to the next item and fetch the first fragments of its first K-tile (already visible: Q3's barrier)
         if (j + 1 < n_mine) {
             cur.j = j + 1;
@@ -728,7 +769,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             decode<TRANS>(a, first_item, stride, cur);
             if constexpr (TRANS == 0) first_frags((t & 1) * SLOT);
         }
+#ifdef LECCR_G256_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        ts_ = __builtin_amdgcn_s_memrealtime();
+        sf_ += ts_ - t2_;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
+#ifdef LECCR_G256_STAMPS
+    if (a.stamps != nullptr && tid == 0) {
+        unsigned long long* o = a.stamps + 32 + (size_t)blockIdx.x * 8;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = start_; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = sk_; o[3] = se_; o[4] = sf_; o[5] = (unsigned long long)n_mine;
+        o[6] = xcc & 15; o[7] = __builtin_amdgcn_s_memtime() - c0_;
+    }
+#endif
     if constexpr (TRANS == 1) {
         if (wr == 0) SEG_BARRIER();                    // group 0 waits out group 1's trailing segment
     }

@@ -15,7 +15,9 @@ from leccr_amd import _lib
 if os.environ.get('LECCR_LIB'): _lib.LIB_PATH = os.environ['LECCR_LIB']
 _lib.lib().leccr_set_gemm_variant(int(os.environ.get('VARIANT', 0)))
 print('variant', os.environ.get('VARIANT', 0))
+only = [x for x in os.environ.get('ONLY', '').split(',') if x]
 for name, tn, m, n, k in SH:
+    if only and name not in only: continue
     if tn:
         a = torch.randn(k, m, device=dev).bfloat16(); b = torch.randn(k, n, device=dev).bfloat16()
         out = torch.zeros(m, n, device=dev)

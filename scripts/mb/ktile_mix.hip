@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -32,8 +33,12 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, floa
     const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t rd = lbase + (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4) + wave * 2048;
     const uint32_t wave_off = lbase + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
+    // fill this block's LDS from src (with random src data the MFMA operands toggle as in a real GEMM: power, hence clocks)
+    for (uint32_t o = tid * 16; o < 131072; o += blockDim.x * 16)
+        *reinterpret_cast<int4_t*>(smem + o) = *reinterpret_cast<const int4_t*>(src + ((size_t)blockIdx.x * 131072 + o) % span);
+    __syncthreads();
     const char* g = src + ((size_t)blockIdx.x * 65536 + (size_t)tid * 16) % span;
-    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     f32x4 acc4[32];
     f32x16 acc16[8];
 #pragma unroll
@@ -99,7 +104,10 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, floa
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += acc16[i][0];
     if (s == 12345.f) out[tid] = s;
-    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(out)[256] = __builtin_amdgcn_s_memtime() - t0;
+    if (blockIdx.x == 0 && tid == 0) {
+        reinterpret_cast<unsigned long long*>(out)[256] = __builtin_amdgcn_s_memtime() - t0;
+        reinterpret_cast<unsigned long long*>(out)[257] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
 }
 
 
@@ -113,7 +121,12 @@ __global__ __launch_bounds__(256) void mix4(const char* __restrict__ src, float*
     const uint32_t lbase = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t rd = lbase + (lane & 15) * 128 + (((lane >> 4) ^ (lane & 7)) << 4) + wave * 2048;
     const uint32_t wave_off = lbase + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
+    // fill this block's LDS from src (with random src data the MFMA operands toggle as in a real GEMM: power, hence clocks)
+    for (uint32_t o = tid * 16; o < 131072; o += blockDim.x * 16)
+        *reinterpret_cast<int4_t*>(smem + o) = *reinterpret_cast<const int4_t*>(src + ((size_t)blockIdx.x * 131072 + o) % span);
+    __syncthreads();
     const char* g = src + ((size_t)blockIdx.x * 65536 + (size_t)tid * 16) % span;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
@@ -155,7 +168,13 @@ __global__ __launch_bounds__(256) void mix4(const char* __restrict__ src, float*
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i][0];
     if (s == 12345.f) out[tid] = s;
-    if (blockIdx.x == 0 && tid == 0) reinterpret_cast<unsigned long long*>(out)[256] = 0;
+    if (tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(out) + 512 + blockIdx.x * 4;
+        o[0] = r0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = __builtin_amdgcn_s_memtime() - t0;
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[3] = xcc;
+    }
 }
 
 template <bool R, bool D, int B>
@@ -174,6 +193,16 @@ static void run4(const char* name, const char* src, float* out, size_t span) {
     hipEventElapsedTime(&ms, e0, e1);
     const double us_per_tile = ms * 1e3 / iters;
     printf("%-44s %7.3f us/K-tile  %6.0f TF/s-equivalent\n", name, us_per_tile, 2.0 * 256 * 256 * 64 * 256 / (us_per_tile * 1e-6) / 1e12);
+    std::vector<unsigned long long> h(256 * 4);
+    hipMemcpy(h.data(), reinterpret_cast<unsigned long long*>(out) + 512, h.size() * 8, hipMemcpyDeviceToHost);
+    unsigned long long rmin = ~0ull;
+    for (int b = 0; b < 256; ++b) rmin = h[b * 4] < rmin ? h[b * 4] : rmin;
+    printf("   per block (start us, duration us, GHz, xcc):");
+    for (int b = 0; b < 256; b += 1) {
+        if (b % 8 == 0) printf("\n     ");
+        printf(" [%5.0f %5.0f %.2f %llu]", (h[b * 4] - rmin) / 100.0, (h[b * 4 + 1] - h[b * 4]) / 100.0, h[b * 4 + 2] / ((h[b * 4 + 1] - h[b * 4]) * 10.0), h[b * 4 + 3] & 15);
+    }
+    printf("\n");
 }
 
 template <int MODE, bool R, bool D, bool B, int STAG = 0>
@@ -192,17 +221,29 @@ static void run(const char* name, const char* src, float* out, size_t span) {
     hipEventElapsedTime(&ms, e0, e1);
     const double us_per_tile = ms * 1e3 / iters;
     const double tf = 2.0 * 256 * 256 * 64 * 256 / (us_per_tile * 1e-6) / 1e12;
-    unsigned long long cyc = 0;
-    hipMemcpy(&cyc, reinterpret_cast<unsigned long long*>(out) + 256, 8, hipMemcpyDeviceToHost);
-    printf("%-44s %7.3f us/K-tile  %5.0f shader cycles/K-tile (clock %.2f GHz)   %6.0f TF/s-equivalent\n", name, us_per_tile,
-           (double)cyc / iters, (double)cyc / (ms * 1e6), tf);
+    unsigned long long cyc[2] = {0, 0};
+    hipMemcpy(cyc, reinterpret_cast<unsigned long long*>(out) + 256, 16, hipMemcpyDeviceToHost);
+    printf("%-44s %7.3f us/K-tile  %5.0f memtime ticks/K-tile (%.2f G/s; memrealtime %.1f M/s)   %6.0f TF/s-equivalent\n", name, us_per_tile,
+           (double)cyc[0] / iters, (double)cyc[0] / (ms * 1e6), (double)cyc[1] / (ms * 1e3), tf);
 }
 
-int main() {
+int main(int argc, char** argv) {
     const size_t span = 512ull << 20;
     char* src; float* out;
-    hipMalloc(&src, span); hipMalloc(&out, 8192);
+    hipMalloc(&src, span); hipMalloc(&out, 65536);
     hipMemset(src, 0, span);
+    if (argc > 1 && atoi(argv[1]) == 1) {           // random bf16 in [-1, 1): realistic operand toggling
+        std::vector<unsigned short> h(32u << 20);
+        unsigned long long x = 88172645463325252ull;
+        for (auto& v : h) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            const float f = (float)((x >> 11) & 0xFFFFFF) / 8388608.f - 1.f;
+            unsigned int u; memcpy(&u, &f, 4);
+            v = (unsigned short)(u >> 16);
+        }
+        for (size_t o = 0; o < span; o += h.size() * 2) hipMemcpy(src + o, h.data(), h.size() * 2, hipMemcpyHostToDevice);
+        printf("operands: random bf16\n");
+    } else printf("operands: zeros\n");
     run<0, false, false, false>("16x16x32 x64, MFMA only", src, out, span);
     run<1, false, false, false>("32x32x16 x32, MFMA only", src, out, span);
     run<0, true, false, false>("16x16x32 + 24 reads", src, out, span);

@@ -477,6 +477,41 @@ def test_gemm256_nt(K, force256, M, N, K_, epi):
         assert e <= 1.2e-2 * s
 
 
+@pytest.mark.parametrize('M,N,K_', [(512, 512, 64), (512, 512, 128), (1154, 768, 768), (2000, 1024, 256), (256 * 40, 2304, 768),
+                                    (300, 288, 192), (256 * 70, 768, 192), (256 * 33 + 1, 3072, 1024)])
+@pytest.mark.parametrize('case', ['plain', 'res', 'act', 'gelu', 'dact'])
+def test_gemm256_w4(K, M, N, K_, case):
+    """The 4-wave 256x256 kernel (forward / dX products, bf16 out) against f64, every epilogue it is compiled for."""
+    from leccr_amd import _lib
+    a, b = _rand((M, K_), torch.bfloat16, 290), _rand((N, K_), torch.bfloat16, 291, 0.05)
+    bias, extra = _rand((N,), torch.float32, 292), _rand((M, N), torch.bfloat16, 293)
+    u = a.double() @ b.double().t() + bias.double()
+    kw, pre = {}, None
+    if case == 'res':
+        kw, ref = dict(residual=extra.to(DEV)), u + extra.double()
+    elif case in ('act', 'gelu'):
+        epi = 1 if case == 'act' else 2
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        kw, ref = dict(epilogue=epi, aux_out=pre), ACT[epi](u)
+    elif case == 'dact':
+        x = extra.double()
+        sg = torch.sigmoid(1.702 * x)
+        kw, ref = dict(epilogue=3, aux=extra.to(DEV)), u * (sg * (1 + 1.702 * x * (1 - sg)))
+    else:
+        ref = u
+    _lib.lib().leccr_set_gemm_variant(3)
+    try:
+        out = K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), **kw)
+        assert _lib.lib().leccr_last_gemm_kernel() == 3
+    finally:
+        _lib.lib().leccr_set_gemm_variant(0)
+    e, s = _err(out, ref)
+    assert e <= 1.2e-2 * s, (e, s)
+    if pre is not None:
+        e, s = _err(pre, u)
+        assert e <= 1.2e-2 * s
+
+
 @pytest.mark.parametrize('M,N,K_', [(1154, 768, 256), (2000, 1024, 128), (300, 260, 64), (40, 24, 16)])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 def test_gemm_fused_colsum(K, dtype, M, N, K_):
