@@ -35,6 +35,7 @@ def parse():
     ap.add_argument('--clip', default='ViT-B/16')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--roofline-steps', type=int, default=3, help='extra single-stream steps after the timed region that time the GEMM launches on their own')
     ap.add_argument('--cpu-batch', type=int, default=4)
     ap.add_argument('--cpu-steps', type=int, default=6)
     return ap.parse_args()
@@ -145,10 +146,32 @@ def main():
         dt = float(tt)
     ms, work, n = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
     lib.leccr_prof_read(ms, work, n)
+    # GEMM busy time = union of the launch intervals (HIP events on the launch streams): the weight-gradient GEMMs run on a
+    # second stream beside the dX chain, so summing per-launch durations would count the overlapped stretches twice
+    busy, gwork, gn = C.c_double(), C.c_double(), C.c_int64()
+    lib.leccr_prof_read_union(0b11, C.byref(busy), C.byref(gwork), C.byref(gn))
+    # Roofline leg: the same steps with every launch on ONE stream, so that a GEMM launch's event interval is the kernel running
+    # alone (in the timed region above a dW GEMM shares the chip with the dX chain, and its own interval is stretched by that).
+    from leccr_amd import ops
+    ms1, work1, n1 = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
+    if args.roofline_steps > 0:
+        overlap, ops.wgrad_overlap = ops.wgrad_overlap, False
+        barrier()
+        lib.leccr_prof_enable(1)
+        for _ in range(args.roofline_steps):
+            train_step(model, batch, opt, sched)
+        barrier()
+        lib.leccr_prof_enable(0)
+        lib.leccr_prof_read(ms1, work1, n1)
+        ops.wgrad_overlap = overlap
     if rank == 0:
         G = args.batch * world
         value = G * args.steps / dt
-        gemm_ms, gemm_fl, gemm_n = ms[0] + ms[1], work[0] + work[1], n[0] + n[1]
+        union_ms, union_fl = busy.value, gwork.value
+        if args.roofline_steps > 0:
+            gemm_ms, gemm_fl, gemm_n, leg_steps = ms1[0] + ms1[1], work1[0] + work1[1], n1[0] + n1[1], args.roofline_steps
+        else:
+            gemm_ms, gemm_fl, gemm_n, leg_steps = ms[0] + ms[1], work[0] + work[1], n[0] + n[1], args.steps
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = None, None
         tj = os.path.join(ROOT, 'profiles', 'r01_gemm256_hbm_traffic.json')
@@ -169,13 +192,18 @@ def main():
                          'achieved': round(achieved, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
                          'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': traffic_src,
-                         'launches_per_step': gemm_n // max(1, args.steps),
+                         'launches_per_step': gemm_n // max(1, leg_steps),
                          'avg_launch_us': round(gemm_ms * 1e3 / max(1, gemm_n), 2),
                          'avg_launch_gflop': round(gemm_fl / max(1, gemm_n) / 1e9, 2),
-                         'gemm_share_of_step': round(gemm_ms / (dt * 1e3), 3),
-                         'attn_fwd_ms_per_step': round(ms[3] / args.steps, 3),
-                         'attn_bwd_ms_per_step': round(ms[4] / args.steps, 3),
-                         'generic_gemm_ms_per_step': round(ms[2] / args.steps, 3)},
+                         'timing': (f'HIP events on the launch stream around every GEMM launch of {leg_steps} single-stream steps run right '
+                                    'after the timed region (same process, same tensors): each interval is the kernel alone. In the timed '
+                                    'region the dW launches share the chip with the dX chain on a second stream')
+                                   if args.roofline_steps > 0 else 'HIP events around every GEMM launch of the timed region',
+                         'timed_region_gemm_tflops_union': round(union_fl / (union_ms * 1e-3) / 1e12, 1) if union_ms > 0 else None,
+                         'timed_region_gemm_busy_share': round(union_ms / (dt * 1e3), 3),
+                         'attn_fwd_ms_per_step': round((ms1[3] / leg_steps) if args.roofline_steps > 0 else (ms[3] / args.steps), 3),
+                         'attn_bwd_ms_per_step': round((ms1[4] / leg_steps) if args.roofline_steps > 0 else (ms[4] / args.steps), 3),
+                         'generic_gemm_ms_per_step': round((ms1[2] / leg_steps) if args.roofline_steps > 0 else (ms[2] / args.steps), 3)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cfg)

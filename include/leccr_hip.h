@@ -42,6 +42,9 @@ int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_ge
                                                 * 2 MFMA 256x256 (8 waves), 3 MFMA 256x256 (4 waves); tests use it */
 int leccr_prof_enable(int on);
 int leccr_prof_read(double* ms, double* work, int64_t* launches);
+/* The launches of the kinds in kind_mask (bit k = index k above) as one busy time: the union of their [start, stop]
+ * intervals (launches that overlap on two streams are not counted twice), their total work and count. */
+int leccr_prof_read_union(int kind_mask, double* busy_ms, double* work, int64_t* launches);
 
 /* ---- GEMM -------------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )      (+ C if accumulate)

@@ -3,6 +3,9 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include <algorithm>
+#include <utility>
+#include <vector>
 
 namespace leccr {
 static thread_local char g_err[512] = "";
@@ -68,6 +71,36 @@ extern "C" int leccr_prof_read(double* ms, double* work, int64_t* launches) {
         work[r.kind] += r.work;
         launches[r.kind] += 1;
     }
+    return LECCR_OK;
+}
+
+// Launches of the kinds in `kind_mask` (bit k = kind k) as ONE busy time: the union of their [start, stop] intervals, so that
+// launches overlapping on two streams (weight-gradient GEMMs beside the dX chain) are not counted twice.  Synchronises.
+extern "C" int leccr_prof_read_union(int kind_mask, double* busy_ms, double* work, int64_t* launches) {
+    using namespace leccr;
+    *busy_ms = 0; *work = 0; *launches = 0;
+    std::vector<std::pair<float, float>> iv;
+    hipEvent_t base = nullptr;
+    for (int i = 0; i < g_prof_n; ++i) {
+        ProfRec& r = g_prof[i];
+        if (!((kind_mask >> r.kind) & 1)) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) continue;
+        if (!base) base = r.a;
+        float t0 = 0.f, t1 = 0.f;
+        if (hipEventElapsedTime(&t0, base, r.a) != hipSuccess || hipEventElapsedTime(&t1, base, r.b) != hipSuccess) continue;
+        iv.emplace_back(t0, t1);
+        *work += r.work;
+        *launches += 1;
+    }
+    std::sort(iv.begin(), iv.end());
+    float lo = 0.f, hi = 0.f;
+    bool open = false;
+    for (auto& p : iv) {
+        if (!open) { lo = p.first; hi = p.second; open = true; }
+        else if (p.first <= hi) hi = p.second > hi ? p.second : hi;
+        else { *busy_ms += hi - lo; lo = p.first; hi = p.second; }
+    }
+    if (open) *busy_ms += hi - lo;
     return LECCR_OK;
 }
 

@@ -37,6 +37,8 @@ class ArenaAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         g = self.param_groups[0]
+        from . import ops
+        ops.join_wgrad_stream()
         if self.grad_sync is not None:
             self.grad_sync()
         self.arena.mark_autograd_grads()

@@ -46,9 +46,11 @@ def attach_grad_sync(optimizer):
 
     def early():
         if not pending:                       # once per step
+            ops.join_wgrad_stream()           # the early region's weight gradients were accumulated on the side stream
             reduce_range(0, split)
 
     def sync():
+        ops.join_wgrad_stream()
         if not pending:                       # no ViT backward ran (e.g. a text-only step): reduce everything now
             reduce_range(0, split)
         reduce_range(split, grad.numel())
