@@ -106,17 +106,6 @@ class RetrievalModel(XVLMBase):
             rank, _ = _dist_info()
             ops.set_dropout_seed((int(self.config.get('seed', 42)) + rank) * 1000003 + self._step_count)
         tval = float(self.temp.detach())          # the step's only host read of a device scalar
-        ori_image, _ = self.get_vision_embeds(image)
-        with torch.no_grad():
-            cap_ids, cap_atts = captions.input_ids, captions.attention_mask
-            cap_hidden = self.get_caption_embeds(cap_ids, cap_atts)
-        kpm = ~cap_atts.bool()
-        after_image, after_caption, ori_caption = self._interaction(ori_image, cap_hidden, kpm)
-
-        loss_cv = self._cv_loss(ori_caption, ori_image, idx) * self.weight_cv_loss
-        loss_reg_c = ops.CapRegFn.apply(ori_caption)
-
-        image_feat = self.get_features(after_image, None)
         ids_s, atts_s = text_ls[0].input_ids, text_ls[0].attention_mask
         ids_t, atts_t = text_ls[1].input_ids, text_ls[1].attention_mask
         b = ids_s.shape[0]
@@ -124,8 +113,35 @@ class RetrievalModel(XVLMBase):
 
         def pad(x):
             return x if x.shape[1] == L else torch.nn.functional.pad(x, (0, L - x.shape[1]))
-        hid = self.get_text_embeds(torch.cat([pad(ids_s), pad(ids_t)], 0), torch.cat([pad(atts_s), pad(atts_t)], 0))
-        feats = self.get_features(None, hid)          # padded key positions are masked: [CLS] rows are unchanged
+        cap_ids, cap_atts = captions.input_ids, captions.attention_mask
+
+        def text_side():
+            with torch.no_grad():
+                cap_h = self.get_caption_embeds(cap_ids, cap_atts)
+            hid = self.get_text_embeds(torch.cat([pad(ids_s), pad(ids_t)], 0), torch.cat([pad(atts_s), pad(atts_t)], 0))
+            return cap_h, self.get_features(None, hid)     # padded key positions are masked: [CLS] rows are unchanged
+
+        # The image tower first (program order = the order the reference runs them; the text towers' autograd nodes are the
+        # younger ones, so backward enqueues them first), the two BERT passes beside it on the text stream when enabled.
+        ori_image, _ = self.get_vision_embeds(image)
+        ts = ops.text_stream(image.device)
+        if ts is None:
+            cap_hidden, feats = text_side()
+        else:
+            main = torch.cuda.current_stream()
+            ts.wait_stream(main)
+            with torch.cuda.stream(ts):
+                cap_hidden, feats = text_side()
+            main.wait_stream(ts)
+            cap_hidden.record_stream(main)
+            feats.record_stream(main)
+        kpm = ~cap_atts.bool()
+        after_image, after_caption, ori_caption = self._interaction(ori_image, cap_hidden, kpm)
+
+        loss_cv = self._cv_loss(ori_caption, ori_image, idx) * self.weight_cv_loss
+        loss_reg_c = ops.CapRegFn.apply(ori_caption)
+
+        image_feat = self.get_features(after_image, None)
         text_feat_s, text_feat_t = feats[:b], feats[b:]
 
         loss_itc_vs = self.get_contrastive_loss(image_feat, text_feat_s, idx=idx, tval=tval)

@@ -67,14 +67,37 @@ def lin_dx(dy2, w, **kw):
 # partial round of tiles (6-7 % of a 1731-tile launch) - the other stream's workgroups fill those CUs.  Measured on the batch-256
 # step: 155.0 -> 150.8 ms.  LECCR_DW_STREAM=0 keeps everything on one stream.
 wgrad_overlap = os.environ.get('LECCR_DW_STREAM', '1') != '0'
+# The text towers (caption BERT forward, text BERT forward + backward: small-M GEMMs that leave CUs idle) run on a third stream
+# beside the image tower (150.8 -> 148.7 ms on the batch-256 step).  LECCR_TEXT_STREAM=0 keeps them on the main stream.
+text_overlap = os.environ.get('LECCR_TEXT_STREAM', '1') != '0'
 _wgrad_stream = None
+_text_stream = None
 _wgrad_join_queued = False
 
 
-def join_wgrad_stream():
-    """The current stream waits for every weight-gradient launch issued so far (before the gradients are read)."""
-    if _wgrad_stream is not None:
-        torch.cuda.current_stream().wait_stream(_wgrad_stream)
+def text_stream(device):
+    """The stream the text towers run on (None: on the current stream)."""
+    global _text_stream
+    if not (text_overlap and torch.device(device).type == 'cuda'):
+        return None
+    if _text_stream is None:
+        _text_stream = torch.cuda.Stream(device=device)
+    return _text_stream
+
+
+def side_streams():
+    return [s for s in (_wgrad_stream, _text_stream) if s is not None]
+
+
+def join_wgrad_stream(stream=None):
+    """`stream` (default: the current one) waits for everything issued so far on the side streams (weight-gradient launches,
+    text-tower backward) - before the gradients are read."""
+    streams = side_streams()
+    if not streams:
+        return
+    cur = stream if stream is not None else torch.cuda.current_stream()
+    for s in streams:
+        cur.wait_stream(s)
 
 
 def lin_dw(dy2, x2, w, b=None, scale=1.0):
@@ -94,10 +117,10 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0):
     if not _wgrad_join_queued:
         # once per backward pass: when the autograd engine has run every node, the main stream waits for the side stream,
         # so whatever follows backward() (optimizer, gradient all-reduce, a test reading .grad) sees complete gradients
-        def _join():
+        def _join():                            # (final callbacks run on the stream that called backward())
             global _wgrad_join_queued
             _wgrad_join_queued = False
-            main.wait_stream(side)
+            join_wgrad_stream()
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join)
             _wgrad_join_queued = True

@@ -44,9 +44,24 @@ def attach_grad_sync(optimizer):
         for o in range(lo, hi, _BUCKET):
             pending.append(dist.all_reduce(grad[o:min(o + _BUCKET, hi)], async_op=True))
 
+    reduce_stream = []
+
     def early():
-        if not pending:                       # once per step
-            ops.join_wgrad_stream()           # the early region's weight gradients were accumulated on the side stream
+        if pending:                           # once per step
+            return
+        if grad.is_cuda and ops.side_streams():
+            # The early region's gradients come from three streams (main: interaction / heads, text stream: BERT backward,
+            # weight-gradient stream: their dW launches) - all of that is enqueued by now (autograd runs the younger text-tower
+            # nodes before the first ViT node).  A stream of its own waits for the three and hands the all-reduces to RCCL, so
+            # the main stream goes straight on with the ViT backward.
+            if not reduce_stream:
+                reduce_stream.append(torch.cuda.Stream(device=grad.device))
+            rs = reduce_stream[0]
+            rs.wait_stream(torch.cuda.current_stream())
+            ops.join_wgrad_stream(rs)
+            with torch.cuda.stream(rs):
+                reduce_range(0, split)
+        else:
             reduce_range(0, split)
 
     def sync():

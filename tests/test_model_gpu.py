@@ -164,17 +164,18 @@ def test_production_kernels_vs_oracle(dtype):
     assert not bad, bad[:8]
 
 
-def test_weight_gradient_side_stream_gives_the_same_gradients():
-    """ops.lin_dw on the second stream (default) vs everything on one stream: same arena gradients (f32 path: the split-K
-    atomics are the only order-dependent sums), read straight after backward() with no device-wide synchronise - the join
-    queued on the autograd engine orders the main stream behind the side stream."""
+def test_side_streams_give_the_same_gradients():
+    """Weight-gradient launches on the second stream and the text towers on the third (defaults) vs everything on one stream:
+    same arena gradients (f32 path: the split-K atomics are the only order-dependent sums), read straight after backward()
+    with no device-wide synchronise - the join queued on the autograd engine orders the main stream behind the side streams."""
     from leccr_amd import ops
     model = build(dict(clip_geometry=MID_VIT, text_config=MID_BERT, compute_dtype='fp32', embed_dim=256,
                        clip_text_tower=False), seed=3)
     batch = _mid_batch()
+    model._ensure_runtime()
 
     def grads(overlap):
-        prev, ops.wgrad_overlap = ops.wgrad_overlap, overlap
+        prev, ops.wgrad_overlap, ops.text_overlap = (ops.wgrad_overlap, ops.text_overlap), overlap, overlap
         try:
             model.arena.zero_grad()
             losses = model(batch['image'].to(DEV), [Enc(batch['ids_s'].to(DEV), batch['mask_s'].to(DEV)),
@@ -183,9 +184,9 @@ def test_weight_gradient_side_stream_gives_the_same_gradients():
             sum(losses).backward()
             return model.arena.grad.clone()            # main-stream copy right behind backward()
         finally:
-            ops.wgrad_overlap = prev
+            ops.wgrad_overlap, ops.text_overlap = prev
     g_side, g_one = grads(True), grads(False)
-    assert ops._wgrad_stream is not None               # the side stream was really used
+    assert ops._wgrad_stream is not None and ops._text_stream is not None          # the side streams were really used
     err = float((g_side - g_one).abs().max())
     assert err <= 1e-5 * float(g_one.abs().max()), err
 
