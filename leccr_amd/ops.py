@@ -297,14 +297,14 @@ class ViTBlockFn(torch.autograd.Function):
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
-        # c_fc's bias gradient = column sums of dpre: accumulated by the GEMM epilogue that writes dpre
-        dpre = lin_dx(g2, blk.mlp.c_proj.weight, epilogue=EPI_DQUICKGELU, aux=pre, colsum=blk.mlp.c_fc.bias._g.reshape(-1))
+        dpre = lin_dx(g2, blk.mlp.c_proj.weight, epilogue=EPI_DQUICKGELU, aux=pre)
         # bias gradients of c_proj / out_proj = column sums of dx2 / dx1: those tensors are the `dres` operands of the two
         # LayerNorm backward launches, which accumulate the sums on their way (no separate colsum pass)
         lin_dw(g2, act, blk.mlp.c_proj.weight, None)
         dh2 = lin_dx(dpre, blk.mlp.c_fc.weight)
-        lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, None)
-        _mark(blk.mlp.c_fc.bias)
+        # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
+        # where it runs beside the (MFMA-bound) dX chain instead of in front of it
+        lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
         dx1 = K.layernorm_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g,
                               blk.ln_2.bias._g, dres=dx2, colsum=blk.mlp.c_proj.bias._g.reshape(-1), colsum_of=1)
         _mark(blk.mlp.c_proj.bias)
@@ -433,12 +433,10 @@ class BertLayerFn(torch.autograd.Function):
                               out.LayerNorm.bias._g)
         g2 = _rows(ds2)                                   # gradient of the sum: the residual path takes it as is
         gd2 = K.dropout(g2, ph, seeds[2]) if ph > 0 else g2   # the dense path takes it through the dropout mask
-        dpre = lin_dx(gd2, out.dense.weight, epilogue=EPI_DGELU, aux=pre,
-                      colsum=layer.intermediate.dense.bias._g.reshape(-1))        # fused bias gradient of intermediate.dense
+        dpre = lin_dx(gd2, out.dense.weight, epilogue=EPI_DGELU, aux=pre)
         lin_dw(gd2, h, out.dense.weight, out.dense.bias)
         dx1 = lin_dx(dpre, layer.intermediate.dense.weight, residual=g2)          # + residual path of s2 = .. + x1
-        lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, None)
-        _mark(layer.intermediate.dense.bias)
+        lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
         ds1 = K.layernorm_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                               ao.LayerNorm.bias._g)
         g1 = _rows(ds1)
