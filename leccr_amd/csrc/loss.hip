@@ -101,10 +101,13 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
                                                       const int64_t* __restrict__ idx, float inv_temp, int G, int D,
                                                       const float* __restrict__ ws, float w_r, float w_c,
                                                       float* __restrict__ da, float* __restrict__ db,
-                                                      float* __restrict__ dtemp, int row0, int row_end) {
+                                                      float* __restrict__ dtemp, int row0, int row_end, int slice) {
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int side = blockIdx.y;
+    // blockIdx.z: a slice of the other operand's rows j (gridDim.z > 1: the slices add into zeroed output rows, so that a shard
+    // of 256 rows against G = 2048 is 1024 workgroups instead of 128 walking all of G)
+    const int j_beg = blockIdx.z * slice, j_end = min(G, j_beg + slice);
     const int i_raw = row0 + blockIdx.x * 4 + wave;   // only rows [row0, row_end) get their gradient (the caller's shard)
     const int i = i_raw < row_end ? i_raw : row_end - 1;          // no early exit: the block synchronises on the staged tiles
     const float* A = side == 0 ? a : b;
@@ -129,13 +132,13 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
     float dt = 0.f;
-    for (int j0 = 0; j0 < G; j0 += 64) {
+    for (int j0 = j_beg; j0 < j_end; j0 += 64) {
         __syncthreads();
         stage_rows64(B, j0, G, D, tile);
         __syncthreads();
         const int j = j0 + lane;
         float g = 0.f;
-        if (j < G) {
+        if (j < j_end) {
             const float s = dot_lds_lds(ar, tile + lane * ldt, D) * inv_temp;
             const float lab = (idx ? (idx[j] == my) : (j == i)) ? 1.f / cnt : 0.f;
             if (w_mine != 0.f) g += w_mine * (__expf(s - li) - lab);
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
         }
         gbuf[lane] = g;
         __syncthreads();
-        const int jn = G - j0 < 64 ? G - j0 : 64;
+        const int jn = j_end - j0 < 64 ? j_end - j0 : 64;
         for (int jj = 0; jj < jn; ++jj) {
             const float gj = gbuf[jj];
             const float* br = tile + jj * ldt;
@@ -159,7 +162,10 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
         const int d = lane + 64 * q;
-        if (d < D) out[(int64_t)i * D + d] = acc[q] * inv_temp;
+        if (d < D) {
+            if (gridDim.z > 1) atomicAdd(out + (int64_t)i * D + d, acc[q] * inv_temp);
+            else out[(int64_t)i * D + d] = acc[q] * inv_temp;
+        }
     }
     if (side == 0 && dtemp) {
         dt = wave_sum(dt);
@@ -400,32 +406,46 @@ __global__ __launch_bounds__(256) void dstl_kl_kernel(const float* __restrict__ 
 }
 
 // g_ij = gs/G (softmax(tv)_ij - lab_ij);  side 0: dt_i = sum_j g_ij v_j ; side 1: dv_j = sum_i g_ij t_i
+// One wave = one output row r (of the caller's shard), one side, one slice of the reduction index o.  Per 64 o's the lanes
+// compute the 64 coefficients g in parallel (one exp per lane instead of the same exp in all 64), then the wave walks the 64
+// operand rows with the coefficient broadcast from its lane; slices meet by atomicAdd into the zeroed output rows.
+// (One wave walking all G o's serially with a redundant exp per lane took 2.6 ms at G = 2048 for 256 rows.)
 __global__ __launch_bounds__(256) void dstl_bwd_kernel(const float* __restrict__ v, const float* __restrict__ t, int G,
                                                        int D, const float* __restrict__ tv,
                                                        const float* __restrict__ lab, const float* __restrict__ lse_tv,
                                                        float w, float* __restrict__ dv, float* __restrict__ dt,
-                                                       int row0, int row_end) {
+                                                       int row0, int row_end, int slice) {
     const int lane = threadIdx.x & 63;
     const int side = blockIdx.y;
     const int r = row0 + blockIdx.x * 4 + (threadIdx.x >> 6);      // only the caller's shard of rows
     if (r >= row_end) return;
+    const int o_beg = blockIdx.z * slice, o_end = min(G, o_beg + slice);
+    const float* src = side == 0 ? v : t;
+    const float lse_r = lse_tv[side == 0 ? r : 0];                 // side 0: the row's own lse; side 1: per o below
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int o = 0; o < G; ++o) {
-        const int i = side == 0 ? r : o, j = side == 0 ? o : r;
-        const int64_t off = (int64_t)i * G + j;
-        const float g = w * (__expf(tv[off] - lse_tv[i]) - lab[off]);
-        const float* src = side == 0 ? v + (int64_t)j * D : t + (int64_t)i * D;
+    for (int o0 = o_beg; o0 < o_end; o0 += 64) {
+        const int o = o0 + lane;
+        float g = 0.f;
+        if (o < o_end) {
+            const int64_t off = side == 0 ? (int64_t)r * G + o : (int64_t)o * G + r;
+            g = w * (__expf(tv[off] - (side == 0 ? lse_r : lse_tv[o])) - lab[off]);
+        }
+        const int cnt = min(64, o_end - o0);
+        for (int u = 0; u < cnt; ++u) {
+            const float gu = __shfl(g, u);
+            const float* row = src + (int64_t)(o0 + u) * D;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int d = lane + 64 * u;
-            if (d < D) acc[u] = fmaf(g, src[d], acc[u]);
+            for (int k = 0; k < 8; ++k) {
+                const int d = lane + 64 * k;
+                if (d < D) acc[k] = fmaf(gu, row[d], acc[k]);
+            }
         }
     }
-    float* out = side == 0 ? dt : dv;
+    float* out = (side == 0 ? dt : dv) + (int64_t)r * D;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int d = lane + 64 * u;
-        if (d < D) out[(int64_t)r * D + d] = acc[u];
+    for (int k = 0; k < 8; ++k) {
+        const int d = lane + 64 * k;
+        if (d < D) atomicAdd(out + d, acc[k]);
     }
 }
 
@@ -573,8 +593,17 @@ extern "C" int leccr_sim_infonce_bwd(const float* a, const float* b, const int64
     const float w_r = gscale * (both_dirs ? 0.5f / G : 1.f / G), w_c = both_dirs ? w_r : 0.f;
     const size_t lds_b = (size_t)(4 * (D + 64) + 64 * (D + 4)) * sizeof(float);
     (void)hipFuncSetAttribute((const void*)sim_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(nrows, 4), 2), dim3(256), lds_b, st, a, b, idx,
-                       1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp, (int)row0, (int)(row0 + nrows));
+    // slices of the reduction index so that the launch has >= ~512 workgroups (slice = multiple of the 64-row staging tile)
+    int nslice = (int)cdiv(512, 2 * cdiv(nrows, 4));
+    if (nslice > cdiv(G, 256)) nslice = (int)cdiv(G, 256);
+    if (nslice < 1) nslice = 1;
+    const int slice = (int)(cdiv(cdiv(G, nslice), 64) * 64);
+    nslice = (int)cdiv(G, slice);
+    if (nslice > 1 && (hipMemsetAsync(da + row0 * D, 0, sizeof(float) * nrows * D, st) != hipSuccess ||
+                       hipMemsetAsync(db + row0 * D, 0, sizeof(float) * nrows * D, st) != hipSuccess))
+        return check_launch("sim_infonce_bwd memset");
+    hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(nrows, 4), 2, (unsigned)nslice), dim3(256), lds_b, st, a, b, idx,
+                       1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp, (int)row0, (int)(row0 + nrows), slice);
     return check_launch("sim_infonce_bwd");
 }
 
@@ -635,8 +664,17 @@ extern "C" int leccr_dstl_bwd(const float* v, const float* t, int64_t G, int64_t
     const float* tv = ws;
     const float* lab = ws + G * G;
     const float* lse_tv = ws + 3 * G * G + 4;
-    hipLaunchKernelGGL(dstl_bwd_kernel, dim3((unsigned)cdiv(nrows, 4), 2), dim3(256), 0, st, v, t, (int)G, (int)D, tv, lab, lse_tv,
-                       gscale / G, dv, dt, (int)row0, (int)(row0 + nrows));
+    // the reduction over G is cut into slices so that the launch has >= ~2048 waves; the slices add into zeroed rows
+    int nslice = (int)cdiv(2048, 2 * nrows);
+    if (nslice > cdiv(G, 64)) nslice = (int)cdiv(G, 64);
+    if (nslice < 1) nslice = 1;
+    const int slice = (int)(cdiv(cdiv(G, nslice), 64) * 64);
+    nslice = (int)cdiv(G, slice);
+    if (hipMemsetAsync(dv + row0 * D, 0, sizeof(float) * nrows * D, st) != hipSuccess ||
+        hipMemsetAsync(dt + row0 * D, 0, sizeof(float) * nrows * D, st) != hipSuccess)
+        return check_launch("dstl_bwd memset");
+    hipLaunchKernelGGL(dstl_bwd_kernel, dim3((unsigned)cdiv(nrows, 4), 2, (unsigned)nslice), dim3(256), 0, st, v, t, (int)G, (int)D,
+                       tv, lab, lse_tv, gscale / G, dv, dt, (int)row0, (int)(row0 + nrows), slice);
     return check_launch("dstl_bwd");
 }
 

@@ -38,6 +38,7 @@ def _next_seed():
 
 # called when the ViT backward begins (= every other parameter gradient of the step is final); set by parallel.py
 on_late_backward_start = None
+on_vit_block_backward = None         # leccr_amd.parallel: called with the block at the start of each ViT block's backward
 
 
 def _p(module, attr):
@@ -294,6 +295,8 @@ class ViTBlockFn(torch.autograd.Function):
     def backward(ctx, dx2):
         x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act = ctx.saved_tensors
         blk = ctx.blk
+        if on_vit_block_backward is not None:
+            on_vit_block_backward(blk)
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)

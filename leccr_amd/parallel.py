@@ -29,9 +29,10 @@ def init_distributed_mode(backend=None):
 def attach_grad_sync(optimizer):
     """Make optimizer.step() average the arena's gradients over ranks first (DDP semantics).
 
-    Two phases: the arena's early region (text tower, heads, interaction: ~70 % of the bytes) is all-reduced as soon as
+    Phases: the arena's early region (text tower, heads, interaction: ~70 % of the bytes) is all-reduced as soon as
     the ViT backward starts (ops.on_late_backward_start fires in the first ViT backward node, when every other gradient
-    is final) and overlaps it on RCCL's stream; the ViT region follows at optimizer.step()."""
+    is final) and overlaps it on RCCL's stream; the ViT region follows in thirds as the block backwards complete
+    (ops.on_vit_block_backward), the last third at optimizer.step()."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return optimizer
     from . import ops
@@ -45,35 +46,49 @@ def attach_grad_sync(optimizer):
             pending.append(dist.all_reduce(grad[o:min(o + _BUCKET, hi)], async_op=True))
 
     reduce_stream = []
+    late = {'hi': grad.numel()}               # [late['hi'], numel) of the ViT region is already handed to RCCL
 
-    def early():
-        if pending:                           # once per step
-            return
-        if grad.is_cuda and ops.side_streams():
-            # The early region's gradients come from three streams (main: interaction / heads, text stream: BERT backward,
-            # weight-gradient stream: their dW launches) - all of that is enqueued by now (autograd runs the younger text-tower
-            # nodes before the first ViT node).  A stream of its own waits for the three and hands the all-reduces to RCCL, so
-            # the main stream goes straight on with the ViT backward.
+    def reduce_async(lo, hi):
+        """All launches that write grad[lo:hi] are enqueued (on the main, text and weight-gradient streams): a stream of its own
+        waits for the three and hands the all-reduces to RCCL, so the main stream goes straight on with the backward pass."""
+        if grad.is_cuda:
             if not reduce_stream:
                 reduce_stream.append(torch.cuda.Stream(device=grad.device))
             rs = reduce_stream[0]
             rs.wait_stream(torch.cuda.current_stream())
             ops.join_wgrad_stream(rs)
             with torch.cuda.stream(rs):
-                reduce_range(0, split)
+                reduce_range(lo, hi)
         else:
-            reduce_range(0, split)
+            reduce_range(lo, hi)
+
+    def early():
+        # first ViT backward node: autograd has run the younger text-tower / interaction nodes, the early region is final
+        if not pending:                       # once per step
+            reduce_async(0, split)
+
+    def vit_block(blk):
+        # start of a ViT block's backward: the blocks behind it in the arena (and ln_post / proj) are final.  Their share of
+        # the ViT region goes out as soon as it is a third of the region, so only the first blocks' gradients are left for
+        # optimizer.step() (unbucketed, the ViT region's 344 MB all-reduce sat exposed between backward and AdamW).
+        end = max(arena.offsets[p._aidx] + p.numel() for p in blk.parameters())
+        end = min((end + 63) // 64 * 64, late['hi'])
+        if late['hi'] - end >= (grad.numel() - split) // 3:
+            reduce_async(end, late['hi'])
+            late['hi'] = end
 
     def sync():
         ops.join_wgrad_stream()
         if not pending:                       # no ViT backward ran (e.g. a text-only step): reduce everything now
             reduce_range(0, split)
-        reduce_range(split, grad.numel())
+        reduce_range(split, late['hi'])
+        late['hi'] = grad.numel()
         for w in pending:
             w.wait()
         pending.clear()
 
     ops.on_late_backward_start = early if split < grad.numel() else None
+    ops.on_vit_block_backward = vit_block if split < grad.numel() else None
     optimizer.grad_sync = sync
     optimizer.grad_scale = 1.0 / world
     return optimizer

@@ -319,7 +319,9 @@ def test_sim_infonce(K, G, D, use_idx, both):
         for r0, r1 in zip(cuts[:-1], cuts[1:]):
             dts = torch.zeros(1, device=DEV)
             das, dbs = K.sim_infonce_bwd(a.to(DEV), b.to(DEV), ia, temp, ws, 1.7, both, dts, rows=(r0, r1 - r0))
-            assert torch.equal(das[r0:r1], da[r0:r1]) and torch.equal(dbs[r0:r1], db[r0:r1])
+            # same rows, possibly another number of reduction slices (f32 atomics): equal to summation-order noise
+            for got_, full_ in ((das, da), (dbs, db)):
+                assert float((got_[r0:r1] - full_[r0:r1]).abs().max()) <= 2e-6 * float(full_.abs().max())
             assert float(das[:r0].abs().sum() + das[r1:].abs().sum() + dbs[:r0].abs().sum() + dbs[r1:].abs().sum()) == 0
             dt_sum += float(dts)
         assert abs(dt_sum - float(dtemp)) <= 1e-4 * abs(float(dtemp)) + 1e-6
@@ -361,7 +363,8 @@ def test_dstl(K, G, n, D):
         assert e <= 2e-4 * sc + 1e-8, (name, e, sc)
     r0, nr = G // 4, G // 2
     dvs, dts = K.dstl_bwd(v.to(DEV), t.to(DEV), ws, 0.3, rows=(r0, nr))
-    assert torch.equal(dvs[r0:r0 + nr], dv[r0:r0 + nr]) and torch.equal(dts[r0:r0 + nr], dt[r0:r0 + nr])
+    for got_, full_ in ((dvs, dv), (dts, dt)):      # another number of reduction slices: summation-order noise only
+        assert float((got_[r0:r0 + nr] - full_[r0:r0 + nr]).abs().max()) <= 2e-6 * float(full_.abs().max())
     assert float(dvs[:r0].abs().sum() + dvs[r0 + nr:].abs().sum() + dts[:r0].abs().sum() + dts[r0 + nr:].abs().sum()) == 0
 
 
