@@ -5,7 +5,7 @@ import torch.nn as nn
 from .. import ops
 from .attention import CrossAttention
 from .layers import Linear
-from .xvlm import XVLMBase, _dist_info, gather_rows, local_rows
+from .xvlm import XVLMBase, _dist_info, begin_step_gathers, gather_rows, gather_rows_packed, local_rows
 
 
 class RetrievalModel(XVLMBase):
@@ -65,9 +65,14 @@ class RetrievalModel(XVLMBase):
         sim[i,j] = <mean_c chat_i, mean_v vhat_j> with chat/vhat normalised over the TOKEN axis (F.normalize's default
         dim=1).  Project + normalise + pool locally, all-gather 2 x [b, vw] instead of the token tensors.  cproj/vproj sit
         after the gather in the reference, so under DDP their gradients are the FULL dL/dtheta: wgrad_scale = W."""
+        return self._cv_loss_pooled(*self._cv_pooled(ori_caption, ori_image), idx)
+
+    def _cv_pooled(self, ori_caption, ori_image):
         _, world = _dist_info()
-        pc = ops.CvPoolFn.apply(self.cproj(ori_caption, wgrad_scale=float(world)))
-        pv = ops.CvPoolFn.apply(self.vproj(ori_image, wgrad_scale=float(world)))
+        return (ops.CvPoolFn.apply(self.cproj(ori_caption, wgrad_scale=float(world))),
+                ops.CvPoolFn.apply(self.vproj(ori_image, wgrad_scale=float(world))))
+
+    def _cv_loss_pooled(self, pc, pv, idx):
         idx_all = gather_rows(idx.view(-1, 1)).view(-1).contiguous()
         return ops.SimInfoNCEFn.apply(gather_rows(pc), gather_rows(pv), None, idx_all, False, 1.0, local_rows(pc.size(0)))
 
@@ -101,6 +106,7 @@ class RetrievalModel(XVLMBase):
         """model_retrieval_caption.py:154-199 -> (loss_itc_vs + loss_cv, loss_itc_vt', loss_itc_st, w_c loss_itc_c,
         w_r loss_reg_c).  Same five scalars; internally batch-major, src+tgt text in one BERT pass."""
         self._ensure_runtime()
+        begin_step_gathers()
         if self.training:          # fresh dropout masks per step and per rank (the reference seeds with seed + rank)
             self._step_count = getattr(self, '_step_count', 0) + 1
             rank, _ = _dist_info()
@@ -138,21 +144,24 @@ class RetrievalModel(XVLMBase):
         kpm = ~cap_atts.bool()
         after_image, after_caption, ori_caption = self._interaction(ori_image, cap_hidden, kpm)
 
-        loss_cv = self._cv_loss(ori_caption, ori_image, idx) * self.weight_cv_loss
+        pc, pv = self._cv_pooled(ori_caption, ori_image)
         loss_reg_c = ops.CapRegFn.apply(ori_caption)
 
         image_feat = self.get_features(after_image, None)
         text_feat_s, text_feat_t = feats[:b], feats[b:]
+        cq = self.caption_proj1(after_caption, out_f32=True).contiguous()   # [b, n, D] f32
+        # every block the loss terms gather (W > 1), in one collective instead of sixteen
+        gather_rows_packed([image_feat, text_feat_s, text_feat_t, cq, pc, pv], None if idx is None else idx.view(-1, 1))
+        loss_cv = self._cv_loss_pooled(pc, pv, idx) * self.weight_cv_loss
 
         loss_itc_vs = self.get_contrastive_loss(image_feat, text_feat_s, idx=idx, tval=tval)
         loss_itc_vt = self.get_contrastive_loss(image_feat, text_feat_t, idx=idx, tval=tval)
         loss_itc_st = self.get_contrastive_loss(text_feat_s, text_feat_t, idx=idx, tval=tval)
 
-        cq = self.caption_proj1(after_caption, out_f32=True)                # [b, n, D] f32
         loss_itc_c = ops.CapSimFn.apply(cq, text_feat_s, self.temp, tval) + \
             ops.CapSimFn.apply(cq, text_feat_t, self.temp, tval)
 
-        loss_dstl = ops.DstlFn.apply(gather_rows(image_feat), gather_rows(cq.contiguous()), gather_rows(text_feat_s),
+        loss_dstl = ops.DstlFn.apply(gather_rows(image_feat), gather_rows(cq), gather_rows(text_feat_s),
                                      gather_rows(text_feat_t), 0.8, local_rows(image_feat.size(0))) * self.weight_dstl_loss
         loss_itc_vt = loss_itc_vt * (1 - self.weight_dstl_loss) + loss_dstl
         return (loss_itc_vs + loss_cv, loss_itc_vt, loss_itc_st, loss_itc_c * self.weight_caption_loss,

@@ -10,7 +10,7 @@ import torch
 from .. import ops
 from .attention import SelfAttention
 from .model_retrieval_caption import RetrievalModel as _ImageRetrievalModel
-from .xvlm import _dist_info, gather_rows, local_rows
+from .xvlm import _dist_info, begin_step_gathers, gather_rows, local_rows
 
 
 class RetrievalModel(_ImageRetrievalModel):
@@ -64,6 +64,7 @@ class RetrievalModel(_ImageRetrievalModel):
     def forward(self, video, video_mask, text_ls, captions=None, idx=None, epoch=None, cap_idx=None):
         """video_model_retrieval_caption.py:180-227 -> the same five scalars as the image model."""
         self._ensure_runtime()
+        begin_step_gathers()
         if self.training:
             self._step_count = getattr(self, '_step_count', 0) + 1
             rank, _ = _dist_info()

@@ -47,9 +47,78 @@ def _dist_info():
     return 0, 1
 
 
+class AllGatherPacked(torch.autograd.Function):
+    """Several f32 row blocks [b, ...] in ONE all-gather (their flat concatenation), same backward as AllGather for each."""
+
+    @staticmethod
+    def forward(ctx, rank, world_size, *tensors):
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        out = torch.empty(world_size, flat.numel(), device=flat.device, dtype=flat.dtype)
+        if dist.get_backend() == 'nccl':
+            dist.all_gather_into_tensor(out.view(-1), flat)
+        else:
+            dist.all_gather(list(out.unbind(0)), flat)
+        ctx.rank, ctx.rows = rank, [t.shape[0] for t in tensors]
+        res, off = [], 0
+        for t in tensors:
+            n = t.numel()
+            res.append(out[:, off:off + n].reshape((world_size * t.shape[0],) + tuple(t.shape[1:])))
+            off += n
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        r = ctx.rank
+        return (None, None) + tuple(None if g is None else g[b * r: b * (r + 1)] for g, b in zip(grads, ctx.rows))
+
+
+# One training step gathers the same feature blocks for several loss terms (image_feat for three of them, idx for four):
+# the gathered copy is kept per source tensor for the duration of the step (begin_step_gathers() clears it), and
+# gather_rows_packed() fills it for the whole set with a single collective.
+_gathered = {}
+
+
+def _gkey(t):
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+
+
+def begin_step_gathers():
+    _gathered.clear()
+
+
 def gather_rows(t):
     rank, world = _dist_info()
-    return t if world == 1 else allgather(t, rank, world)
+    if world == 1:
+        return t
+    hit = _gathered.get(_gkey(t))
+    if hit is not None:
+        return hit[1]
+    out = allgather(t, rank, world)
+    _gathered[_gkey(t)] = (t, out)          # the source stays referenced: its address cannot be reused within the step
+    return out
+
+
+def gather_rows_packed(tensors, idx=None):
+    """All-gather the f32 blocks `tensors` (and the int64 column `idx`, bit-cast to two f32 words per row) in one collective
+    and remember the results for gather_rows()."""
+    rank, world = _dist_info()
+    if world == 1:
+        return
+    srcs = [t for t in tensors if _gkey(t) not in _gathered]
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs)
+    packed = list(srcs)
+    if idx is not None and _gkey(idx) not in _gathered:
+        assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 2 and idx.shape[1] == 1
+        packed.append(idx.view(torch.float32))                     # [b, 2] words, copied bit for bit
+    else:
+        idx = None
+    if not packed:
+        return
+    outs = AllGatherPacked.apply(rank, world, *packed)
+    for t, o in zip(srcs, outs):
+        _gathered[_gkey(t)] = (t, o)
+    if idx is not None:
+        _gathered[_gkey(idx)] = (idx, outs[-1].detach().contiguous().view(torch.int64))
 
 
 def local_rows(b):

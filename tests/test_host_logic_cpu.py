@@ -105,6 +105,23 @@ def _gather_worker(rank, world, port, ret):
     ok = torch.equal(g.detach()[3 * rank:3 * rank + 3], x.detach()) and g.shape == (6, 2)
     ok &= torch.equal(x.grad, w[3 * rank:3 * rank + 3])                  # ONLY the local slice (xvlm.py:62-67)
     ok &= gather_rows(torch.tensor([[rank]])).view(-1).tolist() == [0, 1]
+    # several blocks + the int64 idx column in ONE collective; gather_rows() then serves them from the step's cache
+    from leccr_amd.models import xvlm
+    xvlm.begin_step_gathers()
+    p = (torch.arange(4, dtype=torch.float32).view(2, 2) + 100 * rank).requires_grad_(True)
+    q = (torch.arange(6, dtype=torch.float32).view(2, 3) - 7 * rank).requires_grad_(True)
+    ids = torch.tensor([[5 + rank], [2 ** 40 + rank]])                   # int64 bit patterns survive the f32 transport
+    xvlm.gather_rows_packed([p, q], ids)
+    n_cached = len(xvlm._gathered)
+    gp, gq, gi = gather_rows(p), gather_rows(q), gather_rows(ids)
+    ok &= n_cached == 3 and len(xvlm._gathered) == 3                     # no further collective
+    ok &= torch.equal(gp.detach(), torch.cat([torch.arange(4.).view(2, 2), torch.arange(4.).view(2, 2) + 100]))
+    ok &= torch.equal(gq.detach()[2 * rank:2 * rank + 2], q.detach()) and gq.shape == (4, 3)
+    ok &= gi.view(-1).tolist() == [5, 2 ** 40, 6, 2 ** 40 + 1]
+    wq = torch.arange(12, dtype=torch.float32).view(4, 3)
+    ((gp * 2).sum() + (gq * wq).sum()).backward()
+    ok &= torch.equal(p.grad, torch.full((2, 2), 2.0)) and torch.equal(q.grad, wq[2 * rank:2 * rank + 2])
+    xvlm.begin_step_gathers()
 
     class FakeOpt:                                                       # what attach_grad_sync needs
         class arena:
