@@ -165,7 +165,8 @@ int leccr_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void*
 /* ---- similarity + contrastive losses (f32 in, f32 out) ----------------------------------------------------
  * sim_infonce: get_contrastive_loss (models/xvlm.py:260-292).  a,b [G,D] L2-normalised, idx [G] int64 or NULL.
  *   logits = a b^T / temp ; labels = eq(idx,idx^T)/rowsum (or identity) ; loss = (CE_rows + CE_cols)/2.
- *   Never writes the G x G logits: row/column log-sum-exps in `ws` (>= 2*G floats).
+ *   `ws` (>= 2*G + G*G floats): row / column log-sum-exps (the part the backward reads), then a G x G scratch for the
+ *   forward's logits tiles (f32 products on the matrix cores, one direction at a time).
  *   loss: 1 float.  Backward gives da, db [G,D] (full gathered rows; the caller keeps its local slice,
  *   xvlm.py:62-67) and dtemp (1 float), all scaled by `gscale`.
  * capsim: get_caption_contrastive_loss (model_retrieval_caption.py:145-152).  c [b,n,D], t [b,D]:

@@ -1,8 +1,9 @@
 // loss.hip - all-pairs similarity + contrastive / distillation losses of the LECCR step, forward and backward.
-// f32 features in, f32 losses out.  None of the G x G logits matrices of the contrastive losses is written to
-// HBM: a wave owns one row of the similarity matrix, lanes own columns, row statistics are wave-shuffle reductions;
-// the column direction is the same kernel with the operands swapped.  (Reference sequences: include/leccr_hip.h.)
+// f32 features in, f32 losses out.  Forward score matrices are f32 matrix-core tiles (f32_nt_tile_kernel) written to a G x G
+// scratch and reduced per row; the backward kernels recompute their scores from LDS-staged rows (a wave owns one row, lanes own
+// columns) over a slice of the other operand.  (Reference sequences: include/leccr_hip.h.)
 #include "common.h"
+#include <algorithm>
 
 namespace leccr {
 
@@ -44,6 +45,119 @@ __device__ __forceinline__ float dot_lds_lds(const float* __restrict__ a_lds, co
         acc = fmaf(av[3], bv[3], acc);
     }
     return acc;
+}
+
+// ----------------------------------------------------------------------------------------------- f32 score tiles
+// C[M,N] = alpha * A[M,K] . B[N,K]^T in f32 on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32 products at the vector
+// rate, but a 32 x 32 tile of scores costs 64 operand floats per k instead of 2048 LDS reads).  Block = 64 x 64 scores, 4 waves
+// of 32 x 32; both operands' 64 rows are staged for a K chunk of up to 256 (row stride K chunk + 4 floats).  The MFMA's two
+// k slots may hold ANY two k of the chunk as long as A and B agree, so lane (row, half) walks the contiguous half
+// [half * KC/2, (half + 1) * KC/2) of its row with ds_read_b128.  MODE 0: store, 1: C = max(C, .) (max over the caption queries),
+// 2: the same with the index q of the launch that holds the maximum kept in arg (same leading dimension as C).
+// (The all-pairs loss kernels spent 2 LDS reads per FMA: 0.5 ms for one G = 2048 similarity, 1.6 ms for the three of dstl.)
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+constexpr int kScoreKC = 256;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void f32_nt_tile_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                          int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N,
+                                                          int K, float alpha, int32_t* __restrict__ arg, int q) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    constexpr int LD = kScoreKC + 4;
+    float* As = sm;
+    float* Bs = sm + 64 * LD;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += kScoreKC) {
+        const int kc = min(kScoreKC, K - k0), q4 = kc >> 2;          // K % 8 == 0 (launcher)
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * q4; e += 256) {
+            const int r = e / q4, c = (e - r * q4) * 4;
+            const int ra = m0 + r < M ? m0 + r : M - 1, rb = n0 + r < N ? n0 + r : N - 1;
+            *reinterpret_cast<f32x4*>(As + r * LD + c) = *reinterpret_cast<const f32x4*>(A + (int64_t)ra * lda + k0 + c);
+            *reinterpret_cast<f32x4*>(Bs + r * LD + c) = *reinterpret_cast<const f32x4*>(B + (int64_t)rb * ldb + k0 + c);
+        }
+        __syncthreads();
+        const int half = kc >> 1;
+        const float* ap = As + (wr * 32 + (lane & 31)) * LD + (lane >> 5) * half;
+        const float* bp = Bs + (wc * 32 + (lane & 31)) * LD + (lane >> 5) * half;
+        for (int s4 = 0; s4 < half; s4 += 4) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ap + s4), bv = *reinterpret_cast<const f32x4*>(bp + s4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+        }
+    }
+    // acc[i] = C[m0 + 32 wr + 8 (i >> 2) + 4 (lane >> 5) + (i & 3)][n0 + 32 wc + (lane & 31)]
+    const int n = n0 + wc * 32 + (lane & 31);
+    if (n >= N) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int m = m0 + wr * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
+        if (m < M) {
+            float* cp = C + (int64_t)m * ldc + n;
+            const float v = alpha * acc[i];
+            if constexpr (MODE == 2) {               // running max over launches q = 0, 1, ..: the first maximum wins (torch.max)
+                if (q == 0 || v > *cp) {
+                    *cp = v;
+                    arg[(int64_t)m * ldc + n] = q;
+                }
+            } else {
+                *cp = MODE == 1 ? fmaxf(*cp, v) : v;
+            }
+        }
+    }
+}
+
+static int launch_f32_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
+                         int64_t K, float alpha, bool take_max, hipStream_t st, int32_t* arg = nullptr, int q = 0) {
+    const size_t lds = (size_t)2 * 64 * (kScoreKC + 4) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)f32_nt_tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)f32_nt_tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)f32_nt_tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    const dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64));
+    if (arg) hipLaunchKernelGGL(f32_nt_tile_kernel<2>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, arg, q);
+    else if (take_max) hipLaunchKernelGGL(f32_nt_tile_kernel<1>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, arg, q);
+    else hipLaunchKernelGGL(f32_nt_tile_kernel<0>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, arg, q);
+    return check_launch("f32_nt_tile");
+}
+
+// Row statistics of a stored G x G logits matrix with the soft labels of get_contrastive_loss (lab_ij = [idx_i == idx_j] / cnt_i):
+// lse_i, and loss += scale * (lse_i - mean of the matching logits).  One wave per row, coalesced.
+__global__ __launch_bounds__(256) void sim_rowstat_kernel(const float* __restrict__ logits, const int64_t* __restrict__ idx, int G,
+                                                          float* __restrict__ lse_out, float* __restrict__ loss, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= G) return;
+    const float* row = logits + (int64_t)i * G;
+    const int64_t my = idx ? idx[i] : 0;
+    float m = -INFINITY, pos = 0.f, cnt = 0.f;
+    for (int j = lane; j < G; j += 64) {
+        const float s = row[j];
+        m = fmaxf(m, s);
+        if (idx ? (idx[j] == my) : (j == i)) {
+            pos += s;
+            cnt += 1.f;
+        }
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int j = lane; j < G; j += 64) l += __expf(row[j] - m);
+    l = wave_sum(l);
+    pos = wave_sum(pos);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+        const float lse = m + __logf(l);
+        lse_out[i] = lse;
+        atomicAdd(loss, scale * (lse - pos / cnt));
+    }
 }
 
 // ----------------------------------------------------------------------------------------------- sim_infonce
@@ -227,12 +341,14 @@ __device__ __forceinline__ float capsim_g(const float* logits, const float* lse_
     return w * ((__expf(s - lse_r[i]) - dl) + (__expf(s - lse_c[j]) - dl));
 }
 
-// side 0: wave per i -> dc[i, n, :] ; side 1: wave per j -> dt[j, :].   D <= 512, n <= 8
+// side 0: wave per i -> dc[i, n, :] ; side 1: wave per j -> dt[j, :].   D <= 512, n <= 8.
+// blockIdx.z: a slice of the other index; per 64 of them the lanes compute the coefficients g (and fetch the arg-max query) in
+// parallel, then the wave walks the 64 operand rows with g broadcast from its lane; slices add into the zeroed outputs.
 __global__ __launch_bounds__(256) void capsim_bwd_kernel(const float* __restrict__ c, const float* __restrict__ t,
                                                          float inv_temp, int b, int n, int D,
                                                          const int32_t* __restrict__ argmax,
                                                          const float* __restrict__ ws, float w, float* __restrict__ dc,
-                                                         float* __restrict__ dt, float* __restrict__ dtemp) {
+                                                         float* __restrict__ dt, float* __restrict__ dtemp, int slice) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int side = blockIdx.y;
     const int r = blockIdx.x * 4 + wave;
@@ -240,43 +356,78 @@ __global__ __launch_bounds__(256) void capsim_bwd_kernel(const float* __restrict
     const float* logits = ws;
     const float* lse_r = ws + (int64_t)b * b;
     const float* lse_c = lse_r + b;
+    const int o_beg = blockIdx.z * slice, o_end = min(b, o_beg + slice);
     if (side == 0) {
-        for (int q = 0; q < n; ++q) {  // one pass per query keeps the accumulators in registers
-            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int j = 0; j < b; ++j) {
-                if (argmax[(int64_t)r * b + j] != q) continue;  // wave-uniform
-                const float g = capsim_g(logits, lse_r, lse_c, b, r, j, w);
+        float acc[8][8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int d = lane + 64 * u;
-                    if (d < D) acc[u] = fmaf(g, t[(int64_t)j * D + d], acc[u]);
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[q][u] = 0.f;
+        float dtl = 0.f;
+        for (int j0 = o_beg; j0 < o_end; j0 += 64) {
+            const int j = j0 + lane;
+            float g = 0.f;
+            int am = 0;
+            if (j < o_end) {
+                g = capsim_g(logits, lse_r, lse_c, b, r, j, w);
+                am = argmax[(int64_t)r * b + j];
+                dtl -= g * logits[(int64_t)r * b + j];
+            }
+            const int cnt = min(64, o_end - j0);
+            for (int u = 0; u < cnt; ++u) {
+                const float gu = __shfl(g, u);
+                const int qu = __builtin_amdgcn_readlane(am, u);          // wave-uniform query index
+                const float* row = t + (int64_t)(j0 + u) * D;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (q == qu) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int d = lane + 64 * k;
+                            if (d < D) acc[q][k] = fmaf(gu, row[d], acc[q][k]);
+                        }
+                    }
                 }
             }
+        }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int d = lane + 64 * u;
-                if (d < D) dc[((int64_t)r * n + q) * D + d] = acc[u] * inv_temp;
+        for (int q = 0; q < 8; ++q) {
+            if (q < n) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int d = lane + 64 * k;
+                    if (d < D) atomicAdd(dc + ((int64_t)r * n + q) * D + d, acc[q][k] * inv_temp);
+                }
             }
         }
-        float dtl = 0.f;
-        for (int j = lane; j < b; j += 64) dtl -= capsim_g(logits, lse_r, lse_c, b, r, j, w) * logits[(int64_t)r * b + j];
         dtl = wave_sum(dtl);
         if (lane == 0 && dtemp) atomicAdd(dtemp, dtl * inv_temp);
     } else {
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int i = 0; i < b; ++i) {
-            const float g = capsim_g(logits, lse_r, lse_c, b, i, r, w);
-            const float* cr = c + ((int64_t)i * n + argmax[(int64_t)i * b + r]) * D;
+        for (int i0 = o_beg; i0 < o_end; i0 += 64) {
+            const int i = i0 + lane;
+            float g = 0.f;
+            int am = 0;
+            if (i < o_end) {
+                g = capsim_g(logits, lse_r, lse_c, b, i, r, w);
+                am = argmax[(int64_t)i * b + r];
+            }
+            const int cnt = min(64, o_end - i0);
+            for (int u = 0; u < cnt; ++u) {
+                const float gu = __shfl(g, u);
+                const int qu = __builtin_amdgcn_readlane(am, u);
+                const float* row = c + ((int64_t)(i0 + u) * n + qu) * D;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int d = lane + 64 * u;
-                if (d < D) acc[u] = fmaf(g, cr[d], acc[u]);
+                for (int k = 0; k < 8; ++k) {
+                    const int d = lane + 64 * k;
+                    if (d < D) acc[k] = fmaf(gu, row[d], acc[k]);
+                }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int d = lane + 64 * u;
-            if (d < D) dt[(int64_t)r * D + d] = acc[u] * inv_temp;
+        for (int k = 0; k < 8; ++k) {
+            const int d = lane + 64 * k;
+            if (d < D) atomicAdd(dt + (int64_t)r * D + d, acc[k] * inv_temp);
         }
     }
 }
@@ -294,6 +445,35 @@ __global__ void dstl_init_kernel(int* mm) {
     mm[1] = f2ord(-INFINITY);  // max sv
     mm[2] = f2ord(INFINITY);   // min sc
     mm[3] = f2ord(-INFINITY);  // max sc
+}
+
+// global min / max of the two stored score matrices (norm_score's ranges), grid-stride
+__global__ __launch_bounds__(256) void dstl_minmax_kernel(const float* __restrict__ sv, const float* __restrict__ sc, int64_t n,
+                                                          int* __restrict__ mm) {
+    float mn_sv = INFINITY, mx_sv = -INFINITY, mn_sc = INFINITY, mx_sc = -INFINITY;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float a = sv[e], b = sc[e];
+        mn_sv = fminf(mn_sv, a);
+        mx_sv = fmaxf(mx_sv, a);
+        mn_sc = fminf(mn_sc, b);
+        mx_sc = fmaxf(mx_sc, b);
+    }
+    __shared__ float red[4][4];
+    mn_sv = wave_min(mn_sv);
+    mx_sv = wave_max(mx_sv);
+    mn_sc = wave_min(mn_sc);
+    mx_sc = wave_max(mx_sc);
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        red[0][wv] = mn_sv; red[1][wv] = mx_sv; red[2][wv] = mn_sc; red[3][wv] = mx_sc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                      // one set of atomics per workgroup (4 addresses)
+        atomicMin(mm + 0, f2ord(fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]))));
+        atomicMax(mm + 1, f2ord(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]))));
+        atomicMin(mm + 2, f2ord(fminf(fminf(red[2][0], red[2][1]), fminf(red[2][2], red[2][3]))));
+        atomicMax(mm + 3, f2ord(fmaxf(fmaxf(red[3][0], red[3][1]), fmaxf(red[3][2], red[3][3]))));
+    }
 }
 
 template <bool STAGED>
@@ -431,13 +611,26 @@ __global__ __launch_bounds__(256) void dstl_bwd_kernel(const float* __restrict__
             g = w * (__expf(tv[off] - (side == 0 ? lse_r : lse_tv[o])) - lab[off]);
         }
         const int cnt = min(64, o_end - o0);
-        for (int u = 0; u < cnt; ++u) {
-            const float gu = __shfl(g, u);
-            const float* row = src + (int64_t)(o0 + u) * D;
+        // 8 operand rows per step: their loads are independent and in flight together (one row per step was one L2 round
+        // trip per o); lanes past cnt hold g = 0 and rows are clamped, so the tail needs no separate loop
+#pragma unroll 1
+        for (int u0 = 0; u0 < cnt; u0 += 8) {
+            float rv[8][8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int d = lane + 64 * k;
-                if (d < D) acc[k] = fmaf(gu, row[d], acc[k]);
+            for (int uu = 0; uu < 8; ++uu) {
+                const int o = min(o0 + u0 + uu, G - 1);
+                const float* row = src + (int64_t)o * D;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int d = lane + 64 * k;
+                    rv[uu][k] = d < D ? row[d] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int uu = 0; uu < 8; ++uu) {
+                const float gu = __shfl(g, u0 + uu);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] = fmaf(gu, rv[uu][k], acc[k]);
             }
         }
     }
@@ -577,6 +770,18 @@ extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("sim_infonce memset");
     const float scale = both_dirs ? 0.5f / G : 1.f / G;
+    if ((D & 7) == 0) {
+        // logits = a b^T / temp on the matrix cores into the scratch behind the row statistics (ws: [lse dir0 G | lse dir1 G |
+        // G x G scratch]), then one coalesced pass per row; the column direction is the same with the operands swapped
+        float* logits = ws + 2 * G;
+        for (int dir = 0; dir < (both_dirs ? 2 : 1); ++dir) {
+            const int rc = launch_f32_nt(dir == 0 ? a : b, D, dir == 0 ? b : a, D, logits, G, G, G, D, 1.f / temp, false, st);
+            if (rc != LECCR_OK) return rc;
+            hipLaunchKernelGGL(sim_rowstat_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, logits, idx, (int)G, ws + dir * G,
+                               loss, scale);
+        }
+        return check_launch("sim_infonce_fwd");
+    }
     const size_t lds_f = (size_t)(4 * D + 64 * (D + 4)) * sizeof(float);      // 4 own rows + the staged 64-row tile
     (void)hipFuncSetAttribute((const void*)sim_rowlse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(sim_rowlse_kernel, dim3((unsigned)cdiv(G, 4), both_dirs ? 2 : 1), dim3(256), lds_f, st,
@@ -615,8 +820,15 @@ extern "C" int leccr_capsim_fwd(const float* c, const float* t, float temp, int6
     float* logits = ws;
     float* lse_r = ws + b * b;
     float* lse_c = lse_r + b;
-    hipLaunchKernelGGL(capsim_logits_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 4 * n * D * sizeof(float), st, c, t,
-                       1.f / temp, (int)b, (int)n, (int)D, logits, argmax);
+    if ((D & 7) == 0 && temp > 0.f) {      // max_n <c_n, t> as n matrix-core tile passes keeping the running maximum and its n
+        for (int q = 0; q < n; ++q) {
+            const int rc = launch_f32_nt(c + q * D, n * D, t, D, logits, b, b, b, D, 1.f / temp, true, st, argmax, q);
+            if (rc != LECCR_OK) return rc;
+        }
+    } else {
+        hipLaunchKernelGGL(capsim_logits_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 4 * n * D * sizeof(float), st, c, t,
+                           1.f / temp, (int)b, (int)n, (int)D, logits, argmax);
+    }
     hipLaunchKernelGGL(lse_ce_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, logits, (int)b, (int)b, (int64_t)b, (int64_t)1, lse_r, loss, 0.5f / b);
     hipLaunchKernelGGL(lse_ce_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, logits, (int)b, (int)b, (int64_t)1, (int64_t)b, lse_c, loss, 0.5f / b);
     return check_launch("capsim_fwd");
@@ -627,8 +839,15 @@ extern "C" int leccr_capsim_bwd(const float* c, const float* t, float temp, int6
                                 void* stream) {
     LECCR_REQUIRE(c && t && argmax && ws && dc && dt && b > 0 && n > 0 && n <= 8 && D > 0 && D <= 512, LECCR_EINVAL, "capsim_bwd: bad argument");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(capsim_bwd_kernel, dim3((unsigned)cdiv(b, 4), 2), dim3(256), 0, st, c, t, 1.f / temp, (int)b, (int)n,
-                       (int)D, argmax, ws, gscale * 0.5f / b, dc, dt, dtemp);
+    int nslice = (int)cdiv(1024, 2 * cdiv(b, 4));
+    if (nslice > cdiv(b, 64)) nslice = (int)cdiv(b, 64);
+    if (nslice < 1) nslice = 1;
+    const int slice = (int)(cdiv(cdiv(b, nslice), 64) * 64);
+    nslice = (int)cdiv(b, slice);
+    if (hipMemsetAsync(dc, 0, sizeof(float) * b * n * D, st) != hipSuccess || hipMemsetAsync(dt, 0, sizeof(float) * b * D, st) != hipSuccess)
+        return check_launch("capsim_bwd memset");
+    hipLaunchKernelGGL(capsim_bwd_kernel, dim3((unsigned)cdiv(b, 4), 2, (unsigned)nslice), dim3(256), 0, st, c, t, 1.f / temp, (int)b,
+                       (int)n, (int)D, argmax, ws, gscale * 0.5f / b, dc, dt, dtemp, slice);
     return check_launch("capsim_bwd");
 }
 
@@ -644,7 +863,16 @@ extern "C" int leccr_dstl_fwd(const float* v, const float* c, const float* s, co
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("dstl memset");
     hipLaunchKernelGGL(dstl_init_kernel, dim3(1), dim3(1), 0, st, mm);
     const size_t own = (size_t)4 * (2 + n) * D * sizeof(float), staged = own + (size_t)2 * 64 * (D + 4) * sizeof(float);
-    if (staged <= 160 * 1024 && (D & 3) == 0) {       // both 64-row tiles fit next to the block's own rows
+    if ((D & 7) == 0) {
+        // the 2 + n score products as f32 matrix-core tiles: tv = t v^T, sv = s v^T, sc = max_q c_q s^T (c is [G, n, D]: row
+        // stride n D), then one pass for the global ranges
+        int rc = launch_f32_nt(t, D, v, D, tv, G, G, G, D, 1.f, false, st);
+        if (rc == LECCR_OK) rc = launch_f32_nt(s, D, v, D, lab, G, G, G, D, 1.f, false, st);
+        for (int q = 0; q < n && rc == LECCR_OK; ++q) rc = launch_f32_nt(c + q * D, n * D, s, D, sc, G, G, G, D, 1.f, q > 0, st);
+        if (rc != LECCR_OK) return rc;
+        hipLaunchKernelGGL(dstl_minmax_kernel, dim3((unsigned)std::min<int64_t>(512, cdiv(G * G, 1024))), dim3(256), 0, st, lab, sc,
+                           G * G, mm);
+    } else if (staged <= 160 * 1024 && (D & 3) == 0) {       // both 64-row tiles fit next to the block's own rows
         (void)hipFuncSetAttribute((const void*)dstl_scores_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(dstl_scores_kernel<true>, dim3((unsigned)cdiv(G, 4)), dim3(256), staged, st, v, c, s, t, (int)G, (int)n,
                            (int)D, tv, lab, sc, mm);

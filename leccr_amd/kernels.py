@@ -206,7 +206,7 @@ def sim_infonce_fwd(a, b, idx, temp, both_dirs=True):
     G, D = _f32c(a).shape
     _f32c(b)
     loss = torch.empty(1, device=a.device, dtype=torch.float32)
-    ws = torch.empty(2 * G, device=a.device, dtype=torch.float32)
+    ws = torch.empty(2 * G + G * G, device=a.device, dtype=torch.float32)       # row statistics | G x G logits scratch
     check(lib().leccr_sim_infonce_fwd(ptr(a), ptr(b), ptr(idx), float(temp), G, D, int(both_dirs), ptr(loss),
                                       ptr(ws), stream()), 'leccr_sim_infonce_fwd')
     return loss, ws
