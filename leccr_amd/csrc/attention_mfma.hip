@@ -263,8 +263,21 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
     // inside the loop with a vmcnt(0) that also drains the prefetch
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0) expcnt(7) lgkmcnt(15)
     asm volatile("" : "+v"(qf[0]), "+v"(qf[1]));
+    // Without dropout the normaliser l = sum_k p is one more output row of the PV product: an all-ones "V column" gives every
+    // lane the full row sum of ITS query (all 64 keys, all four lane groups) in lacc - two MFMAs on a pipe with slack instead
+    // of 16 adds + a cross-lane reduction on the VALU that bounds this kernel.  (The sum is then over the bf16-rounded p, i.e.
+    // exactly the weights that multiply V.)  With dropout l must stay the undropped sum: VALU path.
+    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+    // waves whose 16 query rows all lie beyond Lq (577 = 4 x 128 + 65: three of the last block's eight) only stage and
+    // synchronise; a last key tile with <= 16 keys (577 = 9 x 64 + 1) runs one key group instead of four
+    const bool active = __builtin_amdgcn_readfirstlane((int)(q0 + wave * 16 < p.Lq));
+    const bool short_tail = p.Lk - (int64_t)(ntiles - 1) * BT <= 16;
+    const int nloop = short_tail ? ntiles - 1 : ntiles;      // the short last tile runs behind the loop (its own registers)
     stage(0);
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < nloop; ++t) {
         const uint32_t kt = smem_off + (t & 1) * FWD_STAGE, vt = kt + TILE_BYTES;
         // key mask bytes of this tile are fetched BEFORE the next tile's DMA is issued, so waiting for them does
         // not wait for the prefetch (vmcnt retires in order)
@@ -274,6 +287,7 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
+        if (!active) continue;
         bf16x8 kf[8];
         kf[0] = lds_b128<0>(kt + tl.row[0]);
         kf[1] = lds_b128<0>(kt + tl.row[1]);
@@ -317,24 +331,31 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
         const float msafe = mn == -INFINITY ? 0.f : mn;       // every key so far masked: keep exp2 arguments finite
         const float mc = msafe * c;
         const float alpha = exp2_fast(m * c - mc);             // m = -inf -> 0
-        float rs = 0.f;
+        if constexpr (DROP) {
+            float rs = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                s[j][r] = exp2_fast(__builtin_fmaf(s[j][r], c, -mc));
-                rs += s[j][r];
-            }
-        rs = xg_sum(rs);
-        l = l * alpha + rs;
-        m = mn;
-        if constexpr (DROP) {   // dropout on the probabilities that enter PV; the normaliser l keeps the undropped sum
+                for (int r = 0; r < 4; ++r) {
+                    s[j][r] = exp2_fast(__builtin_fmaf(s[j][r], c, -mc));
+                    rs += s[j][r];
+                }
+            rs = xg_sum(rs);
+            l = l * alpha + rs;
+            // dropout on the probabilities that enter PV; the normaliser l keeps the undropped sum
             const uint32_t base = (uint32_t)((bh * p.Lq + q0 + wave * 16 + (lane & 15)) * p.Lk + (int64_t)t * BT + 4 * h4);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s[j][r] *= drop_mul(p.drop, base + 16 * j + r);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[j][r] = exp2_fast(__builtin_fmaf(s[j][r], c, -mc));
+            lacc *= alpha;
         }
+        m = mn;
 #pragma unroll
         for (int i = 0; i < 4; ++i) o[i] *= alpha;
         const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
@@ -345,7 +366,66 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
             o[nd] = MFMA16(vf[2 * nd], pf0, o[nd]);
             o[nd] = MFMA16(vf[2 * nd + 1], pf1, o[nd]);
         }
+        if constexpr (!DROP) {
+            lacc = MFMA16(ones, pf0, lacc);
+            lacc = MFMA16(ones, pf1, lacc);
+        }
     }
+    if (short_tail) {
+        const int t = ntiles - 1;
+        const uint32_t kt = smem_off + (t & 1) * FWD_STAGE, vt = kt + TILE_BYTES;
+        const uint32_t dead = dead_keys(km, p.Lk, (int64_t)t * BT + 4 * h4, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+            // ---- last tile, keys 0..15 only: S group j = 0, PV k-step 0 (keys 16..31 of it are zero weights)
+            bf16x8 kf[2], vf[4];
+            kf[0] = lds_b128<0>(kt + tl.row[0]);
+            kf[1] = lds_b128<0>(kt + tl.row[1]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]));
+            f32x4 s0 = MFMA16(kf[0], qf[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+            s0 = MFMA16(kf[1], qf[1], s0);
+            vf[0] = lds_tr16_pair<0>(vt + tl.tr[0]);
+            vf[1] = lds_tr16_pair<0>(vt + tl.tr[1]);
+            vf[2] = lds_tr16_pair<0>(vt + tl.tr[2]);
+            vf[3] = lds_tr16_pair<0>(vt + tl.tr[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (dead & (1u << r)) s0[r] = -INFINITY;
+            float mx = fmaxf(fmaxf(s0[0], s0[1]), fmaxf(s0[2], s0[3]));
+            mx = xg_max(mx);
+            const float mn = fmaxf(m, mx);
+            const float msafe = mn == -INFINITY ? 0.f : mn;
+            const float mc = msafe * c;
+            const float alpha = exp2_fast(m * c - mc);
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] = exp2_fast(__builtin_fmaf(s0[r], c, -mc));
+                rs += s0[r];
+            }
+            m = mn;
+            if constexpr (DROP) {
+                rs = xg_sum(rs);
+                l = l * alpha + rs;
+                const uint32_t base = (uint32_t)((bh * p.Lq + q0 + wave * 16 + (lane & 15)) * p.Lk + (int64_t)t * BT + 4 * h4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s0[r] *= drop_mul(p.drop, base + r);
+            } else {
+                lacc *= alpha;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] *= alpha;
+            const bf16x8 pf0 = pack2(s0, f32x4{0.f, 0.f, 0.f, 0.f});
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) o[nd] = MFMA16(vf[nd], pf0, o[nd]);
+            if constexpr (!DROP) lacc = MFMA16(ones, pf0, lacc);
+        }
+    }
+    if constexpr (!DROP) l = lacc[0];
     // o[nd][r] = O^T[d = 16 nd + 4 h4 + r][query = lane&15]
     const int64_t qi = q0 + wave * 16 + (lane & 15);
     if (qi < p.Lq) {

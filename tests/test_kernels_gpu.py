@@ -188,7 +188,8 @@ def test_attention(K, dtype, b, heads, Lq, Lk, hd, masked):
     e, s = _err(o, ref)
     assert e <= _tol(dtype) * s, ('o', e, s)
     e, s = _err(lse, ref_lse)
-    assert e <= 1e-4 * s + 1e-4, ('lse', e, s)
+    # bf16 MFMA path: the normaliser is the sum of the bf16-rounded weights (the ones that multiply V), 2^-9 relative each
+    assert e <= (1e-4 * s + 1e-4 if dtype == torch.float32 else 3e-3), ('lse', e, s)
     do = _rand((b, Lq, d), dtype, 34)
     (ref * do.double()).sum().backward()
     if Lq == Lk:        # gradients land in one packed dqkv buffer, as in the model
