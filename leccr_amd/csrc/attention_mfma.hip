@@ -554,14 +554,18 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
     __builtin_amdgcn_s_waitcnt(0x0F70);       // retire the K/V fragment loads visibly (see flash_fwd_kernel)
 #pragma unroll
     for (int g = 0; g < KG; ++g) asm volatile("" : "+v"(kf[g][0]), "+v"(kf[g][1]), "+v"(vf[g][0]), "+v"(vf[g][1]));
+    // a last query tile with <= 16 rows (577 = 9 x 64 + 1) runs behind the loop with one query group instead of four
+    const bool short_tail = p.Lq - (int64_t)(ntiles - 1) * BT <= 16;
+    const int nloop = short_tail ? ntiles - 1 : ntiles;
     stage(0);
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < nloop; ++t) {
         const uint32_t qt = smem_off + (t & 1) * DKV_STAGE, dot = qt + TILE_BYTES;
         const uint32_t rcl = dot + TILE_BYTES + 16 * h4;          // rc1[16 j + 4 h4 ..] at + 64 j; rc0 256 B further
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
+        if (k0 >= p.Lk) continue;                   // none of this wave's keys exist (wave-uniform): stage and synchronise only
         // s[g][j][r], dp[g][j][r]: query = 16 j + 4 h4 + r of the tile, key = group g, lane & 15
         f32x4 s[KG][4], dp[KG][4], dl[4];
         bf16x8 fa[8];
@@ -649,6 +653,60 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
                 dk[g][nd] = MFMA16(fa[2 * nd + 1], df[g][1], dk[g][nd]);
             }
     }
+    if (short_tail) {
+        const int t = ntiles - 1;
+        const uint32_t qt = smem_off + (t & 1) * DKV_STAGE, dot = qt + TILE_BYTES;
+        const uint32_t rcl = dot + TILE_BYTES + 16 * h4;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 < p.Lk) {
+            // queries 0..15 of the tile only (group j = 0): rows of Q / dO for S'^T and dP'^T, k-step 0 of dO^T / Q^T for dV / dK
+            f32x4 s0 = lds_b128_f32<0>(rcl), dl0 = lds_b128_f32<256>(rcl);
+            bf16x8 fq[2], fd[2], fdt[4], fqt[4];
+            fq[0] = lds_b128<0>(qt + tl.row[0]);
+            fq[1] = lds_b128<0>(qt + tl.row[1]);
+            fd[0] = lds_b128<0>(dot + tl.row[0]);
+            fd[1] = lds_b128<0>(dot + tl.row[1]);
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) {
+                fdt[nd] = lds_tr16_pair<0>(dot + tl.tr[nd]);
+                fqt[nd] = lds_tr16_pair<0>(qt + tl.tr[nd]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s0), "+v"(dl0), "+v"(fq[0]), "+v"(fq[1]), "+v"(fd[0]), "+v"(fd[1]));
+            asm volatile("" : "+v"(fdt[0]), "+v"(fdt[1]), "+v"(fdt[2]), "+v"(fdt[3]), "+v"(fqt[0]), "+v"(fqt[1]), "+v"(fqt[2]), "+v"(fqt[3]));
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                f32x4 sg = MFMA16(fq[0], kf[g][0], s0);
+                sg = MFMA16(fq[1], kf[g][1], sg);
+                f32x4 dg = MFMA16(fd[0], vf[g][0], DROP ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dl0);
+                dg = MFMA16(fd[1], vf[g][1], dg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sg[r] = exp2_fast(sg[r] * c);
+                if (any_dead) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sg[r] = dead[g] ? 0.f : sg[r];
+                }
+                if constexpr (DROP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + (int64_t)t * BT + 4 * h4 + r) * p.Lk + key[g]));
+                        dg[r] = sg[r] * (dm * dg[r] + dl0[r]);
+                        sg[r] *= dm;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dg[r] *= sg[r];
+                }
+                const bf16x8 pf0 = pack2(sg, f32x4{0.f, 0.f, 0.f, 0.f}), df0 = pack2(dg, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) {
+                    dv[g][nd] = MFMA16(fdt[nd], pf0, dv[g][nd]);
+                    dk[g][nd] = MFMA16(fqt[nd], df0, dk[g][nd]);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
         if (key[g] < p.Lk) {
@@ -725,14 +783,18 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
 #pragma unroll
     for (int g = 0; g < KG; ++g)
         asm volatile("" : "+v"(qf[g][0]), "+v"(qf[g][1]), "+v"(dof[g][0]), "+v"(dof[g][1]), "+v"(nd_[g]), "+v"(nl_[g]));
+    // a last key tile with <= 16 keys (577 = 9 x 64 + 1) runs behind the loop with one key group instead of four
+    const bool short_tail = p.Lk - (int64_t)(ntiles - 1) * BT <= 16;
+    const int nloop = short_tail ? ntiles - 1 : ntiles;
     stage(0);
-    for (int t = 0; t < ntiles; ++t) {
+    for (int t = 0; t < nloop; ++t) {
         const uint32_t kt = smem_off + (t & 1) * DQ_STAGE, vt = kt + TILE_BYTES;
         const uint32_t deadk = dead_keys(km, p.Lk, (int64_t)t * BT + 4 * h4, t >= nfull);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
+        if (q0 >= p.Lq) continue;                   // none of this wave's queries exist (wave-uniform): stage and synchronise only
         // s[g][j][r], dp[g][j][r]: key = 16 j + 4 h4 + r of the tile, query = group g, lane & 15
         f32x4 s[KG][4], dp[KG][4];
         bf16x8 fa[8];
@@ -804,6 +866,50 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
                 dq[g][nd] = MFMA16(fa[2 * nd], df[g][0], dq[g][nd]);
                 dq[g][nd] = MFMA16(fa[2 * nd + 1], df[g][1], dq[g][nd]);
             }
+    }
+    if (short_tail) {
+        const int t = ntiles - 1;
+        const uint32_t kt = smem_off + (t & 1) * DQ_STAGE, vt = kt + TILE_BYTES;
+        const uint32_t deadk = dead_keys(km, p.Lk, (int64_t)t * BT + 4 * h4, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (q0 < p.Lq) {
+            // keys 0..15 of the tile only (group j = 0): rows of K / V for S'^T and dP'^T, k-step 0 of K^T for dQ^T
+            bf16x8 fk[2], fv[2], ft[4];
+            fk[0] = lds_b128<0>(kt + tl.row[0]);
+            fk[1] = lds_b128<0>(kt + tl.row[1]);
+            fv[0] = lds_b128<0>(vt + tl.row[0]);
+            fv[1] = lds_b128<0>(vt + tl.row[1]);
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd) ft[nd] = lds_tr16_pair<0>(kt + tl.tr[nd]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fk[0]), "+v"(fk[1]), "+v"(fv[0]), "+v"(fv[1]), "+v"(ft[0]), "+v"(ft[1]), "+v"(ft[2]), "+v"(ft[3]));
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                f32x4 sg = MFMA16(fk[0], qf[g][0], (f32x4{nl_[g], nl_[g], nl_[g], nl_[g]}));
+                sg = MFMA16(fk[1], qf[g][1], sg);
+                f32x4 dg = MFMA16(fv[0], dof[g][0], (f32x4{nd_[g], nd_[g], nd_[g], nd_[g]}));
+                dg = MFMA16(fv[1], dof[g][1], dg);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sg[r] = exp2_fast(sg[r] * c);
+                    if (deadk & (1u << r)) sg[r] = 0.f;
+                }
+                if constexpr (DROP) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float dm = drop_mul(p.drop, (uint32_t)((bh * p.Lq + qi[g]) * p.Lk + (int64_t)t * BT + 4 * h4 + r));
+                        dg[r] = sg[r] * (dm * (dg[r] - nd_[g]) + nd_[g]);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dg[r] *= sg[r];
+                }
+                const bf16x8 df0 = pack2(dg, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) dq[g][nd] = MFMA16(ft[nd], df0, dq[g][nd]);
+            }
+        }
     }
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
