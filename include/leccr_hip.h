@@ -38,6 +38,9 @@ int leccr_set_force_generic(int on);           /* 1: route every op through the 
  * {gemm_mfma_nt, gemm_mfma_tn, gemm_generic, attn_fwd, attn_bwd}; synchronises on the recorded events. */
 int leccr_set_gemm_variant(int v);             /* 0 auto (default), 1 force the 128x128 kernel, 2 / 3 force the 8-wave /
                                                 * 4-wave 256x256 kernel where it is legal */
+int leccr_set_gemm_max_blocks(int n);          /* workgroups (= CUs) a persistent 256x256 GEMM launch may use: 0 / 256 = all
+                                                * (default); rounded down to a multiple of 8; returns the value in effect.
+                                                * leccr_amd.parallel lowers it while an all-reduce overlaps the backward pass */
 int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_gemm launched: 0 generic, 1 MFMA 128x128,
                                                 * 2 MFMA 256x256 (8 waves), 3 MFMA 256x256 (4 waves); tests use it */
 int leccr_prof_enable(int on);

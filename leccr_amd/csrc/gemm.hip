@@ -351,6 +351,8 @@ bool gemm256_wanted(const leccr_gemm_params& p);
 bool gemm256_legal(const leccr_gemm_params& p);
 bool gemm256_fuses_colsum(const leccr_gemm_params& p);
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
+void gemm256_set_max_blocks(int n);
+int gemm256_max_blocks();
 bool gemm256w4_legal(const leccr_gemm_params& p);
 int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st);
 // 0 auto, 1 force the 128x128 kernel, 2 force the 8-wave 256x256 kernel where legal, 3 force the 4-wave 256x256 kernel where legal
@@ -365,6 +367,11 @@ extern "C" int leccr_debug_set_stamps(void* p) {      // diagnostic builds (-DLE
 }
 
 extern "C" int leccr_last_gemm_kernel(void) { return g_last_kernel; }
+
+extern "C" int leccr_set_gemm_max_blocks(int n) {
+    gemm256_set_max_blocks(n);
+    return gemm256_max_blocks();
+}
 
 extern "C" int leccr_set_gemm_variant(int v) {
     g_gemm_variant = v;

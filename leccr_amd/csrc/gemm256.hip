@@ -848,8 +848,17 @@ static void launch_inst(const g256::Args& a, int grid, hipStream_t st) {
 static unsigned long long* g_stamps = nullptr;
 void gemm256_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
 
+// Workgroups per launch (one per CU, static item lists).  A collective's kernel resident on some CUs leaves no room there for
+// a workgroup that needs the CU's whole LDS and register file: a 256-workgroup launch would then run its last workgroups as a
+// second round (2x the time).  While a gradient all-reduce overlaps the backward pass, leccr_amd.parallel lowers this to
+// 256 - (CUs left to RCCL); always a multiple of 8 (XCD-contiguous item lists).
+static int g_max_blocks = 256;
+void gemm256_set_max_blocks(int n) { g_max_blocks = n <= 0 || n > 256 ? 256 : (n < 8 ? 8 : n & ~7); }
+int gemm256_max_blocks() { return g_max_blocks; }
+
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     using namespace g256;
+    const int cap = g_max_blocks;
     Args a{};
     a.stamps = g_stamps;
     a.A = (const bf16_t*)p.A; a.B = (const bf16_t*)p.B; a.C = p.C;
@@ -861,15 +870,15 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     const int tiles = a.tiles_m * a.tiles_n;
     int splits = 1;
     if (p.trans_a == 1) {
-        // one item per CU in ONE round: tiles * splits <= 256 (a second, partial round would double the time)
-        splits = tiles >= 256 ? 1 : 256 / tiles;
+        // one item per CU in ONE round: tiles * splits <= cap (a second, partial round would double the time)
+        splits = tiles >= cap ? 1 : cap / tiles;
         if (splits > ktiles / 8) splits = (int)(ktiles / 8);
         if (splits < 1) splits = 1;
     }
     a.splits = splits;
     a.nkt = (int)cdiv(ktiles, splits);
     a.n_items = tiles * splits;
-    const int grid = a.n_items < 256 ? a.n_items : 256;              // <= 256: one item per block (any count)
+    const int grid = a.n_items < cap ? a.n_items : cap;              // < cap: one item per block (any count)
     const int f = flags_of(p);
     if (p.trans_a == 1) {
         if (splits > 1) launch_inst<1, float, LECCR_EPI_NONE, F_ATOMIC>(a, grid, st);

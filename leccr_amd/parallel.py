@@ -10,6 +10,11 @@ import torch
 import torch.distributed as dist
 
 _BUCKET = 64 * 1024 * 1024      # elements per all-reduce (256 MiB f32): large, few collectives (xGMI per-link bound)
+# CUs left to RCCL while an all-reduce overlaps the backward pass.  The persistent GEMMs run one workgroup per CU with a static
+# item list and need the whole CU (160 KiB LDS, every VGPR): a collective's workgroups resident on n CUs would push n of a
+# 256-workgroup launch into a second round - twice the launch time for as long as the collective runs.  So RCCL is capped to
+# this many channels (NCCL_MAX_NCHANNELS, unless the user set it) and the GEMM launches of the overlap window use 256 - n CUs.
+_RCCL_CUS = 16
 
 
 def init_distributed_mode(backend=None):
@@ -17,6 +22,7 @@ def init_distributed_mode(backend=None):
     if 'RANK' not in os.environ or 'WORLD_SIZE' not in os.environ:
         return 0, 1, 0
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ.get('LOCAL_RANK', 0))
+    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(_RCCL_CUS))          # read by RCCL at communicator creation
     if torch.cuda.is_available():
         torch.cuda.set_device(local % torch.cuda.device_count())     # (ranks outnumber GPUs only in gloo rehearsals)
     if not dist.is_initialized():
@@ -47,11 +53,22 @@ def attach_grad_sync(optimizer):
 
     reduce_stream = []
     late = {'hi': grad.numel()}               # [late['hi'], numel) of the ViT region is already handed to RCCL
+    try:
+        rccl_cus = int(os.environ.get('LECCR_RCCL_CUS', os.environ.get('NCCL_MAX_NCHANNELS', _RCCL_CUS)))
+    except ValueError:
+        rccl_cus = _RCCL_CUS
+    rccl_cus = max(0, min(rccl_cus, 128)) if grad.is_cuda and dist.get_backend() == 'nccl' else 0
+
+    def gemm_cus(n):
+        if rccl_cus:
+            from . import _lib
+            _lib.lib().leccr_set_gemm_max_blocks(n)
 
     def reduce_async(lo, hi):
         """All launches that write grad[lo:hi] are enqueued (on the main, text and weight-gradient streams): a stream of its own
         waits for the three and hands the all-reduces to RCCL, so the main stream goes straight on with the backward pass."""
         if grad.is_cuda:
+            gemm_cus(256 - rccl_cus)          # from here to optimizer.step() the GEMM launches leave RCCL its CUs
             if not reduce_stream:
                 reduce_stream.append(torch.cuda.Stream(device=grad.device))
             rs = reduce_stream[0]
@@ -86,6 +103,7 @@ def attach_grad_sync(optimizer):
         for w in pending:
             w.wait()
         pending.clear()
+        gemm_cus(0)
 
     ops.on_late_backward_start = early if split < grad.numel() else None
     ops.on_vit_block_backward = vit_block if split < grad.numel() else None

@@ -544,6 +544,30 @@ def test_gemm256_tn(K, force256, Kt, M, N):
     assert e <= 1e-4 * s, (e, s)
 
 
+def test_gemm256_with_fewer_workgroups(K):
+    """leccr_set_gemm_max_blocks: the persistent GEMMs on 240 of the 256 CUs (what the all-reduce overlap window uses) give the
+    same results - NT bit for bit (same per-tile arithmetic), split-K TN to summation order."""
+    from leccr_amd import _lib
+    lib = _lib.lib()
+    a, b = _rand((256 * 41 + 3, 768), torch.bfloat16, 390).to(DEV), _rand((2304, 768), torch.bfloat16, 391, 0.05).to(DEV)
+    dy, x = _rand((20000, 768), torch.bfloat16, 392).to(DEV), _rand((20000, 1024), torch.bfloat16, 393).to(DEV)
+    try:
+        assert lib.leccr_set_gemm_max_blocks(0) == 256 and lib.leccr_set_gemm_max_blocks(243) == 240
+        o240 = K.gemm(a, b)
+        w240 = torch.zeros(768, 1024, device=DEV)
+        K.gemm(dy, x, trans_a=True, trans_b=True, out=w240, accumulate=True)
+    finally:
+        assert lib.leccr_set_gemm_max_blocks(0) == 256
+    o256 = K.gemm(a, b)
+    w256 = torch.zeros(768, 1024, device=DEV)
+    K.gemm(dy, x, trans_a=True, trans_b=True, out=w256, accumulate=True)
+    assert torch.equal(o240, o256)
+    assert float((w240 - w256).abs().max()) <= 1e-5 * float(w256.abs().max())
+    ref = dy.cpu().double().t() @ x.cpu().double()
+    e, s_ = _err(w240, ref)
+    assert e <= 1e-4 * s_
+
+
 def test_gemm256_matches_128_bitwise_inputs(K):
     """Same bf16 inputs through both kernels: results agree to f32 summation-order noise (bf16 output: <= 1 ulp)."""
     from leccr_amd import _lib
