@@ -438,7 +438,7 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
 }
 
 // --------------------------------------------------------------------------------------------------- backward
-// Row constants (written by flash_rowconst_kernel into the `delta` workspace, [2][b*heads][Lqp], Lqp = Lq rounded up
+// Row constants (written by flash_dq_kernel, which runs first, into the `delta` workspace, [2][b*heads][Lqp], Lqp = Lq rounded up
 // to 64): rc0[q] = -rowsum(dO*O), rc1[q] = -lse[q] / scale; rows q >= Lq hold 0 and -inf.  They are the INITIAL
 // ACCUMULATORS of the dP and S products: S' = Q.K - lse/scale leaves p = exp2(c*S') (no subtraction, no row maximum;
 // -inf rows give p = 0) and dP' = dO.V - delta leaves dS = p*dP' directly.
@@ -745,17 +745,31 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
     bf16x8 qf[KG][2], dof[KG][2];
     int64_t qi[KG];
     float nd_[KG], nl_[KG];
+    // Row constants of the backward, computed here from the fragments this kernel loads anyway (the dO rows; O is read just for
+    // this): -delta = -sum_d dO O and -lse / scale per query.  They start this kernel's dP' and S' accumulators, and are written
+    // to the workspace ([2][b*heads][Lqp], rows q >= Lq: (0, -inf)) for the dK/dV kernel that runs behind this one.
+    const bf16_t* O = p.o + b * p.Lq * p.ldo + head * HD;
+    float* rc_w = const_cast<float*>(p.delta);
+    const float inv_scale = 1.f / p.scale;
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
         qf[g][0] = frag_global(Q, p.ldq, q0 + 16 * g, p.Lq, 0, lane);
         qf[g][1] = frag_global(Q, p.ldq, q0 + 16 * g, p.Lq, 1, lane);
         dof[g][0] = frag_global(DO, p.ldo, q0 + 16 * g, p.Lq, 0, lane);
         dof[g][1] = frag_global(DO, p.ldo, q0 + 16 * g, p.Lq, 1, lane);
+        const bf16x8 o0 = frag_global(O, p.ldo, q0 + 16 * g, p.Lq, 0, lane), o1 = frag_global(O, p.ldo, q0 + 16 * g, p.Lq, 1, lane);
         qi[g] = q0 + 16 * g + (lane & 15);
-        const int64_t qc = qi[g] < p.Lqp ? qi[g] : p.Lqp - 1;         // padded rows hold (0, -inf): p = 0 for queries >= Lq
-        nd_[g] = p.delta[bh * p.Lqp + qc];                            // -delta
-        nl_[g] = p.delta[(p.nbh + bh) * p.Lqp + qc];                  // -lse / scale
-        if (qi[g] >= p.Lqp) { nd_[g] = 0.f; nl_[g] = -INFINITY; }
+        float part = 0.f;                         // this lane's 16 of the 64 head dims of query lane & 15
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)dof[g][0][e] * (float)o0[e] + (float)dof[g][1][e] * (float)o1[e];
+        part = xg_sum(part);                      // the four lane groups hold the other 48
+        const bool live = qi[g] < p.Lq;
+        nd_[g] = live ? -part : 0.f;
+        nl_[g] = live ? -p.lse[bh * p.Lq + qi[g]] * inv_scale : -INFINITY;
+        if (h4 == 0 && qi[g] < p.Lqp) {
+            rc_w[bh * p.Lqp + qi[g]] = nd_[g];
+            rc_w[(p.nbh + bh) * p.Lqp + qi[g]] = nl_[g];
+        }
     }
 
     f32x4 dq[KG][4];
@@ -921,33 +935,6 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
     }
 }
 
-// Row constants of the backward: rc0[bh][q] = -sum_d dO*O, rc1[bh][q] = -lse/scale, q < Lqp (padding: 0, -inf).
-// 8 lanes per (b, h, q) row, 16 bytes of O and dO each.
-__global__ __launch_bounds__(256) void flash_rowconst_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                             const float* __restrict__ lse, float* __restrict__ rc,
-                                                             int64_t heads, int64_t Lq, int64_t Lqp, int64_t ldo,
-                                                             int64_t nbh, float inv_scale) {
-    const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;       // over nbh * Lqp
-    const int sub = threadIdx.x & 7;
-    const int64_t total = nbh * Lqp;
-    const int64_t bh = row / Lqp, qi = row % Lqp;
-    const bool live = row < total && qi < Lq;
-    float s = 0.f;
-    if (live) {
-        const int64_t b = bh / heads, head = bh % heads;
-        const int64_t off = (b * Lq + qi) * ldo + head * HD + sub * 8;
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(o + off), g = *reinterpret_cast<const bf16x8*>(dout + off);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s += (float)a[i] * (float)g[i];
-    }
-#pragma unroll
-    for (int w = 4; w > 0; w >>= 1) s += __shfl_xor(s, w, 64);
-    if (row < total && sub == 0) {
-        rc[row] = live ? -s : 0.f;
-        rc[total + row] = live ? -lse[bh * Lq + qi] * inv_scale : -INFINITY;
-    }
-}
-
 template <typename KFn>
 static void set_smem(KFn k, int bytes) {
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -997,15 +984,13 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
     p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv; p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
     p.Lqp = cdiv(D.Lq, BT) * BT;
     p.nbh = D.b * D.heads;
-    hipLaunchKernelGGL(flash_rowconst_kernel, dim3((unsigned)cdiv(p.nbh * p.Lqp * 8, 256)), dim3(256), 0, st,
-                       (const bf16_t*)o, (const bf16_t*)dout, lse, delta, D.heads, D.Lq, p.Lqp, D.ldo, p.nbh,
-                       sqrtf((float)HD));
+    // dQ first: it computes the row constants (-delta, -lse/scale) and leaves them in `delta` for the dK/dV kernel
 #define LAUNCH_BWD(DR, KG)                                                                                              \
     do {                                                                                                            \
-        hipLaunchKernelGGL((flash_dkdv_kernel<DR, 4, KG>), dim3((unsigned)(cdiv(D.Lk, 64 * KG) * D.b * D.heads)),   \
-                           dim3(256), 2 * DKV_STAGE, st, p);                                                        \
         hipLaunchKernelGGL((flash_dq_kernel<DR, 4, KG>), dim3((unsigned)(cdiv(D.Lq, 64 * KG) * D.b * D.heads)),     \
                            dim3(256), 2 * DQ_STAGE, st, p);                                                         \
+        hipLaunchKernelGGL((flash_dkdv_kernel<DR, 4, KG>), dim3((unsigned)(cdiv(D.Lk, 64 * KG) * D.b * D.heads)),   \
+                           dim3(256), 2 * DKV_STAGE, st, p);                                                        \
     } while (0)
     // 4-wave blocks (see BWD_WPE); two 16-row groups per wave when both sequences are long enough to fill 128-row blocks
     if (D.dropout) LAUNCH_BWD(true, 1);
