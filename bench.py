@@ -155,7 +155,7 @@ def main():
     from leccr_amd import ops
     ms1, work1, n1 = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
     if args.roofline_steps > 0:
-        overlap, ops.wgrad_overlap = ops.wgrad_overlap, False
+        overlap, ops.wgrad_overlap, ops.text_overlap = (ops.wgrad_overlap, ops.text_overlap), False, False
         barrier()
         lib.leccr_prof_enable(1)
         for _ in range(args.roofline_steps):
@@ -163,7 +163,7 @@ def main():
         barrier()
         lib.leccr_prof_enable(0)
         lib.leccr_prof_read(ms1, work1, n1)
-        ops.wgrad_overlap = overlap
+        ops.wgrad_overlap, ops.text_overlap = overlap
     if rank == 0:
         G = args.batch * world
         value = G * args.steps / dt
@@ -197,7 +197,7 @@ def main():
                          'avg_launch_gflop': round(gemm_fl / max(1, gemm_n) / 1e9, 2),
                          'timing': (f'HIP events on the launch stream around every GEMM launch of {leg_steps} single-stream steps run right '
                                     'after the timed region (same process, same tensors): each interval is the kernel alone. In the timed '
-                                    'region the dW launches share the chip with the dX chain on a second stream')
+                                    'region the dW launches and the text towers share the chip with the image tower / dX chain on side streams')
                                    if args.roofline_steps > 0 else 'HIP events around every GEMM launch of the timed region',
                          'timed_region_gemm_tflops_union': round(union_fl / (union_ms * 1e-3) / 1e12, 1) if union_ms > 0 else None,
                          'timed_region_gemm_busy_share': round(union_ms / (dt * 1e3), 3),
