@@ -164,6 +164,41 @@ def test_production_kernels_vs_oracle(dtype):
     assert not bad, bad[:8]
 
 
+XLMR_LARGE_BERT = dict(vocab_size=1000, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                       max_position_embeddings=64)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_xlmr_large_text_geometry_vs_oracle(dtype):
+    """BASELINE configs[4]'s text tower: a BERT-architecture encoder with XLM-R-large dimensions (hidden 1024, 16 heads of 64,
+    FFN 4096; two layers and a small vocabulary here) through the same kernels, against the CPU oracle - losses and
+    text-tower gradients."""
+    model = build(dict(clip_geometry=MID_VIT, text_config=XLMR_LARGE_BERT, compute_dtype=dtype, embed_dim=256,
+                       clip_text_tower=False), seed=5)
+    with torch.no_grad():
+        model.queries.normal_(0, 0.5)
+    batch = _mid_batch(vocab=1000)
+    ref_losses, sd = _oracle_step(model, batch, text_heads=16)
+    losses = model(batch['image'].to(DEV), [Enc(batch['ids_s'].to(DEV), batch['mask_s'].to(DEV)),
+                                            Enc(batch['ids_t'].to(DEV), batch['mask_t'].to(DEV))],
+                   captions=Enc(batch['ids_c'].to(DEV), batch['mask_c'].to(DEV)), idx=batch['idx'].to(DEV))
+    tol = 1e-3 if dtype == 'fp32' else 5e-3
+    for a, r in zip([float(l) for l in losses], ref_losses):
+        assert abs(a - r) <= tol * max(1.0, abs(r)), (dtype, a, r)
+    model.arena.zero_grad()
+    sum(losses).backward()
+    checked, gmax = 0, max(float(v.grad.norm()) for k, v in sd.items() if k.startswith('text_encoder.') and v.grad is not None)
+    for name, p in model.named_parameters():
+        r = sd[name].grad
+        if not name.startswith('text_encoder.encoder.') or r is None or float(r.norm()) < 1e-2 * gmax:
+            continue
+        g, r = p.grad.detach().cpu().double(), r.double()
+        rel, cos = float((g - r).norm() / r.norm()), float((g * r).sum() / (g.norm() * r.norm()))
+        assert (rel <= 1e-3) if dtype == 'fp32' else (rel <= 0.15 and cos >= 0.985), (name, rel, cos)
+        checked += 1
+    assert checked >= 8
+
+
 def test_side_streams_give_the_same_gradients():
     """Weight-gradient launches on the second stream and the text towers on the third (defaults) vs everything on one stream:
     same arena gradients (f32 path: the split-K atomics are the only order-dependent sums), read straight after backward()
