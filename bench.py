@@ -117,7 +117,7 @@ def main():
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
     model, cfg = build_model(args, device)
-    opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model))
+    opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model)).enable_backward_fusion()
     sched = create_scheduler(dict(cfg['schedular'], step_per_epoch=1000), opt)
     sched.step()                                                  # leave lr = 0 (first LambdaLR value) behind
     cpu = make_batch(args.batch, rank=rank)

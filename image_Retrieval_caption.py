@@ -123,6 +123,7 @@ def main(args, config):
 
     arg_opt = config['optimizer']
     optimizer = attach_grad_sync(create_optimizer(arg_opt, model))      # replaces the DDP wrapper (arena all-reduce)
+    optimizer.enable_backward_fusion()          # train() calls step() after every backward(): non-ViT parameters update during the ViT backward
     arg_sche = dict(config['schedular'])
     arg_sche['step_per_epoch'] = max(1, len(train_loader))
     lr_scheduler = create_scheduler(arg_sche, optimizer)

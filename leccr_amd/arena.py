@@ -72,7 +72,7 @@ class ParamArena:
         self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
         self.lp = torch.zeros(self.numel, device=device, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
         self._transposed = []
-        self._tt_table, self._tt_tiles = None, 0
+        self._tt_cache = {}
         self.post_refresh = []          # callables run after every refresh (derived copies outside the arena)
         self.touched = [False] * len(params)
         for i, (p, o) in enumerate(zip(params, self.offsets)):
@@ -97,6 +97,7 @@ class ParamArena:
             setattr(m, gname, pk)
         self.state_m = self.state_v = None
         self._seg_key = None
+        self._seg_range = {}
         self.step_count = 0
 
     # ------------------------------------------------------------------ compute copies
@@ -109,35 +110,51 @@ class ParamArena:
         holder._lpt = torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=torch.bfloat16)
         self._transposed.append(holder)
 
+    def _transpose_table(self, lo, hi):
+        """Batched-transpose table of the [in,out] copies whose master weights live in arena elements [lo, hi)."""
+        key = (lo, hi, len(self._transposed))
+        hit = self._tt_cache.get(key)
+        if hit is None:
+            base, rows, tiles = self.data.data_ptr(), [], 0
+            for h in self._transposed:
+                off = (h.data.data_ptr() - base) // 4
+                if not (lo <= off < hi):
+                    continue
+                R, Cn = h.data.shape
+                assert h.data.is_contiguous() and h.data.dtype == torch.float32
+                rows.append([tiles, h.data.data_ptr(), h._lpt.data_ptr(), R, Cn])
+                tiles += ((R + 31) // 32) * ((Cn + 31) // 32)
+            hit = (torch.tensor(rows, dtype=torch.int64, device=self.data.device) if rows else None, tiles)
+            self._tt_cache[key] = hit
+        return hit
+
     @torch.no_grad()
-    def refresh(self, adamw_wrote_lp=False):
-        """Rebuild the low-precision compute copies from the f32 master weights (call once per optimizer step)."""
+    def refresh(self, adamw_wrote_lp=False, lo=0, hi=None):
+        """Rebuild the low-precision compute copies from the f32 master weights (call once per optimizer step; [lo, hi):
+        only the copies of that element range - the optimizer updates the arena in two parts when it is fused into backward)."""
         if self.lp is None:
             return
+        hi = self.numel if hi is None else hi
         if not adamw_wrote_lp:
-            K.cast_bf16(self.data, self.lp)
+            K.cast_bf16(self.data[lo:hi], self.lp[lo:hi])
         if self._transposed:
-            if self._tt_table is None or self._tt_table.shape[0] != len(self._transposed):
-                rows, tiles = [], 0
-                for h in self._transposed:
-                    R, Cn = h.data.shape
-                    assert h.data.is_contiguous() and h.data.dtype == torch.float32
-                    rows.append([tiles, h.data.data_ptr(), h._lpt.data_ptr(), R, Cn])
-                    tiles += ((R + 31) // 32) * ((Cn + 31) // 32)
-                self._tt_table = torch.tensor(rows, dtype=torch.int64, device=self.data.device)
-                self._tt_tiles = tiles
-            K.transpose_cast_batched(self._tt_table, self._tt_tiles)       # one launch for all [in,out] copies
-        for fn in self.post_refresh:
-            fn()
+            table, tiles = self._transpose_table(lo, hi)
+            if table is not None:
+                K.transpose_cast_batched(table, tiles)                      # one launch for all [in,out] copies of the range
+        if hi == self.numel:
+            for fn in self.post_refresh:
+                fn()
 
     # ------------------------------------------------------------------ gradients
     def zero_grad(self):
         self.grad.zero_()
 
-    def mark_autograd_grads(self):
+    def mark_autograd_grads(self, lo=0, hi=None):
         """Parameters updated through plain autograd (tiny ones: temp, queries) count as touched when non-zero."""
+        hi = self.numel if hi is None else hi
         for i, p in enumerate(self.params):
-            if not self.touched[i] and p.requires_grad and p.numel() <= 1 << 16 and bool(p.grad.abs().sum() != 0):
+            if lo <= self.offsets[i] < hi and not self.touched[i] and p.requires_grad and p.numel() <= 1 << 16 \
+                    and bool(p.grad.abs().sum() != 0):
                 self.touched[i] = True
 
     # ------------------------------------------------------------------ optimizer (transformers.AdamW semantics)
@@ -157,15 +174,33 @@ class ParamArena:
             self._seg_key = key
         return self._seg_end, self._seg_wd
 
+    def _segments_range(self, decay_of, lo, hi):
+        """Segment table of arena elements [lo, hi), ends relative to lo (lo / hi are parameter boundaries)."""
+        seg_end, seg_wd = self._segments(decay_of)
+        if lo == 0 and hi == self.numel:
+            return seg_end, seg_wd
+        key = (self._seg_key, lo, hi)
+        if self._seg_range.get('key') != key:
+            i0 = next(i for i, o in enumerate(self.offsets) if o >= lo)
+            i1 = next((i for i, o in enumerate(self.offsets) if o >= hi), len(self.offsets))
+            self._seg_range = {'key': key, 'end': (seg_end[i0:i1] - lo).clamp_(max=hi - lo).contiguous(),
+                               'wd': seg_wd[i0:i1].contiguous()}
+        return self._seg_range['end'], self._seg_range['wd']
+
     @torch.no_grad()
-    def adamw_step(self, lr, betas, eps, decay_of, gscale=1.0):
+    def adamw_step(self, lr, betas, eps, decay_of, gscale=1.0, lo=0, hi=None, step=None):
+        """One AdamW update of arena elements [lo, hi) (default: everything).  `step` = the bias-correction step number of this
+        update; None: the next one (and the arena's step counter advances)."""
+        hi = self.numel if hi is None else hi
         if self.state_m is None:
             self.state_m = torch.zeros_like(self.data)
             self.state_v = torch.zeros_like(self.data)
-        self.step_count += 1
-        seg_end, seg_wd = self._segments(decay_of)
-        K.adamw(self.data, self.grad, self.state_m, self.state_v, seg_end, seg_wd, lr, betas[0], betas[1], eps,
-                self.step_count, gscale, lp=self.lp)          # also rewrites the bf16 compute copy (bf16 mode)
+        if step is None:
+            self.step_count += 1
+            step = self.step_count
+        seg_end, seg_wd = self._segments_range(decay_of, lo, hi)
+        K.adamw(self.data[lo:hi], self.grad[lo:hi], self.state_m[lo:hi], self.state_v[lo:hi], seg_end, seg_wd, lr, betas[0],
+                betas[1], eps, step, gscale, lp=None if self.lp is None else self.lp[lo:hi])   # also rewrites the bf16 compute copy
 
 
 class _Packed:

@@ -38,6 +38,7 @@ def _next_seed():
 
 # called when the ViT backward begins (= every other parameter gradient of the step is final); set by parallel.py
 on_late_backward_start = None
+on_early_grads_final = None          # ArenaAdamW.enable_backward_fusion: called right after it (same point of the backward pass)
 on_vit_block_backward = None         # leccr_amd.parallel: called with the block at the start of each ViT block's backward
 
 
@@ -343,6 +344,8 @@ class LnProjFn(torch.autograd.Function):
     def backward(ctx, dy):
         if on_late_backward_start is not None:
             on_late_backward_start()
+        if on_early_grads_final is not None:
+            on_early_grads_final()
         x, h, mean, rstd = ctx.saved_tensors
         ln_w, ln_b, proj = ctx.p
         b, N, d = x.shape

@@ -30,6 +30,42 @@ class ArenaAdamW(torch.optim.Optimizer):
         self._decay_of = decay_of_factory(weight_decay)
         self.grad_sync = None          # set by leccr_amd.parallel for W > 1
         self.grad_scale = 1.0          # 1/W under data parallelism (mean over ranks, folded into the AdamW launch)
+        self.backward_fusion = False   # enable_backward_fusion(): update the non-ViT parameters during the ViT backward
+        self._early_handles = []       # W > 1: the early region's all-reduce handles (leccr_amd.parallel)
+        self._early_updated = False
+        self._update_stream = None
+
+    def enable_backward_fusion(self):
+        """Update the arena's early region (text tower, heads, interaction: every parameter whose gradient is final when the ViT
+        backward starts) on a stream of its own WHILE the ViT backward runs, instead of after it: an HBM-bound pass beside
+        MFMA-bound GEMMs.  Only for loops in which every backward() is followed by step() (the reference's train loop;
+        bench.py) - a backward() without step() would leave those parameters updated."""
+        from . import ops
+        self.backward_fusion = True
+        ops.on_early_grads_final = self._early_update
+        return self
+
+    @torch.no_grad()
+    def _early_update(self):
+        a = self.arena
+        split = a.early_numel
+        if not self.backward_fusion or self._early_updated or not (0 < split < a.numel) or not a.data.is_cuda:
+            return
+        from . import ops
+        g = self.param_groups[0]
+        main = torch.cuda.current_stream()
+        if self._update_stream is None:
+            self._update_stream = torch.cuda.Stream(device=a.data.device)
+        us = self._update_stream
+        a.mark_autograd_grads(0, split)
+        us.wait_stream(main)                    # interaction / heads / losses backward
+        ops.join_wgrad_stream(us)               # text-tower backward and every weight-gradient launch so far
+        with torch.cuda.stream(us):
+            for w in self._early_handles:       # W > 1: the region's all-reduce
+                w.wait()
+            a.adamw_step(g['lr'], g['betas'], g['eps'], self._decay_of, self.grad_scale, 0, split, step=a.step_count + 1)
+            a.refresh(adamw_wrote_lp=True, lo=0, hi=split)
+        self._early_updated = True
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()
@@ -41,9 +77,20 @@ class ArenaAdamW(torch.optim.Optimizer):
         ops.join_wgrad_stream()
         if self.grad_sync is not None:
             self.grad_sync()
-        self.arena.mark_autograd_grads()
-        self.arena.adamw_step(g['lr'], g['betas'], g['eps'], self._decay_of, self.grad_scale)
-        self.arena.refresh(adamw_wrote_lp=True)
+        a = self.arena
+        if self._early_updated:                 # the early region was updated during the ViT backward (same step number)
+            self._early_updated = False
+            self._early_handles = []
+            torch.cuda.current_stream().wait_stream(self._update_stream)
+            split = a.early_numel
+            a.mark_autograd_grads(split, a.numel)
+            a.adamw_step(g['lr'], g['betas'], g['eps'], self._decay_of, self.grad_scale, split, a.numel)
+            a.refresh(adamw_wrote_lp=True, lo=split, hi=a.numel)
+            return
+        self._early_handles = []
+        a.mark_autograd_grads()
+        a.adamw_step(g['lr'], g['betas'], g['eps'], self._decay_of, self.grad_scale)
+        a.refresh(adamw_wrote_lp=True)
 
     def state_dict(self):
         a = self.arena

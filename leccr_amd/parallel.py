@@ -83,6 +83,7 @@ def attach_grad_sync(optimizer):
         # first ViT backward node: autograd has run the younger text-tower / interaction nodes, the early region is final
         if not pending:                       # once per step
             reduce_async(0, split)
+            optimizer._early_handles = list(pending)     # a fused early update (optim.py) waits for exactly these
 
     def vit_block(blk):
         # start of a ViT block's backward: the blocks behind it in the arena (and ln_post / proj) are final.  Their share of

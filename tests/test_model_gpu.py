@@ -264,6 +264,40 @@ def test_train_step_updates_like_reference_optimizer():
     assert abs(opt.param_groups[0]['lr'] - 1e-3 * 8 / 9) < 1e-12
 
 
+def test_optimizer_fused_into_backward_moves_parameters_identically():
+    """enable_backward_fusion(): the non-ViT part of the arena is updated on a side stream while the ViT backward runs, the ViT
+    part in step().  Three train steps (eval-mode forward: no dropout) leave the same parameters, moments and compute copies as
+    the plain optimizer, to the summation-order noise of the gradient atomics."""
+    from leccr_amd.optim import create_optimizer
+    from leccr_amd.scheduler import create_scheduler
+    z = load_npz('model_tiny_w1.npz')
+
+    def train(fused):
+        model = build(dict(clip_geometry=MODEL_VIT, text_config=TINY_BERT, compute_dtype='bf16'), weights(z))
+        opt = create_optimizer(dict(lr=1e-3, weight_decay=0.01), model)
+        if fused:
+            opt.enable_backward_fusion()
+        sched = create_scheduler(dict(sched='linear', lr=1e-3, epochs=1, step_per_epoch=10, num_warmup_steps=0.1), opt)
+        sched.step()
+        for _ in range(3):
+            losses = run(model, z)
+            opt.zero_grad()
+            sum(losses).backward()
+            opt.step()
+            sched.step()
+        from leccr_amd import ops
+        ops.on_early_grads_final = None
+        a = model.arena
+        return a.data.clone(), a.state_m.clone(), a.state_v.clone(), a.lp.clone(), a.step_count, float(losses[0])
+    pf, mf, vf, lpf, nf, lf = train(True)
+    pp, mp_, vp, lpp, np_, lp_ = train(False)
+    assert nf == np_ == 3
+    assert float((pf - pp).abs().max()) <= 2e-5 * float(pp.abs().max())
+    assert float((mf - mp_).abs().max()) <= 1e-4 * float(mp_.abs().max()) and float((vf - vp).abs().max()) <= 1e-4 * float(vp.abs().max())
+    assert float((lpf.float() - lpp.float()).abs().max()) <= 2e-2 * float(lpp.float().abs().max())
+    assert abs(lf - lp_) <= 5e-3 * max(1.0, abs(lp_))
+
+
 def test_bert_layer_dropout_matches_masked_reference():
     """Train-mode BertLayer (hidden + attention dropout 0.1): forward and input gradient equal a plain-torch layer that
     applies the SAME masks (regenerated from the kernels' counter-based RNG)."""
