@@ -55,6 +55,46 @@ def test_two_rank_losses_and_gradients_match_reference_ddp():
         assert n > 100 and not bad, (r, bad)
 
 
+def _train_worker(rank, world, port, fused, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from leccr_amd import ops
+    from leccr_amd.optim import create_optimizer
+    from leccr_amd.parallel import attach_grad_sync
+    from tests.helpers import load_npz, weights
+    from tests.test_model_gpu import MODEL_VIT, TINY_BERT, build, run
+    z1 = load_npz('model_tiny_w1.npz')
+    model = build(dict(clip_geometry=MODEL_VIT, text_config=TINY_BERT, compute_dtype='fp32'), weights(z1))
+    opt = attach_grad_sync(create_optimizer(dict(lr=1e-3, weight_decay=0.01), model))
+    if fused:
+        opt.enable_backward_fusion()
+    b = 8 // world
+    for _ in range(2):
+        losses = run(model, z1, slice(rank * b, (rank + 1) * b))
+        opt.zero_grad()
+        sum(losses).backward()
+        opt.step()
+    ops.on_early_grads_final = None
+    a = model.arena
+    ret[(fused, rank)] = (a.data.detach().cpu().numpy().copy(), a.step_count)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_training_with_the_optimizer_fused_into_backward():
+    """Two optimizer steps on 2 ranks: every all-reduce phase (early region during the ViT backward, ViT thirds, rest at step())
+    and the early parameter update behind its all-reduce give both ranks the same weights, equal to the plain optimizer's."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_train_worker, args=(2, 29671, True, ret), nprocs=2, join=True)
+    mp.spawn(_train_worker, args=(2, 29673, False, ret), nprocs=2, join=True)
+    (f0, n0), (f1, _), (p0, _), (p1, _) = ret[(True, 0)], ret[(True, 1)], ret[(False, 0)], ret[(False, 1)]
+    assert n0 == 2
+    assert np.array_equal(f0, f1) and np.array_equal(p0, p1)               # ranks stay in lock step (same summed gradients)
+    assert np.max(np.abs(f0 - p0)) <= 2e-6 * np.max(np.abs(p0))            # fused = plain (gradient atomics' order only)
+
+
 def _eval_worker(rank, world, port, ret):
     import types
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
