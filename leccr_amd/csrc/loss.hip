@@ -287,10 +287,11 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
     }
 }
 
-// The same gradient for wide rows (512 < D <= 1024: the pooled cv vectors of a ViT-L/14 tower, D = 768), where a 64-row LDS tile
-// of the other operand no longer fits: a wave owns one row (kept in LDS), each lane scores one row of the other operand straight
-// from global memory (G x D is L2-resident), then the wave walks those 64 rows in 8-row load batches with the coefficient
-// broadcast from its lane.  Always adds into zeroed output rows.
+// The same gradient for wide rows (D > 512: the pooled cv vectors of a ViT-L/14 tower, D = 768; the 4096-wide frame features of
+// the video model), where a 64-row LDS tile of the other operand no longer fits: a wave owns one row (kept in LDS), each lane
+// scores one row of the other operand straight from global memory (G x D is L2-resident) - the coefficients of the whole slice
+// (<= 512 rows: 8 per lane) stay in registers - then the wave walks the slice once per 1024-column chunk in 4-row load batches
+// with the coefficient broadcast from its lane.  Always adds into zeroed output rows.
 __global__ __launch_bounds__(256) void sim_bwd_wide_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                            const int64_t* __restrict__ idx, float inv_temp, int G, int D,
                                                            const float* __restrict__ ws, float w_r, float w_c,
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) void sim_bwd_wide_kernel(const float* __restri
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int side = blockIdx.y;
-    const int j_beg = blockIdx.z * slice, j_end = min(G, j_beg + slice);
+    const int j_beg = blockIdx.z * slice, j_end = min(G, j_beg + slice);       // slice <= 512 (launcher)
     const int i = row0 + blockIdx.x * 4 + wave;
     if (i >= row_end) return;                          // no block-wide synchronisation in this kernel
     const float* A = side == 0 ? a : b;
@@ -316,12 +317,11 @@ __global__ __launch_bounds__(256) void sim_bwd_wide_kernel(const float* __restri
     for (int j = lane; j < G; j += 64) cnt += (idx ? (idx[j] == my) : (j == i)) ? 1.f : 0.f;
     cnt = wave_sum(cnt);
     const float li = w_mine != 0.f ? lse_mine[i] : 0.f;
-    float acc[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float gs[8];
     float dt = 0.f;
-    for (int j0 = j_beg; j0 < j_end; j0 += 64) {
-        const int j = j0 + lane;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int j = j_beg + 64 * t + lane;
         float g = 0.f;
         if (j < j_end) {
             const float s = dot_lds_glb(ar, B + (int64_t)j * D, D) * inv_temp;
@@ -330,31 +330,42 @@ __global__ __launch_bounds__(256) void sim_bwd_wide_kernel(const float* __restri
             if (w_oth != 0.f) g += w_oth * (__expf(s - lse_other[j]) - lab);
             dt -= g * s;
         }
-        const int jn = min(64, j_end - j0);
+        gs[t] = g;
+    }
+    for (int c0 = 0; c0 < D; c0 += 1024) {
+        float acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int j0 = j_beg + 64 * t;
+            if (j0 >= j_end) continue;
+            const int jn = min(64, j_end - j0);
 #pragma unroll 1
-        for (int u0 = 0; u0 < jn; u0 += 4) {
-            float rv[4][16];
+            for (int u0 = 0; u0 < jn; u0 += 4) {
+                float rv[4][16];
 #pragma unroll
-            for (int uu = 0; uu < 4; ++uu) {
-                const float* row = B + (int64_t)min(j0 + u0 + uu, G - 1) * D;
+                for (int uu = 0; uu < 4; ++uu) {
+                    const float* row = B + (int64_t)min(j0 + u0 + uu, G - 1) * D + c0;
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const int d = lane + 64 * q;
-                    rv[uu][q] = d < D ? row[d] : 0.f;
+                    for (int q = 0; q < 16; ++q) {
+                        const int d = lane + 64 * q;
+                        rv[uu][q] = c0 + d < D ? row[d] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int uu = 0; uu < 4; ++uu) {
+                    const float gu = __shfl(gs[t], u0 + uu);               // lanes past jn hold g = 0
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc[q] = fmaf(gu, rv[uu][q], acc[q]);
                 }
             }
-#pragma unroll
-            for (int uu = 0; uu < 4; ++uu) {
-                const float gu = __shfl(g, u0 + uu);               // lanes past jn hold g = 0
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = fmaf(gu, rv[uu][q], acc[q]);
-            }
         }
-    }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int d = lane + 64 * q;
-        if (d < D) atomicAdd(out + (int64_t)i * D + d, acc[q] * inv_temp);
+        for (int q = 0; q < 16; ++q) {
+            const int d = c0 + lane + 64 * q;
+            if (d < D) atomicAdd(out + (int64_t)i * D + d, acc[q] * inv_temp);
+        }
     }
     if (side == 0 && dtemp) {
         dt = wave_sum(dt);
@@ -867,7 +878,7 @@ extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64
 extern "C" int leccr_sim_infonce_bwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
                                      int both_dirs, const float* ws, float gscale, float* da, float* db, float* dtemp,
                                      int64_t row0, int64_t nrows, void* stream) {
-    LECCR_REQUIRE(a && b && ws && da && db && G > 0 && D > 0 && D <= 1024 && (D & 3) == 0, LECCR_EINVAL, "sim_infonce_bwd: bad argument (D <= 1024)");
+    LECCR_REQUIRE(a && b && ws && da && db && G > 0 && D > 0 && D <= 8192 && (D & 3) == 0, LECCR_EINVAL, "sim_infonce_bwd: bad argument (D <= 8192)");
     LECCR_REQUIRE(row0 >= 0 && nrows > 0 && row0 + nrows <= G, LECCR_EINVAL, "sim_infonce_bwd: row range outside [0, G)");
     hipStream_t st = as_stream(stream);
     const float w_r = gscale * (both_dirs ? 0.5f / G : 1.f / G), w_c = both_dirs ? w_r : 0.f;
@@ -883,9 +894,11 @@ extern "C" int leccr_sim_infonce_bwd(const float* a, const float* b, const int64
                                     hipMemsetAsync(db + row0 * D, 0, sizeof(float) * nrows * D, st) != hipSuccess))
         return check_launch("sim_infonce_bwd memset");
     if (D > 512) {
-        hipLaunchKernelGGL(sim_bwd_wide_kernel, dim3((unsigned)cdiv(nrows, 4), 2, (unsigned)nslice), dim3(256),
+        const int wslice = slice > 512 ? 512 : slice;                  // the wide kernel keeps a slice's coefficients in 8 registers
+        (void)hipFuncSetAttribute((const void*)sim_bwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(sim_bwd_wide_kernel, dim3((unsigned)cdiv(nrows, 4), 2, (unsigned)cdiv(G, wslice)), dim3(256),
                            (size_t)4 * D * sizeof(float), st, a, b, idx, 1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp,
-                           (int)row0, (int)(row0 + nrows), slice);
+                           (int)row0, (int)(row0 + nrows), wslice);
         return check_launch("sim_infonce_bwd");
     }
     hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(nrows, 4), 2, (unsigned)nslice), dim3(256), lds_b, st, a, b, idx,

@@ -286,7 +286,7 @@ def _unit(shape, seed):
 
 @pytest.mark.parametrize('G,D,use_idx,both', [(6, 16, True, True), (70, 256, True, True), (256, 256, False, True),
                                               (130, 512, True, False), (33, 64, False, False), (70, 768, True, False),
-                                              (40, 1024, False, True)])
+                                              (40, 1024, False, True), (600, 4096, True, False)])
 def test_sim_infonce(K, G, D, use_idx, both):
     a, b = _unit((G, D), 70), _unit((G, D), 71)
     idx = torch.arange(G)

@@ -427,17 +427,19 @@ def test_video_reference_fixture_forward_backward_f32():
     assert n > 90 and not bad, bad[:8]
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_video_production_kernels_vs_oracle(dtype):
-    """vision_width 512 (8 heads of 64: the MFMA attention and GEMM kernels), 8 frames, ragged clips, vs the CPU oracle."""
+@pytest.mark.parametrize('dtype,vw,vl', [('fp32', 512, 2), ('bf16', 512, 2), ('fp32', 4096, 1), ('bf16', 4096, 1)])
+def test_video_production_kernels_vs_oracle(dtype, vw, vl):
+    """vision_width 512 (8 heads of 64: the MFMA attention and GEMM kernels) and the reference's MSR-VTT geometry (4096-wide
+    frame features, one SelfAttention layer, 8 heads of 512: the generic attention kernel, the wide contrastive backward),
+    8 frames, ragged clips, vs the CPU oracle."""
     from oracle import leccr_oracle as O
-    model = build_video(dict(text_config=MID_BERT, compute_dtype=dtype, embed_dim=256, vision_width=512, vision_layer=2),
+    model = build_video(dict(text_config=MID_BERT, compute_dtype=dtype, embed_dim=256, vision_width=vw, vision_layer=vl),
                         seed=5)
     with torch.no_grad():
         model.queries.normal_(0, 0.5)
-    b, F = 16, 8
+    b, F = (16 if vw == 512 else 8), 8
     g = torch.Generator().manual_seed(11)
-    video = torch.randn(b, F, 512, generator=g)
+    video = torch.randn(b, F, vw, generator=g)
     lens = torch.randint(3, F + 1, (b,), generator=g)
     lens[0] = F
     vmask = torch.arange(F)[None] < lens[:, None]
@@ -470,7 +472,12 @@ def test_video_production_kernels_vs_oracle(dtype):
         if rn < 1e-6 * gmax:
             continue
         rel = err / rn
-        ok = rel <= 1e-3 if dtype == 'fp32' else ((rel <= 0.15 and cos >= 0.985) if rn >= 1e-2 * gmax else (rel <= 0.7 and cos >= 0.8))
+        # bf16: 4096-long reductions carry ~8x the rounding noise of 64-long ones: the small-gradient class is looser there, and
+        # gradients under a thousandth of the largest are below that noise floor
+        if dtype == 'bf16' and vw > 512 and rn < 1e-3 * gmax:
+            continue
+        weak = (rel <= 0.7 and cos >= 0.8) if vw == 512 else (rel <= 1.5 and cos >= 0.6)
+        ok = rel <= 1e-3 if dtype == 'fp32' else ((rel <= 0.15 and cos >= 0.985) if rn >= 1e-2 * gmax else weak)
         if not ok:
             bad.append((name, rel, cos, rn))
     assert not bad, bad[:8]
