@@ -100,6 +100,15 @@ def cpu_baseline(args, cfg):
 
 
 def main():
+    # stdout carries exactly one line - the result JSON of rank 0; the reference-style "### ..." notices of create_optimizer /
+    # create_scheduler and any library chatter go to stderr
+    import contextlib
+    real_stdout = sys.stdout
+    with contextlib.redirect_stdout(sys.stderr):
+        _main(real_stdout)
+
+
+def _main(real_stdout):
     args = parse()
     from leccr_amd import _lib
     from leccr_amd.optim import create_optimizer
@@ -187,7 +196,7 @@ def main():
                                    f'(global {G}), L_t=32, L_c=64, train mode (dropout 0.1 on), full step (fwd+bwd+all-gather+all-reduce+AdamW)',
                        'global_batch': G, 'parallelism': f'dp{world}',
                        'step_tflops_algorithmic': round(F_PAIR_GFLOP * value / 1e3, 1) if args.clip == 'ViT-B/16' else None,
-                       'losses': [round(float(l), 4) for l in losses]},
+                       'losses': [round(float(l.detach()), 4) for l in losses]},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm256_kernel (bf16 256x256x64 MFMA GEMM: NT forward/dX + TN weight-gradient instantiations)',
                          'achieved': round(achieved, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
@@ -207,7 +216,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cfg)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
