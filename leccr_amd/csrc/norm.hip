@@ -1,5 +1,5 @@
 // norm.hip - LayerNorm forward/backward, row L2-normalise forward/backward, column sums (bias gradients).
-// All HBM-bound: one wave64 per row, 16-byte (f32) / 8-byte (bf16) vector accesses, statistics in f32,
+// All HBM-bound: one wave64 per row (bf16: one or two rows with 16-byte accesses where the width allows), statistics in f32,
 // wave-shuffle reductions (no LDS for the row statistics).
 #include "common.h"
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             if (c < d) {
                 f32x4 o = (gy[i] - s1 - xh[i] * s2) * rs;
                 if (dres) {
-                    const f32x4 r = load4(dres + row * d + c);
+                    const f32x4 r = load4(dres + row * d + c);     // (prefetching it with dy / x costs occupancy: measured slower)
                     o += r;
                     if (colsum_of == 1) dc[i] += r;
                 }
@@ -138,6 +138,129 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         float* out = pass == 0 ? dgamma : pass == 1 ? dbeta : colsum;
         for (int c = threadIdx.x; c < d; c += 256) atomicAdd(out + c, red[c]);
     }
+}
+
+// ---- bf16 rows with 16-byte accesses.  8 bf16 per lane and access instead of 4: 8-byte accesses stream at 0.54-0.70x the
+// 16-byte rate on this chip (the 4-element kernels above measure 3.9-4.0 TB/s on [147712, 768]).  A row is C = d / 8 chunks;
+// a wave owns R consecutive rows such that R C = 64 NS: lane l of slot s holds chunk (64 s + l) % C of row (64 s + l) / C
+// (d = 768: two rows in three slots; d = 512 / 1024: one row in one / two slots; d = 256: two rows in one slot).
+template <int NS, int R>
+struct Rows16 {
+    int col[NS];      // first column of this lane's chunk in slot s
+    int rsel[NS];     // which of the wave's R rows it belongs to
+    __device__ __forceinline__ void init(int lane, int C) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int flat = 64 * s + lane;
+            rsel[s] = R == 1 ? 0 : (flat >= C ? 1 : 0);
+            col[s] = (flat - rsel[s] * C) * 8;
+        }
+    }
+};
+
+__device__ __forceinline__ void load8f(const bf16_t* p, float (&v)[8]) {
+    const bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+}
+__device__ __forceinline__ void store8f(bf16_t* p, const float (&v)[8]) {
+    bf16x8 t;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = (bf16_t)v[j];
+    *reinterpret_cast<bf16x8*>(p) = t;
+}
+
+template <int NS, int R>
+__global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ add,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              bf16_t* __restrict__ y, bf16_t* __restrict__ sum_out,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
+                                                              int d, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
+    Rows16<NS, R> m;
+    m.init(lane, d >> 3);
+    float v[NS][8];
+    float ps[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) ps[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int64_t row = row0 + m.rsel[s];
+        float t = 0.f;
+        if (row < rows) {
+            const int64_t o = row * d + m.col[s];
+            load8f(x + o, v[s]);
+            if (add) {
+                float a[8];
+                load8f(add + o, a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[s][j] += a[j];
+            }
+            if (sum_out) {           // normalise exactly what is stored (and later handed to the backward as x_in)
+                store8f(sum_out + o, v[s]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[s][j] = (float)(bf16_t)v[s][j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t += v[s][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[s][j] = 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) ps[r] += m.rsel[s] == r ? t : 0.f;
+    }
+    float mu[R], rs[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) mu[r] = wave_sum(ps[r]) / d;
+#pragma unroll
+    for (int r = 0; r < R; ++r) ps[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const float mm = R == 1 ? mu[0] : (m.rsel[s] ? mu[R - 1] : mu[0]);
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float c = v[s][j] - mm;
+            t += c * c;
+        }
+        if (row0 + m.rsel[s] >= rows) t = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) ps[r] += m.rsel[s] == r ? t : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) rs[r] = rsqrtf(wave_sum(ps[r]) / d + eps);
+    if (lane < R && row0 + lane < rows) {
+        mean[row0 + lane] = lane == 0 ? mu[0] : mu[R - 1];
+        rstd[row0 + lane] = lane == 0 ? rs[0] : rs[R - 1];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int64_t row = row0 + m.rsel[s];
+        if (row >= rows) continue;
+        const float mm = R == 1 ? mu[0] : (m.rsel[s] ? mu[R - 1] : mu[0]), rr = R == 1 ? rs[0] : (m.rsel[s] ? rs[R - 1] : rs[0]);
+        const f32x4 g0 = load4(gamma + m.col[s]), g1 = load4(gamma + m.col[s] + 4);
+        const f32x4 b0 = load4(beta + m.col[s]), b1 = load4(beta + m.col[s] + 4);
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[j] = (v[s][j] - mm) * rr * g0[j] + b0[j];
+            o[4 + j] = (v[s][4 + j] - mm) * rr * g1[j] + b1[j];
+        }
+        store8f(y + row * d + m.col[s], o);
+    }
+}
+
+// (R, NS) of the 16-byte forward kernel for a row of d bf16, or false: the 4-element kernel takes the shape.  (A backward with
+// the same mapping needs 150-216 registers for its three sets of column partials and measured slower than the 4-element one.)
+static bool rows16_shape(int64_t d, int* R, int* NS) {
+    if (d & 7) return false;
+    const int64_t C = d >> 3;
+    if (C % 64 == 0 && C / 64 <= 4) { *R = 1; *NS = (int)(C / 64); return true; }
+    if ((2 * C) % 64 == 0 && C < 64 * 3 && 2 * C / 64 <= 5) { *R = 2; *NS = (int)(2 * C / 64); return true; }
+    return false;
 }
 
 template <typename T>
@@ -202,6 +325,20 @@ template <typename T>
 static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                            void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
                            hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        int R = 0, NS = 0;
+        if (rows16_shape(d, &R, &NS)) {
+            dim3 g16((unsigned)cdiv(cdiv(rows, R), 4));
+#define F16(NS_, R_)                                                                                                     \
+    hipLaunchKernelGGL((layernorm_fwd16_kernel<NS_, R_>), g16, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)add, gamma,  \
+                       beta, (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)d, eps)
+            if (R == 1 && NS == 1) F16(1, 1); else if (R == 1 && NS == 2) F16(2, 1); else if (R == 1 && NS == 3) F16(3, 1);
+            else if (R == 1 && NS == 4) F16(4, 1); else if (R == 2 && NS == 1) F16(1, 2); else if (R == 2 && NS == 3) F16(3, 2);
+            else if (R == 2 && NS == 5) F16(5, 2); else R = 0;
+#undef F16
+            if (R) return check_launch("layernorm_fwd");
+        }
+    }
     dim3 grid((unsigned)cdiv(rows, 4));
 #define L(N)                                                                                                      \
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, (const T*)add, gamma, beta, \
