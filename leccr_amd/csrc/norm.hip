@@ -321,6 +321,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     if (nn < N) atomicAdd(out + nn, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
+// bf16 with 16-byte accesses: block = 32 column-octets x 8 row phases (N % 8 == 0, ldx % 8 == 0)
+__global__ __launch_bounds__(256) void colsum16_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int64_t M, int64_t N,
+                                                       int64_t ldx, int rows_per_block) {
+    __shared__ float red[8][256 + 8];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t n = ((int64_t)blockIdx.x * 32 + tx) * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        const bf16_t* p = x + n;
+        int64_t m = r0 + ty;
+        for (; m + 8 < r1; m += 16) {                 // two independent loads per iteration
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + m * ldx), b = *reinterpret_cast<const bf16x8*>(p + (m + 8) * ldx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)a[j] + (float)b[j];
+        }
+        for (; m < r1; m += 8) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(p + m * ldx);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += (float)a[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[ty][tx * 8 + j] = acc[j];
+    __syncthreads();
+    const int c = threadIdx.x;
+    const int64_t nn = (int64_t)blockIdx.x * 256 + c;
+    if (nn < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][c];
+        atomicAdd(out + nn, t);
+    }
+}
+
 template <typename T>
 static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                            void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
@@ -430,6 +467,12 @@ static int cs(const void* x, float* out, int64_t M, int64_t N, int64_t ldx, hipS
     int rpb = 256;
     while ((int64_t)cdiv(M, rpb) * cdiv(N, 256) > 4096) rpb *= 2;
     dim3 grid((unsigned)cdiv(N, 256), (unsigned)cdiv(M, rpb));
+    if constexpr (sizeof(T) == 2) {
+        if ((N & 7) == 0 && (ldx & 7) == 0) {
+            hipLaunchKernelGGL(colsum16_kernel, grid, dim3(256), 0, st, (const bf16_t*)x, out, M, N, ldx, rpb);
+            return check_launch("colsum");
+        }
+    }
     hipLaunchKernelGGL((colsum_kernel<T>), grid, dim3(256), 0, st, (const T*)x, out, M, N, ldx, rpb);
     return check_launch("colsum");
 }
