@@ -88,10 +88,23 @@ __global__ __launch_bounds__(256) void axpy_kernel(const T* __restrict__ x, T* _
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, DropCfg d) {
+__global__ __launch_bounds__(256) void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, DropCfg d,
+                                                      int64_t base) {      // element i of this call is element base + i of the tensor
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-        y[i] = from_f32<T>(to_f32(x[i]) * drop_mul(d, (uint32_t)i));
+        y[i] = from_f32<T>(to_f32(x[i]) * drop_mul(d, (uint32_t)(base + i)));
+}
+
+// bf16, 16 bytes per lane: 8 consecutive elements per thread (the mask of element i depends on i only: same masks as above)
+__global__ __launch_bounds__(256) void dropout8_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t n8, DropCfg d) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n8; q += stride) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(x + q * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)v[j] * drop_mul(d, (uint32_t)(q * 8 + j)));
+        *reinterpret_cast<bf16x8*>(y + q * 8) = o;
+    }
 }
 
 static unsigned stream_grid(int64_t n_items) {
@@ -177,8 +190,17 @@ extern "C" int leccr_dropout(const void* x, void* y, int64_t n, float p, uint64_
     LECCR_REQUIRE(n < (1ll << 32), LECCR_EINVAL, "dropout: more than 2^32 elements");
     if (n == 0) return LECCR_OK;
     const DropCfg d = make_drop(p, seed);
-    if (dtype == LECCR_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, n, d);
-    else if (dtype == LECCR_BF16) hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), (const bf16_t*)x, (bf16_t*)y, n, d);
+    if (dtype == LECCR_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, n, d, (int64_t)0);
+    else if (dtype == LECCR_BF16) {
+        const bf16_t *xb = (const bf16_t*)x;
+        bf16_t* yb = (bf16_t*)y;
+        int64_t n8 = (((uintptr_t)x | (uintptr_t)y) & 15) == 0 ? n / 8 : 0;          // 16-byte part, then the scalar tail
+        if (n8) hipLaunchKernelGGL(dropout8_kernel, dim3(stream_grid(n8)), dim3(256), 0, as_stream(stream), xb, yb, n8, d);
+        if (n8 * 8 < n) {
+            hipLaunchKernelGGL((dropout_kernel<bf16_t>), dim3(stream_grid(n - n8 * 8)), dim3(256), 0, as_stream(stream), xb + n8 * 8,
+                               yb + n8 * 8, n - n8 * 8, d, n8 * 8);
+        }
+    }
     else { set_error("dropout: bad dtype"); return LECCR_EINVAL; }
     return check_launch("dropout");
 }

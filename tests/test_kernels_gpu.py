@@ -591,6 +591,12 @@ def test_dropout_mask_is_counter_based(K):
     y3 = K.dropout(x, 0.1, 1235)
     assert float(((y1 != 0) == (y3 != 0)).float().mean()) < 0.85     # a different seed decorrelates (0.82 expected)
     assert torch.equal(K.dropout(x, 0.0, 7), x)
+    # bf16 (16-byte kernel + scalar tail, and a misaligned view: scalar kernel only): the same element -> mask mapping as f32
+    xb = torch.ones(8 * 4000 + 13, device=DEV, dtype=torch.bfloat16)
+    want = (K.dropout(torch.ones(xb.numel(), device=DEV), 0.1, 1234) != 0)
+    assert torch.equal(K.dropout(xb, 0.1, 1234) != 0, want)
+    xv = torch.ones(8 * 500 + 3, device=DEV, dtype=torch.bfloat16)[1:]
+    assert torch.equal(K.dropout(xv.contiguous(), 0.1, 99) != 0, K.dropout(torch.ones(xv.numel(), device=DEV), 0.1, 99) != 0)
 
 
 @pytest.mark.parametrize('Lq,Lk', [(70, 50), (40, 72)])        # short (<= 16 rows) last query tile / last key tile
