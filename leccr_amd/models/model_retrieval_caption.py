@@ -121,23 +121,30 @@ class RetrievalModel(XVLMBase):
             return x if x.shape[1] == L else torch.nn.functional.pad(x, (0, L - x.shape[1]))
         cap_ids, cap_atts = captions.input_ids, captions.attention_mask
 
-        def text_side():
+        def caption_side():
             with torch.no_grad():
-                cap_h = self.get_caption_embeds(cap_ids, cap_atts)
+                return self.get_caption_embeds(cap_ids, cap_atts)
+
+        def text_side():
             hid = self.get_text_embeds(torch.cat([pad(ids_s), pad(ids_t)], 0), torch.cat([pad(atts_s), pad(atts_t)], 0))
-            return cap_h, self.get_features(None, hid)     # padded key positions are masked: [CLS] rows are unchanged
+            return self.get_features(None, hid)             # padded key positions are masked: [CLS] rows are unchanged
 
         # The image tower first (program order = the order the reference runs them; the text towers' autograd nodes are the
         # younger ones, so backward enqueues them first), the two BERT passes beside it on the text stream when enabled.
         ori_image, _ = self.get_vision_embeds(image)
         ts = ops.text_stream(image.device)
         if ts is None:
-            cap_hidden, feats = text_side()
+            cap_hidden, feats = caption_side(), text_side()
         else:
             main = torch.cuda.current_stream()
+            cs = ops.caption_stream(image.device) or ts      # the forward-only caption pass on a stream of its own
+            cs.wait_stream(main)
             ts.wait_stream(main)
+            with torch.cuda.stream(cs):
+                cap_hidden = caption_side()
             with torch.cuda.stream(ts):
-                cap_hidden, feats = text_side()
+                feats = text_side()
+            main.wait_stream(cs)
             main.wait_stream(ts)
             cap_hidden.record_stream(main)
             feats.record_stream(main)

@@ -87,6 +87,20 @@ def text_stream(device):
     return _text_stream
 
 
+_caption_stream = None
+
+
+def caption_stream(device):
+    """A further stream for the caption-BERT forward (no gradient, so nothing of the backward pass runs on it), or None
+    (LECCR_CAP_STREAM=0): the two BERT forwards then overlap each other as well as the image tower (+1.3 % on the step)."""
+    global _caption_stream
+    if os.environ.get('LECCR_CAP_STREAM', '1') == '0' or torch.device(device).type != 'cuda':
+        return None
+    if _caption_stream is None:
+        _caption_stream = torch.cuda.Stream(device=device)
+    return _caption_stream
+
+
 def side_streams():
     return [s for s in (_wgrad_stream, _text_stream) if s is not None]
 
