@@ -41,6 +41,9 @@ int leccr_set_gemm_variant(int v);             /* 0 auto (default), 1 force the 
 int leccr_set_gemm_max_blocks(int n);          /* workgroups (= CUs) a persistent 256x256 GEMM launch may use: 0 / 256 = all
                                                 * (default); rounded down to a multiple of 8; returns the value in effect.
                                                 * leccr_amd.parallel lowers it while an all-reduce overlaps the backward pass */
+int leccr_get_gemm_max_blocks(void);
+int leccr_set_gemm_max_blocks_for(int n, int64_t launches);   /* the same limit for the next `launches` persistent-GEMM launches
+                                                * only, after which all CUs are used again (the expected duration of a collective) */
 int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_gemm launched: 0 generic, 1 MFMA 128x128,
                                                 * 2 MFMA 256x256 (8 waves), 3 MFMA 256x256 (4 waves); tests use it */
 int leccr_prof_enable(int on);

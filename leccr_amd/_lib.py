@@ -31,6 +31,8 @@ _SIGS = {
     'leccr_set_gemm_variant': ([C.c_int], C.c_int),
     'leccr_last_gemm_kernel': ([], C.c_int),
     'leccr_set_gemm_max_blocks': ([C.c_int], C.c_int),
+    'leccr_set_gemm_max_blocks_for': ([C.c_int, C.c_int64], C.c_int),
+    'leccr_get_gemm_max_blocks': ([], C.c_int),
     'leccr_prof_enable': ([C.c_int], C.c_int),
     'leccr_prof_read': ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
     'leccr_prof_read_union': ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),

@@ -351,7 +351,7 @@ bool gemm256_wanted(const leccr_gemm_params& p);
 bool gemm256_legal(const leccr_gemm_params& p);
 bool gemm256_fuses_colsum(const leccr_gemm_params& p);
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
-void gemm256_set_max_blocks(int n);
+void gemm256_set_max_blocks(int n, int64_t launches);
 int gemm256_max_blocks();
 bool gemm256w4_legal(const leccr_gemm_params& p);
 int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st);
@@ -369,7 +369,14 @@ extern "C" int leccr_debug_set_stamps(void* p) {      // diagnostic builds (-DLE
 extern "C" int leccr_last_gemm_kernel(void) { return g_last_kernel; }
 
 extern "C" int leccr_set_gemm_max_blocks(int n) {
-    gemm256_set_max_blocks(n);
+    gemm256_set_max_blocks(n, -1);
+    return gemm256_max_blocks();
+}
+
+extern "C" int leccr_get_gemm_max_blocks(void) { return gemm256_max_blocks(); }
+
+extern "C" int leccr_set_gemm_max_blocks_for(int n, int64_t launches) {
+    gemm256_set_max_blocks(n, launches < 1 ? 1 : launches);
     return gemm256_max_blocks();
 }
 

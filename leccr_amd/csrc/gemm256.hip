@@ -853,12 +853,20 @@ void gemm256_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
 // second round (2x the time).  While a gradient all-reduce overlaps the backward pass, leccr_amd.parallel lowers this to
 // 256 - (CUs left to RCCL); always a multiple of 8 (XCD-contiguous item lists).
 static int g_max_blocks = 256;
-void gemm256_set_max_blocks(int n) { g_max_blocks = n <= 0 || n > 256 ? 256 : (n < 8 ? 8 : n & ~7); }
+static int64_t g_max_blocks_launches = -1;       // >= 0: launches left before the limit lapses by itself
+void gemm256_set_max_blocks(int n, int64_t launches) {
+    g_max_blocks = n <= 0 || n > 256 ? 256 : (n < 8 ? 8 : n & ~7);
+    g_max_blocks_launches = g_max_blocks == 256 ? -1 : launches;
+}
 int gemm256_max_blocks() { return g_max_blocks; }
 
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     using namespace g256;
     const int cap = g_max_blocks;
+    if (g_max_blocks_launches > 0 && --g_max_blocks_launches == 0) {       // this is the last limited launch
+        g_max_blocks = 256;
+        g_max_blocks_launches = -1;
+    }
     Args a{};
     a.stamps = g_stamps;
     a.A = (const bf16_t*)p.A; a.B = (const bf16_t*)p.B; a.C = p.C;

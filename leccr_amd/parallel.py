@@ -59,6 +59,20 @@ def attach_grad_sync(optimizer):
         rccl_cus = _RCCL_CUS
     rccl_cus = max(0, min(rccl_cus, 128)) if grad.is_cuda and dist.get_backend() == 'nccl' else 0
 
+    # How long the limit stays on after an all-reduce is handed to RCCL: its expected duration at a deliberately low ring
+    # bandwidth (LECCR_RCCL_GBPS, default 60 GB/s of bus bandwidth), in persistent-GEMM launches of the ViT backward (about 8 per
+    # 6 ms block over the two streams = 1.3 per ms), with a 1.5x margin.  Past it the GEMMs use every CU again.
+    try:
+        ring_gbps = float(os.environ.get('LECCR_RCCL_GBPS', 60))
+    except ValueError:
+        ring_gbps = 60.0
+
+    def limit_gemms_for(nbytes):
+        if rccl_cus:
+            from . import _lib
+            ms = nbytes * 2.0 * (world - 1) / world / (ring_gbps * 1e6)
+            _lib.lib().leccr_set_gemm_max_blocks_for(256 - rccl_cus, int(ms * 1.3 * 1.5) + 2)
+
     def gemm_cus(n):
         if rccl_cus:
             from . import _lib
@@ -68,7 +82,7 @@ def attach_grad_sync(optimizer):
         """All launches that write grad[lo:hi] are enqueued (on the main, text and weight-gradient streams): a stream of its own
         waits for the three and hands the all-reduces to RCCL, so the main stream goes straight on with the backward pass."""
         if grad.is_cuda:
-            gemm_cus(256 - rccl_cus)          # from here to optimizer.step() the GEMM launches leave RCCL its CUs
+            limit_gemms_for((hi - lo) * 4)    # while this all-reduce is expected to run, the GEMM launches leave RCCL its CUs
             if not reduce_stream:
                 reduce_stream.append(torch.cuda.Stream(device=grad.device))
             rs = reduce_stream[0]

@@ -557,6 +557,12 @@ def test_gemm256_with_fewer_workgroups(K):
         o240 = K.gemm(a, b)
         w240 = torch.zeros(768, 1024, device=DEV)
         K.gemm(dy, x, trans_a=True, trans_b=True, out=w240, accumulate=True)
+        # the limit for a number of launches only (the expected duration of a collective): it lapses by itself
+        assert lib.leccr_set_gemm_max_blocks_for(240, 2) == 240
+        K.gemm(a, b)
+        assert lib.leccr_get_gemm_max_blocks() == 240
+        K.gemm(a, b)
+        assert lib.leccr_get_gemm_max_blocks() == 256
     finally:
         assert lib.leccr_set_gemm_max_blocks(0) == 256
     o256 = K.gemm(a, b)
