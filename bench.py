@@ -165,6 +165,7 @@ def _main(real_stdout):
     ms1, work1, n1 = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
     if args.roofline_steps > 0:
         overlap, ops.wgrad_overlap, ops.text_overlap = (ops.wgrad_overlap, ops.text_overlap), False, False
+        fusion, opt.backward_fusion = opt.backward_fusion, False
         barrier()
         lib.leccr_prof_enable(1)
         for _ in range(args.roofline_steps):
@@ -173,6 +174,7 @@ def _main(real_stdout):
         lib.leccr_prof_enable(0)
         lib.leccr_prof_read(ms1, work1, n1)
         ops.wgrad_overlap, ops.text_overlap = overlap
+        opt.backward_fusion = fusion
     if rank == 0:
         G = args.batch * world
         value = G * args.steps / dt
