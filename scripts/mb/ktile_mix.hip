@@ -113,7 +113,7 @@ __global__ __launch_bounds__(512, 2) void mix(const char* __restrict__ src, floa
 
 // The alternative block shape for the same 256x256x64 K-tile: 4 waves (one per SIMD), wave tile 128x128 = 16 accumulators of
 // v_mfma_f32_32x32x16_bf16 (256 accumulator registers), per wave and iteration 64 MFMAs + 32 ds_read_b128 + 16 DMA pieces.
-template <bool READS, bool DMA, int BARS>
+template <bool READS, bool DMA, int BARS, int SHAPE = 0>
 __global__ __launch_bounds__(256) void mix4(const char* __restrict__ src, float* __restrict__ out, int iters, size_t span) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -128,10 +128,13 @@ __global__ __launch_bounds__(256) void mix4(const char* __restrict__ src, float*
     const char* g = src + ((size_t)blockIdx.x * 65536 + (size_t)tid * 16) % span;
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     f32x16 acc[16];
+    f32x4 acc4[64];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 fa[8], fb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { fa[i] = lds_b128<0>(rd + i * 2048); fb[i] = lds_b128<64>(rd + i * 2048); }
@@ -140,7 +143,12 @@ __global__ __launch_bounds__(256) void mix4(const char* __restrict__ src, float*
         const uint32_t slot = (it & 1) * 65536;
 #pragma unroll
         for (int i = 0; i < 64; ++i) {
-            acc[i & 15] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i & 7], fa[(i >> 1) & 7], acc[i & 15], 0, 0, 0);
+            if constexpr (SHAPE == 0) {
+                acc[i & 15] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[i & 7], fa[(i >> 1) & 7], acc[i & 15], 0, 0, 0);
+            } else {     // the same K-tile as 128 x 16x16x32: two per filler slot
+                acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[i & 7], fa[(i >> 3) & 7], acc4[i], 0, 0, 0);
+                acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[(i + 1) & 7], fa[(i >> 3) & 7], acc4[i], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (READS && i < 32) {
                 if (i < 16) fa[i & 7] = lds_b128<0>(rd + slot + (i & 7) * 2048 + (i >> 3) * 64);
@@ -167,6 +175,8 @@ __global__ __launch_bounds__(256) void mix4(const char* __restrict__ src, float*
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += acc[i][0];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) s += acc4[i][0];
     if (s == 12345.f) out[tid] = s;
     if (tid == 0) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(out) + 512 + blockIdx.x * 4;
@@ -177,9 +187,9 @@ __global__ __launch_bounds__(256) void mix4(const char* __restrict__ src, float*
     }
 }
 
-template <bool R, bool D, int B>
+template <bool R, bool D, int B, int SHAPE = 0>
 static void run4(const char* name, const char* src, float* out, size_t span) {
-    auto k = mix4<R, D, B>;
+    auto k = mix4<R, D, B, SHAPE>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     const int iters = 2000;
     hipEvent_t e0, e1;
@@ -265,5 +275,9 @@ int main(int argc, char** argv) {
     run4<true, true, 0>("4 waves: + reads + 16 DMA", src, out, span);
     run4<true, true, 2>("4 waves: + reads + DMA + 2 barriers", src, out, span);
     run4<true, true, 1>("4 waves: + reads + DMA + 1 barrier (vmcnt 0)", src, out, span);
+    run4<false, false, 0, 1>("4 waves 16x16x32 x128, MFMA only", src, out, span);
+    run4<true, false, 0, 1>("4 waves 16x16x32: + 32 reads", src, out, span);
+    run4<true, true, 0, 1>("4 waves 16x16x32: + reads + 16 DMA", src, out, span);
+    run4<true, true, 1, 1>("4 waves 16x16x32: + reads + DMA + 1 barrier", src, out, span);
     return 0;
 }
