@@ -198,7 +198,8 @@ def _main(real_stdout):
                                    f'(global {G}), L_t=32, L_c=64, train mode (dropout 0.1 on), full step (fwd+bwd+all-gather+all-reduce+AdamW)',
                        'global_batch': G, 'parallelism': f'dp{world}',
                        'step_tflops_algorithmic': round(F_PAIR_GFLOP * value / 1e3, 1) if args.clip == 'ViT-B/16' else None,
-                       'losses': [round(float(l.detach()), 4) for l in losses]},
+                       'losses': [round(float(l.detach()), 4) for l in losses],
+                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm256_kernel (bf16 256x256x64 MFMA GEMM: NT forward/dX + TN weight-gradient instantiations)',
                          'achieved': round(achieved, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
