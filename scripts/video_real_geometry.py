@@ -1,5 +1,7 @@
+"""The video model at the reference's MSR-VTT geometry (configs/cclm-base-ft/Retrieval_msrvtt.yaml:36-37: 4096-wide frame features, one
+SelfAttention layer): three synthetic train steps of batch 32 on one MI355X.  usage: video_real_geometry.py [bf16|fp32]"""
 import sys, os
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from leccr_amd.models.video_model_retrieval_caption import RetrievalModel
 from leccr_amd.synthetic import VATEX_CFG, make_video_batch
