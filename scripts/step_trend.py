@@ -1,4 +1,5 @@
-"""Per-step wall time of the bench workload from a cold start (is the warm-up long enough?)."""
+"""Per-step wall time and allocator state of the bench workload from a cold start (is the warm-up long enough?  does memory
+grow with the step count - side streams, record_stream, the gather cache?)."""
 import sys, time, torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,13 +12,16 @@ from leccr_amd.scheduler import create_scheduler
 from leccr_amd.synthetic import make_batch
 dev = torch.device('cuda', 0)
 model, cfg = bench.build_model(args, dev)
-opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model))
+opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model)).enable_backward_fusion()
 sched = create_scheduler(dict(cfg['schedular'], step_per_epoch=1000), opt)
 cpu = make_batch(args.batch)
 batch = {'image': cpu['image'].to(dev), 'text': [t.to(dev) for t in cpu['text']], 'captions': cpu['captions'].to(dev), 'idx': cpu['idx'].to(dev)}
 ts = []
-for i in range(16):
+n = int(os.environ.get('STEPS', 48))
+for i in range(n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     bench.train_step(model, batch, opt, sched)
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
-print(' '.join(f'{t:.1f}' for t in ts))
+    if i % 8 == 7:
+        print(f'step {i + 1:3d}: last 8 steps ' + ' '.join(f'{t:.1f}' for t in ts[-8:]) +
+              f' ms | allocated {torch.cuda.memory_allocated() / 2**30:.2f} GiB reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB', flush=True)
