@@ -61,9 +61,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // Backward.  Grid-stride over rows so each wave accumulates its dgamma/dbeta partials in registers; one LDS reduce
-// per block and one f32 atomic per (block, column).
-template <typename T, int NCH>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xin,
+// per block and one f32 atomic per (block, column).  gamma is re-read per row (L1-resident) and the colsum partials exist only
+// in the CS instantiation: the kernel is bound by how many rows are in flight, i.e. by waves per SIMD (94 registers: 5 waves;
+// 106 with the colsum partials: 4 waves - forcing 5 there spills and costs 75 %).
+template <typename T, int NCH, bool CS>
+__global__ __launch_bounds__(256, NCH <= 3 ? (CS ? 4 : 5) : 1) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xin,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -72,14 +74,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             int colsum_of, int64_t rows, int d) {
     __shared__ float red[NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    f32x4 g[NCH], dg[NCH], db[NCH], dc[NCH];     // dc: column sums of dres (colsum_of = 1) or of the dx written (2)
+    f32x4 dg[NCH], db[NCH], dc[CS ? NCH : 1];    // dc: column sums of dres (colsum_of = 1) or of the dx written (2)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int c = (lane + 64 * i) * 4;
-        g[i] = c < d ? load4(gamma + c) : f32x4{0.f, 0.f, 0.f, 0.f};
         dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        dc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (CS) dc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             if (c < d) {
                 const f32x4 dyv = load4(dy + row * d + c);
                 xh[i] = (load4(xin + row * d + c) - mu) * rs;
-                gy[i] = dyv * g[i];
+                gy[i] = dyv * load4(gamma + c);
                 dg[i] += dyv * xh[i];
                 db[i] += dyv;
 #pragma unroll
@@ -111,15 +111,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 if (dres) {
                     const f32x4 r = load4(dres + row * d + c);     // (prefetching it with dy / x costs occupancy: measured slower)
                     o += r;
-                    if (colsum_of == 1) dc[i] += r;
+                    if constexpr (CS) {
+                        if (colsum_of == 1) dc[i] += r;
+                    }
                 }
-                if (colsum_of == 2) dc[i] += o;
+                if constexpr (CS) {
+                    if (colsum_of == 2) dc[i] += o;
+                }
                 store4(dx + row * d + c, o);
             }
         }
     }
     // reduce the 4 waves' partials through LDS (one wave at a time), then one f32 atomic per column
-    for (int pass = 0; pass < (colsum_of ? 3 : 2); ++pass) {
+    for (int pass = 0; pass < (CS ? 3 : 2); ++pass) {
         for (int w = 0; w < 4; ++w) {
             __syncthreads();
             if (wave == w) {
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     const int c = (lane + 64 * i) * 4;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float val = pass == 0 ? dg[i][j] : pass == 1 ? db[i][j] : dc[i][j];
+                        const float val = pass == 0 ? dg[i][j] : pass == 1 ? db[i][j] : dc[CS ? i : 0][j];
                         red[c + j] = w == 0 ? val : red[c + j] + val;
                     }
                 }
@@ -391,11 +395,18 @@ static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, 
                            const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of,
                            int64_t rows, int64_t d, hipStream_t st) {
     int64_t nb = cdiv(rows, 4);
-    if (nb > 1024) nb = 1024;
+    const int64_t resident = colsum_of ? 1024 : 1280;      // 4 / 5 workgroups per CU fit (registers): exactly one round
+    if (nb > resident) nb = resident;
     dim3 grid((unsigned)nb);
 #define L(N)                                                                                                     \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma, mean, \
-                       rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d)
+    do {                                                                                                         \
+        if (colsum_of)                                                                                           \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, true>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma,  \
+                               mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d);          \
+        else                                                                                                     \
+            hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, false>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma, \
+                               mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d);          \
+    } while (0)
     if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
     else if (d <= 2048) L(8); else L(16);
 #undef L

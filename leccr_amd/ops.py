@@ -316,27 +316,27 @@ class ViTBlockFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
         dpre = lin_dx(g2, blk.mlp.c_proj.weight, epilogue=EPI_DQUICKGELU, aux=pre)
-        # bias gradients of c_proj / out_proj = column sums of dx2 / dx1: those tensors are the `dres` operands of the two
-        # LayerNorm backward launches, which accumulate the sums on their way (no separate colsum pass)
-        lin_dw(g2, act, blk.mlp.c_proj.weight, None)
+        # bias gradients of c_proj / out_proj = column sums of dx2 / dx1.  They ride the weight-gradient stream as 40 us HBM-bound
+        # passes beside the dX chain: folded into the LayerNorm backward launches (whose `dres` operands those tensors are) they
+        # cost that kernel a fifth of its occupancy - 253 us against 201 us per launch on the main chain
+        lin_dw(g2, act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
         dh2 = lin_dx(dpre, blk.mlp.c_fc.weight)
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
         lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
         dx1 = K.layernorm_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g,
-                              blk.ln_2.bias._g, dres=dx2, colsum=blk.mlp.c_proj.bias._g.reshape(-1), colsum_of=1)
-        _mark(blk.mlp.c_proj.bias)
+                              blk.ln_2.bias._g, dres=dx2)
         g1 = _rows(dx1)
         do = lin_dx(g1, blk.attn.out_proj.weight).view(b, N, d)
-        lin_dw(g1, _rows(o), blk.attn.out_proj.weight, None)
+        lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
         dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight)
         lin_dw(_rows(dqkv), _rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias)
         dx = K.layernorm_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g,
-                             blk.ln_1.bias._g, dres=dx1, colsum=blk.attn.out_proj.bias._g.reshape(-1), colsum_of=1)
-        for p in (blk.attn.out_proj.bias, blk.ln_1.weight, blk.ln_1.bias, blk.ln_2.weight, blk.ln_2.bias):
+                             blk.ln_1.bias._g, dres=dx1)
+        for p in (blk.ln_1.weight, blk.ln_1.bias, blk.ln_2.weight, blk.ln_2.bias):
             _mark(p)
         return (dx, None) + (None,) * 12
 

@@ -17,5 +17,7 @@ def t(f, reps=10):
 y, mean, rstd, _ = K.layernorm_fwd(x, g, b, 1e-5)
 tf = t(lambda: K.layernorm_fwd(x, g, b, 1e-5))
 tb = t(lambda: K.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres))
+cs = torch.zeros(d, device=dev)
+tc = t(lambda: K.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres, colsum=cs, colsum_of=1))
 nb = rows * d * 2
-print(f'LN fwd {tf*1e3:.1f} us  {2*nb/tf/1e9:.2f} TB/s (read x + write y) | LN bwd {tb*1e3:.1f} us  {4*nb/tb/1e9:.2f} TB/s (dy, x, dres -> dx)')
+print(f'LN fwd {tf*1e3:.1f} us  {2*nb/tf/1e9:.2f} TB/s (read x + write y) | LN bwd {tb*1e3:.1f} us  {4*nb/tb/1e9:.2f} TB/s (dy, x, dres -> dx) | with colsum(dres) {tc*1e3:.1f} us  {4*nb/tc/1e9:.2f} TB/s')
