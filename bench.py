@@ -1,29 +1,39 @@
 #!/usr/bin/env python3
 """bench.py - LECCR train-step throughput on MI355X (image-text pairs/s), one process per GPU.
 
-    python bench.py [--gpus N --steps K --warmup W]        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W]
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK / WORLD_SIZE in
+the environment), or started bare as `python bench.py --gpus N`, in which case THIS process - before it makes any GPU call -
+starts the N ranks itself as a torch.distributed.run child and exits with its code.  A bare run never silently measures one
+rank: the world size must equal --gpus.
 
 A step = RetrievalModel.forward (ViT-B/16 @384 + mBERT + caption interaction + 5 losses) + backward + gradient
 all-reduce + fused AdamW + LR schedule on one synthetic Multi30K-shaped batch that is already resident in HBM
 (BASELINE.json configs[1]: bf16, batch 256 per GPU, 1xMI355X; weak scaling: the per-GPU batch is fixed, the contrastive
 batch is all-gathered across ranks).  Prints ONE JSON line on rank 0 with the metric, a `roofline` object for the
-dominant kernel family (bf16 MFMA GEMMs, timed with hipEvents on the launch stream inside the timed region) and a
-`cpu_baseline` object (the CPU oracle timed on this host, bounded sample).
+dominant kernel family (bf16 MFMA GEMMs, timed with hipEvents on the launch stream), an `hbm_kernels` list (achieved TB/s of
+the bandwidth-bound launches), a `parity` object (the same weights on a 2-row slice against the CPU oracle) and a
+`cpu_baseline` object (the CPU oracle timed on this host: BASELINE config A, bounded sample).
+
+Other workloads (not the headline line): --model video (the reference's MSR-VTT geometry: 4096-wide frame features, F = 8)
+and --model video_vit (BASELINE configs[3] as worded: 8 frames x ViT-B/16 -> vid_encoder, vw 512).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
-F_PAIR_GFLOP = 389.9                # algorithmic FLOPs per pair per train step, B/16 + mBERT
+HBM_PEAK_TBS = 8.0                  # HBM3E, same guide
+F_PAIR_GFLOP = {'image': 389.9,     # algorithmic FLOPs per pair per train step, B/16 + mBERT
+                'video_vit': 2718.0}   # config D: 8 x B/16 frames + mBERT (same table)
 
 
 def parse():
@@ -31,29 +41,121 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch (BASELINE configs[1]: 256)')
+    ap.add_argument('--model', default='image', choices=['image', 'video', 'video_vit'])
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (image: 256 = BASELINE configs[1]; video: 128; video_vit: 64)')
     ap.add_argument('--clip', default='ViT-B/16')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--roofline-steps', type=int, default=3, help='extra single-stream steps after the timed region that time the GEMM launches on their own')
-    ap.add_argument('--cpu-batch', type=int, default=4)
-    ap.add_argument('--cpu-steps', type=int, default=6)
-    return ap.parse_args()
+    ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--roofline-steps', type=int, default=3, help='extra single-stream steps after the timed region that time every launch on its own')
+    ap.add_argument('--cpu-batch', type=int, default=32, help='cpu_baseline batch (BASELINE config A: 32)')
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-budget-s', type=float, default=150.0, help='cpu_baseline stops adding steps past this many seconds')
+    args = ap.parse_args()
+    if args.batch is None:
+        args.batch = {'image': 256, 'video': 128, 'video_vit': 64}[args.model]
+    return args
 
 
-def build_model(args, device):
-    from leccr_amd.models import RetrievalModel
-    from leccr_amd.synthetic import MULTI30K_CFG
-    cfg = dict(MULTI30K_CFG)
-    cfg.update(clip_name=args.clip, compute_dtype=args.dtype, clip_text_tower=False)
+def maybe_self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `torch.distributed.run` and exit with its
+    code.  Runs before this process has imported leccr_amd or touched the GPU (a process that has initialised the GPU must
+    neither exec nor hand the device to children it forks)."""
+    if args.gpus <= 1 or ('RANK' in os.environ and 'WORLD_SIZE' in os.environ):
+        return
+    import torch
+    have = torch.cuda.device_count()           # counts devices without initialising the runtime on this image
+    backend = os.environ.get('LECCR_BENCH_BACKEND', 'nccl')
+    if backend == 'nccl' and have < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but this node exposes {have} GPU(s); refusing to report a {args.gpus}-GPU number',
+              file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: starting ranks: ' + ' '.join(cmd), file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
+def host_cores():
+    """(threads to use, description): the physical cores this process may run on - sched_getaffinity, one thread per
+    (physical id, core id) pair of /proc/cpuinfo inside it, capped by a cgroup CPU quota when one is set."""
+    logical = os.cpu_count() or 1
+    try:
+        aff = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = list(range(logical))
+    phys = set()
+    try:
+        cur = {}
+        with open('/proc/cpuinfo') as fh:
+            for line in fh.read().split('\n') + ['']:
+                if ':' in line:
+                    k, v = line.split(':', 1)
+                    cur[k.strip()] = v.strip()
+                elif cur:
+                    if int(cur.get('processor', -1)) in aff:
+                        phys.add((cur.get('physical id', '0'), cur.get('core id', cur.get('processor'))))
+                    cur = {}
+    except OSError:
+        pass
+    n_phys = len(phys) or len(aff)
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            q, p = fh.read().split()
+            if q != 'max':
+                quota = max(1, int(float(q) / float(p)))
+    except (OSError, ValueError):
+        pass
+    n = min(n_phys, quota) if quota else n_phys
+    return max(1, n), f'os.cpu_count()={logical}, affinity={len(aff)}, physical cores in affinity={n_phys}, cgroup quota={quota}'
+
+
+# ------------------------------------------------------------------------------------------------ workloads
+def build_workload(args, device, rank):
+    """-> (model, cfg, batch on device, fwd(model, batch) -> 5 losses, description)."""
+    import torch
+    from leccr_amd.synthetic import MULTI30K_CFG, VATEX_CFG, make_batch, make_video_batch
     torch.manual_seed(1234)                      # identical weights on every rank (DDP broadcasts rank 0's)
-    model = RetrievalModel(cfg)
+    if args.model == 'image':
+        from leccr_amd.models import RetrievalModel
+        cfg = dict(MULTI30K_CFG)
+        cfg.update(clip_name=args.clip, compute_dtype=args.dtype, clip_text_tower=False)
+        model = RetrievalModel(cfg)
+        cpu = make_batch(args.batch, rank=rank)
+        batch = {'image': cpu['image'].to(device)}
+        fwd = lambda m, b: m(b['image'], b['text'], captions=b['captions'], idx=b['idx'])
+        what = f'Multi30K en-de shaped, {args.clip}@384 + mBERT'
+    elif args.model == 'video':
+        from leccr_amd.models.video_model_retrieval_caption import RetrievalModel
+        # configs/cclm-base-ft/Retrieval_msrvtt.yaml:36-66: vision_width 4096, vision_layer 1, num_queries 2, 2+2 interaction layers
+        cfg = dict(VATEX_CFG, vision_width=4096, vision_layer=1, num_queries=2, caption_ca_layer=2, compute_dtype=args.dtype)
+        model = RetrievalModel(cfg)
+        cpu = make_video_batch(args.batch, rank=rank, frames=8, width=4096)
+        batch = {'video': cpu['video'].to(device), 'video_mask': cpu['video_mask'].to(device)}
+        fwd = lambda m, b: m(b['video'], b['video_mask'], b['text'], captions=b['captions'], idx=b['idx'])
+        what = 'MSR-VTT shaped (run_video.sh), 8 frames x 4096-wide features + mBERT, double-sim losses'
+    else:
+        from leccr_amd.models.video_frames_model import FrameViTRetrievalModel
+        cfg = dict(VATEX_CFG, vision_layer=1, clip_name=args.clip, compute_dtype=args.dtype)
+        model = FrameViTRetrievalModel(cfg)
+        cpu = make_video_batch(args.batch, rank=rank, frames=8, width=8)
+        g = torch.Generator().manual_seed(4242 + rank)
+        batch = {'video': torch.randn(args.batch, 8, 3, 384, 384, generator=g).to(device), 'video_mask': cpu['video_mask'].to(device)}
+        fwd = lambda m, b: m(b['video'], b['video_mask'], b['text'], captions=b['captions'], idx=b['idx'])
+        what = f'VATEX shaped (BASELINE configs[3]), 8 frames x {args.clip}@384 -> vid_encoder (vw 512) + mBERT, double-sim losses'
     model.init_caption_encoder()
-    return model.to(device).train(), cfg
+    batch.update(text=[t.to(device) for t in cpu['text']], captions=cpu['captions'].to(device), idx=cpu['idx'].to(device))
+    return model.to(device).train(), cfg, batch, fwd, what
 
 
-def train_step(model, batch, opt, sched):
-    losses = model(batch['image'], batch['text'], captions=batch['captions'], idx=batch['idx'])
+def train_step(model, batch, fwd, opt, sched):
+    losses = fwd(model, batch)
     loss = losses[0] + losses[1] + losses[2] + losses[3] + losses[4]
     opt.zero_grad()
     loss.backward()
@@ -62,76 +164,130 @@ def train_step(model, batch, opt, sched):
     return losses
 
 
-def cpu_baseline(args, cfg):
-    """The CPU oracle (oracle/leccr_oracle.py, a restatement of the reference pinned to its fixtures - kind 'port')
-    timed on this host: full step = forward + backward + AdamW, same geometry, batch `cpu_batch`."""
-    from leccr_amd.models import RetrievalModel
-    from leccr_amd.synthetic import make_batch
+def _oracle_state(model):
+    import torch
+    return {k: v.detach().cpu().float().clone() for k, v in model.state_dict().items() if not k.startswith('caption_encoder.')}
+
+
+def _oracle_losses(args, cfg, sd, batch, rows):
+    """The CPU oracle's five losses on rows [0, rows) of `batch` (CPU tensors) with the state dict `sd`."""
+    import torch
     from oracle import leccr_oracle as O
-    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))      # the GPU box's CPU share for one GPU
-    torch.manual_seed(1234)
-    c = dict(cfg)
-    c['compute_dtype'] = 'fp32'
-    model = RetrievalModel(c)
-    model.init_caption_encoder()
-    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()
-          if not k.startswith('caption_encoder.')}
-    del model
+    wl = {k: cfg[k] for k in ('weight_reg_loss', 'weight_caption_loss', 'weight_dstl_loss', 'weight_cv_loss')}
+    s = slice(0, rows)
+    t0, t1, c = batch['text'][0], batch['text'][1], batch['captions']
+    txt = (t0.input_ids[s], t0.attention_mask[s], t1.input_ids[s], t1.attention_mask[s], c.input_ids[s], c.attention_mask[s],
+           batch['idx'][s])
+    if args.model == 'image':
+        return O.retrieval_forward(sd, wl, batch['image'][s], *txt, text_heads=12)
+    video = batch['video'][s]
+    if args.model == 'video_vit':
+        b, F = video.shape[:2]
+        hidden = O.encode_image(sd, 'clip_encoder.visual.', video.reshape(b * F, *video.shape[2:]))
+        video = hidden[:, 0, :].reshape(b, F, -1)
+    return O.video_retrieval_forward(sd, wl, video, batch['video_mask'][s], *txt, text_heads=12)
+
+
+def cpu_baseline(args, cfg, model):
+    """The CPU oracle (oracle/leccr_oracle.py, a restatement of the reference pinned to its fixtures - kind 'port') timed on
+    this host: full step = forward + backward + AdamW, same geometry, BASELINE config A's batch (32) on the physical cores
+    this process may use; bounded: at most --cpu-steps timed steps after one warm-up, fewer once --cpu-budget-s is spent."""
+    import torch
+    from leccr_amd.synthetic import make_batch, make_video_batch
+    n, how = host_cores()
+    torch.set_num_threads(n)
+    sd = {k: v.requires_grad_(v.is_floating_point()) for k, v in _oracle_state(model).items()}
     params = [v for v in sd.values() if v.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
     b = args.cpu_batch
-    batch = make_batch(b)
-    wl = {k: cfg[k] for k in ('weight_reg_loss', 'weight_caption_loss', 'weight_dstl_loss', 'weight_cv_loss')}
-    times = []
+    if args.model == 'image':
+        batch = make_batch(b)
+    else:
+        batch = make_video_batch(b, frames=8, width=4096 if args.model == 'video' else 8)
+        if args.model == 'video_vit':
+            batch['video'] = torch.randn(b, 8, 3, 384, 384, generator=torch.Generator().manual_seed(4242))
+    times, t_begin = [], time.perf_counter()
     for it in range(1 + args.cpu_steps):
         t0 = time.perf_counter()
-        losses = O.retrieval_forward(sd, wl, batch['image'], batch['text'][0].input_ids, batch['text'][0].attention_mask,
-                                     batch['text'][1].input_ids, batch['text'][1].attention_mask,
-                                     batch['captions'].input_ids, batch['captions'].attention_mask, batch['idx'],
-                                     text_heads=12)
+        losses = _oracle_losses(args, cfg, sd, batch, b)
         opt.zero_grad()
         sum(losses).backward()
         opt.step()
         times.append(time.perf_counter() - t0)
-    t = sorted(times[1:])[len(times[1:]) // 2]
+        if it >= 1 and time.perf_counter() - t_begin > args.cpu_budget_s:
+            break
+    timed = times[1:] or times
+    t = sorted(timed)[len(timed) // 2]
     return {'value': round(b / t, 4), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{args.cpu_steps} full train steps (fwd+bwd+AdamW) of batch {b} after 1 warm-up, same '
-                      f'{args.clip}+mBERT geometry, fp32, os.cpu_count()={os.cpu_count()}', 's_per_step': round(t, 3)}
+            'sample': f'{len(timed)} full train step(s) (fwd+bwd+AdamW) of batch {b} (BASELINE config A) after '
+                      f'{1 if len(times) > 1 else 0} warm-up, same {args.clip}+mBERT geometry, fp32; {how}',
+            's_per_step': round(t, 3), 'step_times_s': [round(x, 2) for x in times]}
+
+
+def parity_probe(args, cfg, model, batch, fwd, rows=2):
+    """After the timed region: the HIP model (the benchmarked weights, eval mode = dropout off) on rows [0, rows) of the
+    batch against the CPU oracle (fp32) on the same weights and inputs - the five losses."""
+    import torch
+    was_training = model.training
+    model.eval()
+    sub = {k: (v[:rows] if torch.is_tensor(v) else v) for k, v in batch.items()}
+    sub['text'] = [type(t)(t.input_ids[:rows], t.attention_mask[:rows]) for t in batch['text']]
+    sub['captions'] = type(batch['captions'])(batch['captions'].input_ids[:rows], batch['captions'].attention_mask[:rows])
+    with torch.no_grad():
+        got = [float(l) for l in fwd(model, sub)]
+    model.train(was_training)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sub.items()}
+    cpu['text'] = [t.to('cpu') for t in sub['text']]
+    cpu['captions'] = sub['captions'].to('cpu')
+    torch.set_num_threads(host_cores()[0])
+    with torch.no_grad():
+        ref = [float(l) for l in _oracle_losses(args, cfg, _oracle_state(model), cpu, rows)]
+    err = max(abs(a - r) for a, r in zip(got, ref))
+    tol = 1e-3 if args.dtype == 'fp32' else 3e-2
+    return {'rows': rows, 'max_abs_loss_err': round(err, 6), 'tolerance': tol, 'ok': bool(err <= tol),
+            'losses_hip': [round(x, 5) for x in got], 'losses_oracle_fp32': [round(x, 5) for x in ref],
+            'what': f'{args.dtype} HIP path (eval mode) vs CPU oracle fp32, same weights (after the timed steps) and inputs, '
+                    f'full {args.clip}@384 + mBERT geometry'}
+
+
+HBM_KINDS = ['layernorm_fwd', 'layernorm_bwd', 'colsum', 'bert_embed_fwd', 'adamw', 'dropout']
 
 
 def main():
+    args = parse()
+    maybe_self_launch(args)
     # stdout carries exactly one line - the result JSON of rank 0; the reference-style "### ..." notices of create_optimizer /
     # create_scheduler and any library chatter go to stderr
     import contextlib
     real_stdout = sys.stdout
     with contextlib.redirect_stdout(sys.stderr):
-        _main(real_stdout)
+        _main(args, real_stdout)
 
 
-def _main(real_stdout):
-    args = parse()
-    from leccr_amd import _lib
-    from leccr_amd.optim import create_optimizer
-    from leccr_amd.parallel import attach_grad_sync, init_distributed_mode
-    from leccr_amd.scheduler import create_scheduler
-    from leccr_amd.synthetic import make_batch
+def _main(args, real_stdout):
     import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    from leccr_amd import _lib, ops
+    from leccr_amd.optim import create_optimizer
+    from leccr_amd.parallel import attach_grad_sync, init_distributed_mode, rccl_cus
+    from leccr_amd.scheduler import create_scheduler
     # RCCL ('nccl') over xGMI, one rank per GPU.  LECCR_BENCH_BACKEND=gloo is a rehearsal aid only: it lets two ranks share
     # the single GPU of a development box to exercise this N > 1 control flow (not a measurement configuration).
     backend = os.environ.get('LECCR_BENCH_BACKEND', 'nccl')
     rank, world, local = init_distributed_mode(backend)
-    assert world == args.gpus or world == 1, (world, args.gpus)
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: world size {world} != --gpus {args.gpus} (launch with torch.distributed.run '
+                         f'--nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` bare and let it start the ranks)')
     if backend != 'nccl':
         local = local % max(1, torch.cuda.device_count())
     device = torch.device('cuda', local)
     torch.cuda.set_device(device)
-    model, cfg = build_model(args, device)
+    model, cfg, batch, fwd, what = build_workload(args, device, rank)
     opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model)).enable_backward_fusion()
     sched = create_scheduler(dict(cfg['schedular'], step_per_epoch=1000), opt)
     sched.step()                                                  # leave lr = 0 (first LambdaLR value) behind
-    cpu = make_batch(args.batch, rank=rank)
-    batch = {'image': cpu['image'].to(device), 'text': [t.to(device) for t in cpu['text']],
-             'captions': cpu['captions'].to(device), 'idx': cpu['idx'].to(device)}
 
     def barrier():
         if world > 1:
@@ -139,13 +295,13 @@ def _main(real_stdout):
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        train_step(model, batch, opt, sched)
+        train_step(model, batch, fwd, opt, sched)
     lib = _lib.lib()
     barrier()
     lib.leccr_prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = train_step(model, batch, opt, sched)
+        losses = train_step(model, batch, fwd, opt, sched)
     barrier()
     dt = time.perf_counter() - t0
     lib.leccr_prof_enable(0)
@@ -153,76 +309,102 @@ def _main(real_stdout):
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    ms, work, n = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
-    lib.leccr_prof_read(ms, work, n)
+    NK = 11
+    ms, work, n = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
+    lib.leccr_prof_read_n(NK, ms, work, n)
     # GEMM busy time = union of the launch intervals (HIP events on the launch streams): the weight-gradient GEMMs run on a
     # second stream beside the dX chain, so summing per-launch durations would count the overlapped stretches twice
     busy, gwork, gn = C.c_double(), C.c_double(), C.c_int64()
     lib.leccr_prof_read_union(0b11, C.byref(busy), C.byref(gwork), C.byref(gn))
-    # Roofline leg: the same steps with every launch on ONE stream, so that a GEMM launch's event interval is the kernel running
+    # Roofline leg: the same steps with every launch on ONE stream, so that a launch's event interval is the kernel running
     # alone (in the timed region above a dW GEMM shares the chip with the dX chain, and its own interval is stretched by that).
-    from leccr_amd import ops
-    ms1, work1, n1 = (C.c_double * 5)(), (C.c_double * 5)(), (C.c_int64 * 5)()
+    ms1, work1, n1 = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
     if args.roofline_steps > 0:
         overlap, ops.wgrad_overlap, ops.text_overlap = (ops.wgrad_overlap, ops.text_overlap), False, False
         fusion, opt.backward_fusion = opt.backward_fusion, False
         barrier()
         lib.leccr_prof_enable(1)
         for _ in range(args.roofline_steps):
-            train_step(model, batch, opt, sched)
+            train_step(model, batch, fwd, opt, sched)
         barrier()
         lib.leccr_prof_enable(0)
-        lib.leccr_prof_read(ms1, work1, n1)
+        lib.leccr_prof_read_n(NK, ms1, work1, n1)
         ops.wgrad_overlap, ops.text_overlap = overlap
         opt.backward_fusion = fusion
+        leg, leg_ms, leg_work, leg_n = args.roofline_steps, ms1, work1, n1
+    else:
+        leg, leg_ms, leg_work, leg_n = args.steps, ms, work, n
+    parity = None
+    if world == 1 and not args.no_parity:          # (the model's forward gathers across ranks: a one-rank probe would hang W > 1)
+        parity = parity_probe(args, cfg, model, batch, fwd)
     if rank == 0:
         G = args.batch * world
         value = G * args.steps / dt
         union_ms, union_fl = busy.value, gwork.value
-        if args.roofline_steps > 0:
-            gemm_ms, gemm_fl, gemm_n, leg_steps = ms1[0] + ms1[1], work1[0] + work1[1], n1[0] + n1[1], args.roofline_steps
-        else:
-            gemm_ms, gemm_fl, gemm_n, leg_steps = ms[0] + ms[1], work[0] + work[1], n[0] + n[1], args.steps
+        gemm_ms, gemm_fl, gemm_n = leg_ms[0] + leg_ms[1], leg_work[0] + leg_work[1], leg_n[0] + leg_n[1]
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         traffic, traffic_src = None, None
-        tj = os.path.join(ROOT, 'profiles', 'r01_gemm256_hbm_traffic.json')
-        if os.path.exists(tj) and args.clip == 'ViT-B/16' and args.batch == 256 and args.dtype == 'bf16':
+        tj = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_gemm256_hbm_traffic.json') for r in (2, 1))
+                   if os.path.exists(p)), '')
+        if tj and args.model == 'image' and args.clip == 'ViT-B/16' and args.batch == 256 and args.dtype == 'bf16':
             with open(tj) as fh:        # PMC counters cannot be read from inside the run: the committed rocprofv3 passes
                 tr = json.load(fh)      # of this same command (FETCH_SIZE x2 + WRITE_SIZE, per launch) are reported
-            traffic, traffic_src = round(tr['hbm_bytes_per_launch']), 'profiles/r01_gemm256_hbm_traffic.json'
+            traffic, traffic_src = round(tr['hbm_bytes_per_launch']), 'profiles/' + os.path.basename(tj)
+        hbm = []
+        for k, name in enumerate(HBM_KINDS, start=5):
+            if leg_n[k]:
+                tbs = leg_work[k] / (leg_ms[k] * 1e-3) / 1e12
+                hbm.append({'kernel': name, 'launches_per_step': leg_n[k] // leg, 'ms_per_step': round(leg_ms[k] / leg, 3),
+                            'algorithmic_gb_per_step': round(leg_work[k] / leg / 1e9, 3), 'achieved_tb_s': round(tbs, 3),
+                            'frac_of_hbm_peak': round(tbs / HBM_PEAK_TBS, 3)})
+        try:
+            rccl = '.'.join(map(str, torch.cuda.nccl.version())) if world > 1 else None
+        except Exception:                                                            # noqa: BLE001 (reporting only)
+            rccl = None
+        fpair = F_PAIR_GFLOP.get(args.model) if args.clip == 'ViT-B/16' else None
         out = {
-            'metric': 'image-text pairs/sec (train step)', 'value': round(value, 2), 'unit': 'pairs/s',
+            'metric': 'image-text pairs/sec (train step)' if args.model == 'image' else 'video-text pairs/sec (train step)',
+            'value': round(value, 2), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'Multi30K en-de shaped, {args.clip}@384 + mBERT, {args.dtype}, batch {args.batch}/GPU '
-                                   f'(global {G}), L_t=32, L_c=64, train mode (dropout 0.1 on), full step (fwd+bwd+all-gather+all-reduce+AdamW)',
+            'config': {'workload': f'{what}, {args.dtype}, batch {args.batch}/GPU (global {G}), L_t=32, L_c=64, train mode '
+                                   f'(dropout 0.1 on), full step (fwd+bwd+all-gather+all-reduce+AdamW)',
                        'global_batch': G, 'parallelism': f'dp{world}',
-                       'step_tflops_algorithmic': round(F_PAIR_GFLOP * value / 1e3, 1) if args.clip == 'ViT-B/16' else None,
+                       'step_tflops_algorithmic': round(fpair * value / 1e3, 1) if fpair else None,
                        'losses': [round(float(l.detach()), 4) for l in losses],
-                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+                       'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       'world': world, 'backend': backend if world > 1 else None, 'rccl_version': rccl,
+                       'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'LECCR_RCCL_CUS': rccl_cus()},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm256_kernel (bf16 256x256x64 MFMA GEMM: NT forward/dX + TN weight-gradient instantiations)',
                          'achieved': round(achieved, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
                          'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': traffic_src,
-                         'launches_per_step': gemm_n // max(1, leg_steps),
+                         'launches_per_step': gemm_n // max(1, leg),
                          'avg_launch_us': round(gemm_ms * 1e3 / max(1, gemm_n), 2),
                          'avg_launch_gflop': round(gemm_fl / max(1, gemm_n) / 1e9, 2),
-                         'timing': (f'HIP events on the launch stream around every GEMM launch of {leg_steps} single-stream steps run right '
+                         'timing': (f'HIP events on the launch stream around every GEMM launch of {leg} single-stream steps run right '
                                     'after the timed region (same process, same tensors): each interval is the kernel alone. In the timed '
                                     'region the dW launches and the text towers share the chip with the image tower / dX chain on side streams')
                                    if args.roofline_steps > 0 else 'HIP events around every GEMM launch of the timed region',
                          'timed_region_gemm_tflops_union': round(union_fl / (union_ms * 1e-3) / 1e12, 1) if union_ms > 0 else None,
                          'timed_region_gemm_busy_share': round(union_ms / (dt * 1e3), 3),
-                         'attn_fwd_ms_per_step': round((ms1[3] / leg_steps) if args.roofline_steps > 0 else (ms[3] / args.steps), 3),
-                         'attn_bwd_ms_per_step': round((ms1[4] / leg_steps) if args.roofline_steps > 0 else (ms[4] / args.steps), 3),
-                         'generic_gemm_ms_per_step': round((ms1[2] / leg_steps) if args.roofline_steps > 0 else (ms[2] / args.steps), 3)},
+                         'gemm_ms_per_step': round(gemm_ms / leg, 3),
+                         'attn_fwd_ms_per_step': round(leg_ms[3] / leg, 3), 'attn_bwd_ms_per_step': round(leg_ms[4] / leg, 3),
+                         'attn_fwd_tflops': round(leg_work[3] / (leg_ms[3] * 1e-3) / 1e12, 1) if leg_ms[3] > 0 else None,
+                         'attn_bwd_tflops': round(leg_work[4] / (leg_ms[4] * 1e-3) / 1e12, 1) if leg_ms[4] > 0 else None,
+                         'generic_gemm_ms_per_step': round(leg_ms[2] / leg, 3)},
+            'hbm_kernels': hbm,
         }
+        if parity is not None:
+            out['parity'] = parity
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args, cfg)
+            out['cpu_baseline'] = cpu_baseline(args, cfg, model)
         print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity['ok']:
+        raise SystemExit(f'bench.py: parity probe outside its tolerance: {parity}')
 
 
 if __name__ == '__main__':

@@ -48,6 +48,9 @@ int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_ge
                                                 * 2 MFMA 256x256 (8 waves), 3 MFMA 256x256 (4 waves); tests use it */
 int leccr_prof_enable(int on);
 int leccr_prof_read(double* ms, double* work, int64_t* launches);
+/* The first n <= 11 kinds: the five above, then {layernorm_fwd, layernorm_bwd, colsum, embedding stages, adamw, dropout} -
+ * the HBM-bound launches, whose work[] entry is ALGORITHMIC BYTES (every operand read once, every result written once). */
+int leccr_prof_read_n(int n, double* ms, double* work, int64_t* launches);
 /* The launches of the kinds in kind_mask (bit k = index k above) as one busy time: the union of their [start, stop]
  * intervals (launches that overlap on two streams are not counted twice), their total work and count. */
 int leccr_prof_read_union(int kind_mask, double* busy_ms, double* work, int64_t* launches);

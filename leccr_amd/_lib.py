@@ -35,6 +35,7 @@ _SIGS = {
     'leccr_get_gemm_max_blocks': ([], C.c_int),
     'leccr_prof_enable': ([C.c_int], C.c_int),
     'leccr_prof_read': ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
+    'leccr_prof_read_n': ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
     'leccr_prof_read_union': ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
     'leccr_gemm': ([C.POINTER(GemmParams), vp], C.c_int),
     'leccr_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, vp], C.c_int),

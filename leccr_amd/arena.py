@@ -99,6 +99,10 @@ class ParamArena:
         self._seg_key = None
         self._seg_range = {}
         self.step_count = 0
+        # backward-pass hooks of THIS arena's model (fired by leccr_amd.ops from the ViT backward nodes; see ops._fire)
+        self.on_late_backward_start = None
+        self.on_early_grads_final = None
+        self.on_vit_block_backward = None
 
     # ------------------------------------------------------------------ compute copies
     def need_transposed(self, holder):

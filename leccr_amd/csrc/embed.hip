@@ -168,6 +168,7 @@ extern "C" int leccr_bert_embed_fwd(const int64_t* ids, const float* word, const
     if (b == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     const unsigned grid = (unsigned)cdiv(b * L, 4);
+    ProfScope prof(PROF_EMBED, (double)b * L * (8.0 + d * (4.0 + (dtype == LECCR_BF16 ? 2.0 : 4.0))), st);   // word row in, emb row out
     if (dtype == LECCR_F32)
         hipLaunchKernelGGL((bert_embed_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, ids, word, pos, type0, (float*)emb, b * L, (int)L, (int)d, vocab);
     else if (dtype == LECCR_BF16)

@@ -60,10 +60,18 @@ extern "C" int leccr_prof_enable(int on) {
 
 // ms[k], work[k] (FLOPs), launches[k] for k < 5 (gemm_nt, gemm_tn, gemm_generic, attn_fwd, attn_bwd). Synchronises.
 extern "C" int leccr_prof_read(double* ms, double* work, int64_t* launches) {
+    return leccr_prof_read_n(leccr::PROF_KINDS_V1, ms, work, launches);
+}
+
+// The same for the first n kinds of ProfKind (n <= 11: + layernorm fwd / bwd, colsum, embedding stages, AdamW + copies, dropout,
+// whose `work` is algorithmic HBM bytes).
+extern "C" int leccr_prof_read_n(int n, double* ms, double* work, int64_t* launches) {
     using namespace leccr;
-    for (int k = 0; k < PROF_KINDS; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    if (n < 1 || n > PROF_KINDS) { set_error("prof_read_n: n=%d", n); return LECCR_EINVAL; }
+    for (int k = 0; k < n; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
     for (int i = 0; i < g_prof_n; ++i) {
         ProfRec& r = g_prof[i];
+        if (r.kind >= n) continue;
         if (hipEventSynchronize(r.b) != hipSuccess) continue;
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) continue;
@@ -104,5 +112,5 @@ extern "C" int leccr_prof_read_union(int kind_mask, double* busy_ms, double* wor
     return LECCR_OK;
 }
 
-extern "C" int leccr_version(void) { return 1; }
+extern "C" int leccr_version(void) { return 2; }
 extern "C" const char* leccr_last_error(void) { return leccr::g_err; }

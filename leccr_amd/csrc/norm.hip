@@ -432,6 +432,8 @@ extern "C" int leccr_layernorm_fwd(const void* x, const void* add, const float* 
     LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_fwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
     if (rows == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
+    const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
+    ProfScope prof(PROF_LN_FWD, (double)rows * d * esz * (2 + (add ? 1 : 0) + (sum_out ? 1 : 0)) + 8.0 * rows, st);
     DISPATCH_T(dtype, ln_fwd_dispatch<float>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, st),
                ln_fwd_dispatch<bf16_t>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, st));
 }
@@ -445,6 +447,8 @@ extern "C" int leccr_layernorm_bwd(const void* dy, const void* x_in, const float
     LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_bwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
     if (rows == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
+    const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
+    ProfScope prof(PROF_LN_BWD, (double)rows * d * esz * (3 + (dres ? 1 : 0)) + 8.0 * rows, st);
     DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, st),
                ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, st));
 }
@@ -492,5 +496,6 @@ extern "C" int leccr_colsum(const void* x, float* out, int64_t M, int64_t N, int
     LECCR_REQUIRE(x && out && ldx >= N, LECCR_EINVAL, "colsum: bad argument");
     LECCR_REQUIRE((ldx & 3) == 0 && ((uintptr_t)x & 15) == 0, LECCR_EALIGN, "colsum: x must be 16-byte aligned with ldx %% 4 == 0");
     if (M == 0 || N == 0) return LECCR_OK;
+    ProfScope prof(PROF_COLSUM, (double)M * N * (dtype == LECCR_BF16 ? 2.0 : 4.0), as_stream(stream));
     DISPATCH_T(dtype, cs<float>(x, out, M, N, ldx, as_stream(stream)), cs<bf16_t>(x, out, M, N, ldx, as_stream(stream)));
 }

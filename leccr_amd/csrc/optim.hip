@@ -125,6 +125,7 @@ extern "C" int leccr_adamw(float* p, const float* g, float* m, float* v, int64_t
     if (n == 0) return LECCR_OK;
     const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
     const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+    ProfScope prof(PROF_ADAMW, (double)n * (28.0 + (lp_bf16 ? 2.0 : 0.0)), as_stream(stream));   // p,g,m,v read; p,m,v (+bf16) written
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_grid(cdiv(n, 4))), dim3(256), 0, as_stream(stream), p, g, m, v, n, seg_end,
                        seg_wd, (int)n_seg, lr, beta1, beta2, eps, step_size, gscale, (bf16_t*)lp_bf16);
     return check_launch("adamw");
@@ -190,6 +191,7 @@ extern "C" int leccr_dropout(const void* x, void* y, int64_t n, float p, uint64_
     LECCR_REQUIRE(n < (1ll << 32), LECCR_EINVAL, "dropout: more than 2^32 elements");
     if (n == 0) return LECCR_OK;
     const DropCfg d = make_drop(p, seed);
+    ProfScope prof(PROF_DROPOUT, (double)n * 2.0 * (dtype == LECCR_BF16 ? 2.0 : 4.0), as_stream(stream));
     if (dtype == LECCR_F32) hipLaunchKernelGGL((dropout_kernel<float>), dim3(stream_grid(n)), dim3(256), 0, as_stream(stream), (const float*)x, (float*)y, n, d, (int64_t)0);
     else if (dtype == LECCR_BF16) {
         const bf16_t *xb = (const bf16_t*)x;

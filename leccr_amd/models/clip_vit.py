@@ -141,3 +141,73 @@ def build_clip(name='ViT-B/32', image_resolution=384, text_tower=True, geometry=
         return CLIP(text_tower=text_tower, **geometry)
     width, layers, patch, embed = VIT_GEOMETRY[name]
     return CLIP(embed, image_resolution, layers, width, patch, 77, 49408, 512, 8, 12, text_tower=text_tower)
+
+
+# --------------------------------------------------------------------------------------- raw CLIP checkpoints
+def _cubic_weights(t, a=-0.75):
+    """The 4 taps of the cubic-convolution kernel (Keys, a = -0.75: what torch's mode='bicubic' uses) at fraction t."""
+    t = np.asarray(t, dtype=np.float64)
+    w0 = ((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a
+    w1 = ((a + 2) * t - (a + 3)) * t * t + 1
+    w2 = ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1
+    w3 = ((a * (2 - t) - 5 * a) * (2 - t) + 8 * a) * (2 - t) - 4 * a
+    return np.stack([w0, w1, w2, w3], -1)
+
+
+def _resize_matrix(n_in, n_out):
+    """[n_out, n_in] bicubic resampling matrix, align_corners=False, border taps clamped (F.interpolate semantics)."""
+    src = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+    i0 = np.floor(src).astype(np.int64)
+    w = _cubic_weights(src - i0)
+    m = np.zeros((n_out, n_in), dtype=np.float64)
+    for k in range(4):
+        np.add.at(m, (np.arange(n_out), np.clip(i0 - 1 + k, 0, n_in - 1)), w[:, k])
+    return m
+
+
+def interpolate_pos_embed(pos_embed_checkpoint, num_patches, num_extra_tokens=1):
+    """clip/model.py:456-481: bicubically resize the [1, 1+g0*g0, d] positional embedding of a CLIP checkpoint to
+    [1, 1+g*g, d] (g*g = num_patches); the class-token row is kept.  Load-time host arithmetic (separable resampling as two
+    small matrix products in f64), not part of the step."""
+    pe = pos_embed_checkpoint
+    d = pe.shape[-1]
+    orig = int((pe.shape[-2] - num_extra_tokens) ** 0.5)
+    new = int(num_patches ** 0.5)
+    if orig == new:
+        return pe
+    extra = pe[:, :num_extra_tokens]
+    grid = pe[:, num_extra_tokens:].reshape(-1, orig, orig, d).detach().cpu().double().numpy()
+    m = _resize_matrix(orig, new)
+    out = np.einsum('yi,bixd->byxd', m, grid)                             # rows
+    out = np.einsum('xj,byjd->byxd', m, out)                             # columns
+    out = torch.from_numpy(out.reshape(-1, new * new, d)).to(pe.dtype)
+    print('reshape position embedding from %d to %d' % (orig ** 2, new ** 2))
+    return torch.cat((extra, out.to(extra.device)), dim=1)
+
+
+def build_model(state_dict, text_tower=True):
+    """clip/model.py:408-453: a CLIP whose geometry is inferred from a raw (OpenAI-format) ViT state dict, image
+    resolution hard-coded to 384 with the positional embedding resized to it, weights loaded (as f32 master weights)."""
+    assert 'visual.proj' in state_dict, 'ModifiedResNet towers are outside the LECCR path'
+    sd = dict(state_dict)
+    image_resolution = 384
+    patch = sd['visual.conv1.weight'].shape[-1]
+    num_patches = (image_resolution // patch) ** 2
+    sd['visual.positional_embedding'] = interpolate_pos_embed(sd['visual.positional_embedding'].unsqueeze(0).float(),
+                                                              num_patches=num_patches).squeeze(0)
+    width = sd['visual.conv1.weight'].shape[0]
+    layers = len([k for k in sd if k.startswith('visual.') and k.endswith('.attn.in_proj_weight')])
+    embed_dim = sd['text_projection'].shape[1] if 'text_projection' in sd else sd['visual.proj'].shape[1]
+    has_text = text_tower and 'token_embedding.weight' in sd
+    if has_text:
+        tw = sd['ln_final.weight'].shape[0]
+        model = CLIP(embed_dim, image_resolution, layers, width, patch, sd['positional_embedding'].shape[0],
+                     sd['token_embedding.weight'].shape[0], tw, tw // 64,
+                     len(set(k.split('.')[2] for k in sd if k.startswith('transformer.resblocks'))))
+    else:
+        model = CLIP(embed_dim, image_resolution, layers, width, patch, 77, 49408, 512, 8, 12, text_tower=False)
+        sd = {k: v for k, v in sd.items() if k.startswith('visual.')}
+    for key in ('input_resolution', 'context_length', 'vocab_size'):
+        sd.pop(key, None)
+    model.load_state_dict({k: v.float() for k, v in sd.items()})
+    return model.eval()

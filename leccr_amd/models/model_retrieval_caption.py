@@ -107,6 +107,7 @@ class RetrievalModel(XVLMBase):
         w_r loss_reg_c).  Same five scalars; internally batch-major, src+tgt text in one BERT pass."""
         self._ensure_runtime()
         begin_step_gathers()
+        ops.begin_step()
         if self.training:          # fresh dropout masks per step and per rank (the reference seeds with seed + rank)
             self._step_count = getattr(self, '_step_count', 0) + 1
             rank, _ = _dist_info()

@@ -65,6 +65,7 @@ class RetrievalModel(_ImageRetrievalModel):
         """video_model_retrieval_caption.py:180-227 -> the same five scalars as the image model."""
         self._ensure_runtime()
         begin_step_gathers()
+        ops.begin_step()
         if self.training:
             self._step_count = getattr(self, '_step_count', 0) + 1
             rank, _ = _dist_info()

@@ -36,10 +36,16 @@ def _next_seed():
     return (_Rng.base * 1000003 + _Rng.n * 7919) & 0xFFFFFFFFFFFFFFFF
 
 
-# called when the ViT backward begins (= every other parameter gradient of the step is final); set by parallel.py
-on_late_backward_start = None
-on_early_grads_final = None          # ArenaAdamW.enable_backward_fusion: called right after it (same point of the backward pass)
-on_vit_block_backward = None         # leccr_amd.parallel: called with the block at the start of each ViT block's backward
+# Backward-pass hooks live ON THE ARENA of the parameters whose backward is running (so a second model in the same process
+# never triggers another model's optimizer / all-reduce):
+#   arena.on_late_backward_start()   when the ViT backward begins (= every other parameter gradient of the step is final); set
+#                                    by leccr_amd.parallel.attach_grad_sync
+#   arena.on_early_grads_final()     right after it (same point of the pass); set by ArenaAdamW.enable_backward_fusion
+#   arena.on_vit_block_backward(blk) at the start of each ViT block's backward; set by leccr_amd.parallel
+def _fire(param, hook, *args):
+    cb = getattr(getattr(param, '_arena', None), hook, None)
+    if cb is not None:
+        cb(*args)
 
 
 def _p(module, attr):
@@ -75,6 +81,13 @@ text_overlap = os.environ.get('LECCR_TEXT_STREAM', '1') != '0'
 _wgrad_stream = None
 _text_stream = None
 _wgrad_join_queued = False
+
+
+def begin_step():
+    """Called at the start of every model forward: a backward pass that raised leaves its end-of-pass join unqueued-but-flagged;
+    the next pass must queue its own."""
+    global _wgrad_join_queued
+    _wgrad_join_queued = False
 
 
 def text_stream(device):
@@ -310,8 +323,7 @@ class ViTBlockFn(torch.autograd.Function):
     def backward(ctx, dx2):
         x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act = ctx.saved_tensors
         blk = ctx.blk
-        if on_vit_block_backward is not None:
-            on_vit_block_backward(blk)
+        _fire(blk.ln_1.weight, 'on_vit_block_backward', blk)
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
@@ -356,12 +368,10 @@ class LnProjFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        if on_late_backward_start is not None:
-            on_late_backward_start()
-        if on_early_grads_final is not None:
-            on_early_grads_final()
         x, h, mean, rstd = ctx.saved_tensors
         ln_w, ln_b, proj = ctx.p
+        _fire(ln_w, 'on_late_backward_start')
+        _fire(ln_w, 'on_early_grads_final')
         b, N, d = x.shape
         dy2 = _rows(dy.contiguous())
         dh = K.gemm(dy2, proj._lp)                                    # dH = dY @ proj^T : B(n=d, k=vw) = proj[n, k]

@@ -40,9 +40,8 @@ class ArenaAdamW(torch.optim.Optimizer):
         backward starts) on a stream of its own WHILE the ViT backward runs, instead of after it: an HBM-bound pass beside
         MFMA-bound GEMMs.  Only for loops in which every backward() is followed by step() (the reference's train loop;
         bench.py) - a backward() without step() would leave those parameters updated."""
-        from . import ops
         self.backward_fusion = True
-        ops.on_early_grads_final = self._early_update
+        self.arena.on_early_grads_final = self._early_update      # keyed on this model's arena (ops._fire)
         return self
 
     @torch.no_grad()

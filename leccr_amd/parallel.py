@@ -10,11 +10,29 @@ import torch
 import torch.distributed as dist
 
 _BUCKET = 64 * 1024 * 1024      # elements per all-reduce (256 MiB f32): large, few collectives (xGMI per-link bound)
-# CUs left to RCCL while an all-reduce overlaps the backward pass.  The persistent GEMMs run one workgroup per CU with a static
-# item list and need the whole CU (160 KiB LDS, every VGPR): a collective's workgroups resident on n CUs would push n of a
-# 256-workgroup launch into a second round - twice the launch time for as long as the collective runs.  So RCCL is capped to
-# this many channels (NCCL_MAX_NCHANNELS, unless the user set it) and the GEMM launches of the overlap window use 256 - n CUs.
-_RCCL_CUS = 16
+
+
+def rccl_cus():
+    """CUs reserved for RCCL while an all-reduce overlaps the backward pass (LECCR_RCCL_CUS, default 0 = off).
+
+    The persistent GEMMs run one workgroup per CU with a static item list and need the whole CU (160 KiB LDS, every VGPR): a
+    collective's workgroups resident on n CUs would push n of a 256-workgroup launch into a second round.  With LECCR_RCCL_CUS=n
+    RCCL is capped to n channels (NCCL_MAX_NCHANNELS, unless the user set it) and the GEMM launches enqueued while an all-reduce
+    of the step is in flight use 256 - n CUs.  It is OFF by default: the trade has not been measured on a multi-GPU node yet
+    (this project's development box has one GPU), and an unmeasured cap must not cost the single-GPU path anything."""
+    try:
+        return max(0, min(int(os.environ.get('LECCR_RCCL_CUS', '0')), 128))
+    except ValueError:
+        return 0
+
+
+def setup_rccl_env():
+    """Environment RCCL reads at communicator creation - called by BOTH init paths (this module's and
+    leccr_amd.utils.init_distributed_mode, the one the task scripts use) before init_process_group."""
+    n = rccl_cus()
+    if n > 0:
+        os.environ.setdefault('NCCL_MAX_NCHANNELS', str(n))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')         # dmabuf IPC (the host driver supports only that)
 
 
 def init_distributed_mode(backend=None):
@@ -22,7 +40,7 @@ def init_distributed_mode(backend=None):
     if 'RANK' not in os.environ or 'WORLD_SIZE' not in os.environ:
         return 0, 1, 0
     rank, world, local = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ.get('LOCAL_RANK', 0))
-    os.environ.setdefault('NCCL_MAX_NCHANNELS', str(_RCCL_CUS))          # read by RCCL at communicator creation
+    setup_rccl_env()
     if torch.cuda.is_available():
         torch.cuda.set_device(local % torch.cuda.device_count())     # (ranks outnumber GPUs only in gloo rehearsals)
     if not dist.is_initialized():
@@ -53,28 +71,10 @@ def attach_grad_sync(optimizer):
 
     reduce_stream = []
     late = {'hi': grad.numel()}               # [late['hi'], numel) of the ViT region is already handed to RCCL
-    try:
-        rccl_cus = int(os.environ.get('LECCR_RCCL_CUS', os.environ.get('NCCL_MAX_NCHANNELS', _RCCL_CUS)))
-    except ValueError:
-        rccl_cus = _RCCL_CUS
-    rccl_cus = max(0, min(rccl_cus, 128)) if grad.is_cuda and dist.get_backend() == 'nccl' else 0
-
-    # How long the limit stays on after an all-reduce is handed to RCCL: its expected duration at a deliberately low ring
-    # bandwidth (LECCR_RCCL_GBPS, default 60 GB/s of bus bandwidth), in persistent-GEMM launches of the ViT backward (about 8 per
-    # 6 ms block over the two streams = 1.3 per ms), with a 1.5x margin.  Past it the GEMMs use every CU again.
-    try:
-        ring_gbps = float(os.environ.get('LECCR_RCCL_GBPS', 60))
-    except ValueError:
-        ring_gbps = 60.0
-
-    def limit_gemms_for(nbytes):
-        if rccl_cus:
-            from . import _lib
-            ms = nbytes * 2.0 * (world - 1) / world / (ring_gbps * 1e6)
-            _lib.lib().leccr_set_gemm_max_blocks_for(256 - rccl_cus, int(ms * 1.3 * 1.5) + 2)
+    cus = rccl_cus() if grad.is_cuda and dist.get_backend() == 'nccl' else 0
 
     def gemm_cus(n):
-        if rccl_cus:
+        if cus:
             from . import _lib
             _lib.lib().leccr_set_gemm_max_blocks(n)
 
@@ -82,7 +82,7 @@ def attach_grad_sync(optimizer):
         """All launches that write grad[lo:hi] are enqueued (on the main, text and weight-gradient streams): a stream of its own
         waits for the three and hands the all-reduces to RCCL, so the main stream goes straight on with the backward pass."""
         if grad.is_cuda:
-            limit_gemms_for((hi - lo) * 4)    # while this all-reduce is expected to run, the GEMM launches leave RCCL its CUs
+            gemm_cus(256 - cus)     # from here until sync(): GEMM launches leave RCCL its CUs (no-op unless LECCR_RCCL_CUS > 0)
             if not reduce_stream:
                 reduce_stream.append(torch.cuda.Stream(device=grad.device))
             rs = reduce_stream[0]
@@ -120,8 +120,8 @@ def attach_grad_sync(optimizer):
         pending.clear()
         gemm_cus(0)
 
-    ops.on_late_backward_start = early if split < grad.numel() else None
-    ops.on_vit_block_backward = vit_block if split < grad.numel() else None
+    arena.on_late_backward_start = early if split < grad.numel() else None       # this arena's backward only (ops._fire)
+    arena.on_vit_block_backward = vit_block if split < grad.numel() else None
     optimizer.grad_sync = sync
     optimizer.grad_scale = 1.0 / world
     return optimizer

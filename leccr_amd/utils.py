@@ -110,6 +110,8 @@ def init_distributed_mode(args):
         args.distributed = False
         return
     args.distributed = True
+    from .parallel import setup_rccl_env
+    setup_rccl_env()                       # the same RCCL environment as leccr_amd.parallel.init_distributed_mode
     torch.cuda.set_device(args.gpu)
     args.dist_backend = 'nccl'
     print('| distributed init (rank {}): {}'.format(args.rank, args.dist_url), flush=True)

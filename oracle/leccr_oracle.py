@@ -22,12 +22,71 @@ import torch
 import torch.nn.functional as F
 
 
+# --------------------------------------------------------------------------------------- bf16 storage model (optional)
+# `with lowp():` makes the oracle round to bf16 wherever the MI355X throughput path materialises a tensor in bf16 (activations
+# after every GEMM / LayerNorm / attention / residual add, the attention probabilities fed to the PV product, the bf16 compute
+# copies of the weights, and - in backward - the gradient of each such tensor), keeping f32 accumulation, statistics, biases,
+# gains, heads and losses, exactly like DESIGN.md section 2 describes the bf16 path.  It is NOT the reference's arithmetic (the
+# reference is fp32 throughout, models/xvlm.py:88) and is off by default - every fixture check runs with it off.  The GPU
+# tests use it as the NOISE MODEL of the bf16 path: how far bf16 storage at those points moves each loss / gradient away
+# from the fp32 result is the yardstick the HIP bf16 path's own deviation is held against, tensor by tensor.
+_LOWP = False
+
+
+class lowp:
+    def __enter__(self):
+        global _LOWP
+        self.prev, _LOWP = _LOWP, True
+
+    def __exit__(self, *exc):
+        global _LOWP
+        _LOWP = self.prev
+
+
+class _RoundAct(torch.autograd.Function):
+    """A tensor stored in bf16: rounded going forward, its gradient (also stored in bf16) rounded coming back."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().float()
+
+
+class _RoundWeight(torch.autograd.Function):
+    """The bf16 compute copy of an f32 master weight: rounded going forward; its gradient accumulates in f32."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return w.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _r(x):
+    return _RoundAct.apply(x) if _LOWP else x
+
+
+def _w(w):
+    return _RoundWeight.apply(w) if _LOWP else w
+
+
+def linear(x, w, b=None, keep_f32=False):
+    """F.linear; under lowp() on the weight's bf16 copy, result stored in bf16 unless keep_f32 (the heads feeding the losses)."""
+    y = F.linear(x, _w(w), b)
+    return y if keep_f32 else _r(y)
+
+
 # --------------------------------------------------------------------------------------- primitives
 def layer_norm(x, w, b, eps):
     """nn.LayerNorm over the last axis, statistics in fp32 (clip/model.py:157-163)."""
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
-    return (x - mu) / torch.sqrt(var + eps) * w + b
+    return _r((x - mu) / torch.sqrt(var + eps) * w + b)
 
 
 def quick_gelu(x):
@@ -55,21 +114,25 @@ def attention_core(q, k, v, heads, key_padding_mask=None):
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float('-inf'))
-    p = torch.softmax(s, dim=-1)
-    o = p @ vh
-    return o.permute(0, 2, 1, 3).reshape(b, Lq, d)
+    if _LOWP:       # the PV product takes bf16 probabilities; the normaliser is the sum of those same rounded values
+        e = _r(torch.exp(s - s.amax(-1, keepdim=True)))
+        o = (e @ vh) / e.sum(-1, keepdim=True)
+    else:
+        p = torch.softmax(s, dim=-1)
+        o = p @ vh
+    return _r(o.permute(0, 2, 1, 3).reshape(b, Lq, d))
 
 
-def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None):
+def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None, keep_f32=False):
     """nn.MultiheadAttention with packed in_proj ordered q,k,v (clip/model.py:175,187; attention.py:27,47).
     Batch-major in/out."""
     w, bias = sd[pre + 'in_proj_weight'], sd[pre + 'in_proj_bias']
     d = w.shape[1]
-    q = F.linear(query, w[:d], bias[:d])
-    k = F.linear(memory, w[d:2 * d], bias[d:2 * d])
-    v = F.linear(memory, w[2 * d:], bias[2 * d:])
+    q = linear(query, w[:d], bias[:d])
+    k = linear(memory, w[d:2 * d], bias[d:2 * d])
+    v = linear(memory, w[2 * d:], bias[2 * d:])
     o = attention_core(q, k, v, heads, key_padding_mask)
-    return F.linear(o, sd[pre + 'out_proj.weight'], sd[pre + 'out_proj.bias'])
+    return linear(o, sd[pre + 'out_proj.weight'], sd[pre + 'out_proj.bias'], keep_f32=keep_f32)
 
 
 # --------------------------------------------------------------------------------------- CLIP ViT
@@ -83,9 +146,10 @@ def vit_trunk(sd, pre, image):
     # stride == kernel: the conv is a GEMM over non-overlapping patches
     image = image[..., :g * p, :g * p]          # conv1 has stride p and no padding: R % p edge pixels are never read
     patches = image.reshape(b, 3, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, 3 * p * p)
-    x = patches @ w.reshape(d, -1).t()
+    x = _r(_r(patches) @ _w(w.reshape(d, -1)).t())
     cls = sd[pre + 'class_embedding'].reshape(1, 1, d).expand(b, 1, d)
-    x = torch.cat([cls, x], 1) + sd[pre + 'positional_embedding']
+    pos = sd[pre + 'positional_embedding']
+    x = _r(torch.cat([cls + pos[:1], x + pos[1:]], 1))
     x = layer_norm(x, sd[pre + 'ln_pre.weight'], sd[pre + 'ln_pre.bias'], 1e-5)
     heads = d // 64
     i = 0
@@ -93,10 +157,10 @@ def vit_trunk(sd, pre, image):
         bp = f'{pre}transformer.resblocks.{i}.'
         # ResidualAttentionBlock (clip/model.py:171-192): pre-LN attention + pre-LN QuickGELU MLP
         h = layer_norm(x, sd[bp + 'ln_1.weight'], sd[bp + 'ln_1.bias'], 1e-5)
-        x = x + torch_mha(sd, bp + 'attn.', h, h, heads)
+        x = _r(x + torch_mha(sd, bp + 'attn.', h, h, heads, keep_f32=True))      # residual added in the GEMM epilogue (f32)
         h = layer_norm(x, sd[bp + 'ln_2.weight'], sd[bp + 'ln_2.bias'], 1e-5)
-        h = quick_gelu(F.linear(h, sd[bp + 'mlp.c_fc.weight'], sd[bp + 'mlp.c_fc.bias']))
-        x = x + F.linear(h, sd[bp + 'mlp.c_proj.weight'], sd[bp + 'mlp.c_proj.bias'])
+        h = _r(quick_gelu(linear(h, sd[bp + 'mlp.c_fc.weight'], sd[bp + 'mlp.c_fc.bias'], keep_f32=True)))
+        x = _r(x + linear(h, sd[bp + 'mlp.c_proj.weight'], sd[bp + 'mlp.c_proj.bias'], keep_f32=True))
         i += 1
     return x
 
@@ -104,7 +168,7 @@ def vit_trunk(sd, pre, image):
 def encode_image(sd, pre, image):
     """CLIP.encode_image(return_hidden=True) (clip/model.py:340-346): ln_post on ALL tokens, then @ proj."""
     x = vit_trunk(sd, pre, image)
-    return layer_norm(x, sd[pre + 'ln_post.weight'], sd[pre + 'ln_post.bias'], 1e-5) @ sd[pre + 'proj']
+    return _r(layer_norm(x, sd[pre + 'ln_post.weight'], sd[pre + 'ln_post.bias'], 1e-5) @ _w(sd[pre + 'proj']))
 
 
 # --------------------------------------------------------------------------------------- BERT
@@ -119,21 +183,21 @@ def bert_forward(sd, pre, ids, mask, heads):
     x = F.embedding(ids, sd[pre + 'embeddings.word_embeddings.weight'], padding_idx=0) \
         + sd[pre + 'embeddings.position_embeddings.weight'][:L] \
         + sd[pre + 'embeddings.token_type_embeddings.weight'][0]
-    x = layer_norm(x, sd[pre + 'embeddings.LayerNorm.weight'], sd[pre + 'embeddings.LayerNorm.bias'], 1e-12)
+    x = layer_norm(_r(x), sd[pre + 'embeddings.LayerNorm.weight'], sd[pre + 'embeddings.LayerNorm.bias'], 1e-12)
     kpm = ~mask.bool()
     i = 0
     while f'{pre}encoder.layer.{i}.attention.self.query.weight' in sd:
         lp = f'{pre}encoder.layer.{i}.'
-        q = F.linear(x, sd[lp + 'attention.self.query.weight'], sd[lp + 'attention.self.query.bias'])
-        k = F.linear(x, sd[lp + 'attention.self.key.weight'], sd[lp + 'attention.self.key.bias'])
-        v = F.linear(x, sd[lp + 'attention.self.value.weight'], sd[lp + 'attention.self.value.bias'])
+        q = linear(x, sd[lp + 'attention.self.query.weight'], sd[lp + 'attention.self.query.bias'])
+        k = linear(x, sd[lp + 'attention.self.key.weight'], sd[lp + 'attention.self.key.bias'])
+        v = linear(x, sd[lp + 'attention.self.value.weight'], sd[lp + 'attention.self.value.bias'])
         a = attention_core(q, k, v, heads, kpm)
-        a = F.linear(a, sd[lp + 'attention.output.dense.weight'], sd[lp + 'attention.output.dense.bias'])
-        x = layer_norm(x + a, sd[lp + 'attention.output.LayerNorm.weight'],
+        a = linear(a, sd[lp + 'attention.output.dense.weight'], sd[lp + 'attention.output.dense.bias'], keep_f32=True)
+        x = layer_norm(_r(x + a), sd[lp + 'attention.output.LayerNorm.weight'],
                        sd[lp + 'attention.output.LayerNorm.bias'], 1e-12)
-        h = gelu_erf(F.linear(x, sd[lp + 'intermediate.dense.weight'], sd[lp + 'intermediate.dense.bias']))
-        h = F.linear(h, sd[lp + 'output.dense.weight'], sd[lp + 'output.dense.bias'])
-        x = layer_norm(x + h, sd[lp + 'output.LayerNorm.weight'], sd[lp + 'output.LayerNorm.bias'], 1e-12)
+        h = _r(gelu_erf(linear(x, sd[lp + 'intermediate.dense.weight'], sd[lp + 'intermediate.dense.bias'], keep_f32=True)))
+        h = linear(h, sd[lp + 'output.dense.weight'], sd[lp + 'output.dense.bias'], keep_f32=True)
+        x = layer_norm(_r(x + h), sd[lp + 'output.LayerNorm.weight'], sd[lp + 'output.LayerNorm.bias'], 1e-12)
         i += 1
     return x
 
@@ -149,9 +213,9 @@ def cross_attention(sd, pre, tgt, memory, key_padding_mask=None, heads=8):
     while f'{pre}layers.{i}.linear1.weight' in sd:
         lp = f'{pre}layers.{i}.'
         a = torch_mha(sd, lp + 'multihead_attn.', tgt, memory, heads, key_padding_mask)
-        h = gelu_erf(F.linear(a, sd[lp + 'linear1.weight'], sd[lp + 'linear1.bias']))
-        h = F.linear(h, sd[lp + 'linear2.weight'], sd[lp + 'linear2.bias'])
-        tgt = layer_norm(tgt + h, sd[lp + 'norm2.weight'], sd[lp + 'norm2.bias'], 1e-5)
+        h = _r(gelu_erf(linear(a, sd[lp + 'linear1.weight'], sd[lp + 'linear1.bias'], keep_f32=True)))
+        h = linear(h, sd[lp + 'linear2.weight'], sd[lp + 'linear2.bias'], keep_f32=True)
+        tgt = layer_norm(_r(tgt + h), sd[lp + 'norm2.weight'], sd[lp + 'norm2.bias'], 1e-5)
         i += 1
     return tgt
 
@@ -160,8 +224,8 @@ def interaction_with_caption(sd, image_embeds, caption_hidden, key_padding_mask)
     """RetrievalModel.interaction_with_caption (models/model_retrieval_caption.py:76-84).
     All tensors batch-major here: returns (after_image [b,N,vw], after_caption [b,n,vw], ori_caption [b,n,vw])."""
     b = image_embeds.shape[0]
-    queries = sd['queries'].permute(1, 0, 2).expand(b, -1, -1)
-    cap = F.linear(caption_hidden, sd['caption_proj.weight'], sd['caption_proj.bias'])
+    queries = _r(sd['queries'].permute(1, 0, 2).expand(b, -1, -1))
+    cap = linear(caption_hidden, sd['caption_proj.weight'], sd['caption_proj.bias'])
     ori_caption = cross_attention(sd, 'crossattn_query.', queries, cap, key_padding_mask)
     after_image = cross_attention(sd, 'crossattn.', image_embeds, ori_caption)
     after_caption = cross_attention(sd, 'crossattn2.', ori_caption, image_embeds)
@@ -245,8 +309,8 @@ def caption_vision_loss(sd, ori_caption, ori_image, idx):
     tensors, project, F.normalize with its default dim=1 (the TOKEN axis), all token pairs, mean over both
     token axes, soft-label CE in one direction.  ori_caption [b,n,vw], ori_image [b,N,vw] batch-major."""
     img, cap = gather_rows(ori_image), gather_rows(ori_caption)
-    cap = F.normalize(F.linear(cap, sd['cproj.weight'], sd['cproj.bias']), dim=1)
-    img = F.normalize(F.linear(img, sd['vproj.weight'], sd['vproj.bias']), dim=1)
+    cap = F.normalize(linear(cap, sd['cproj.weight'], sd['cproj.bias']), dim=1)
+    img = F.normalize(linear(img, sd['vproj.weight'], sd['vproj.bias']), dim=1)
     sim = torch.einsum('icd,jvd->ijcv', cap, img).mean(-1).mean(-1)
     lab = soft_labels(gather_rows(idx.view(-1, 1)))
     return -(torch.log_softmax(sim, 1) * lab).sum(1).mean()
@@ -262,8 +326,8 @@ def caption_regularization(ori_caption):
 def get_features(sd, image_embeds=None, text_embeds=None):
     """XVLMBase.get_features (models/xvlm.py:241-256): CLS -> Linear -> L2 normalise."""
     if image_embeds is not None:
-        return F.normalize(F.linear(image_embeds[:, 0, :], sd['vision_proj.weight'], sd['vision_proj.bias']), dim=-1)
-    return F.normalize(F.linear(text_embeds[:, 0, :], sd['text_proj.weight'], sd['text_proj.bias']), dim=-1)
+        return F.normalize(linear(image_embeds[:, 0, :], sd['vision_proj.weight'], sd['vision_proj.bias'], keep_f32=True), dim=-1)
+    return F.normalize(linear(text_embeds[:, 0, :], sd['text_proj.weight'], sd['text_proj.bias'], keep_f32=True), dim=-1)
 
 
 # --------------------------------------------------------------------------------------- full step
@@ -282,7 +346,7 @@ def retrieval_forward(sd, cfg, image, ids_s, mask_s, ids_t, mask_t, ids_c, mask_
     l_vs = contrastive_loss(feat_v, feat_s, temp, idx)
     l_vt = contrastive_loss(feat_v, feat_t, temp, idx)
     l_st = contrastive_loss(feat_s, feat_t, temp, idx)
-    cq = F.linear(after_caption, sd['caption_proj1.weight'], sd['caption_proj1.bias'])
+    cq = linear(after_caption, sd['caption_proj1.weight'], sd['caption_proj1.bias'], keep_f32=True)
     l_c = caption_contrastive_loss(cq, feat_s, temp) + caption_contrastive_loss(cq, feat_t, temp)
     wd = cfg['weight_dstl_loss']
     l_vt = l_vt * (1 - wd) + dstl_loss(feat_v, cq, feat_s, feat_t) * wd
@@ -309,8 +373,8 @@ def video_interaction_with_caption(sd, video_embeds, caption_hidden, key_padding
     """video_model_retrieval_caption.py:96-108: as the image model, except that crossattn2 (caption queries attending to
     the frames) masks the padded frames; crossattn (frames attending to the caption queries) is unmasked."""
     b = video_embeds.shape[0]
-    queries = sd['queries'].permute(1, 0, 2).expand(b, -1, -1)
-    cap = F.linear(caption_hidden, sd['caption_proj.weight'], sd['caption_proj.bias'])
+    queries = _r(sd['queries'].permute(1, 0, 2).expand(b, -1, -1))
+    cap = linear(caption_hidden, sd['caption_proj.weight'], sd['caption_proj.bias'])
     ori_caption = cross_attention(sd, 'crossattn_query.', queries, cap, key_padding_mask)
     after_video = cross_attention(sd, 'crossattn.', video_embeds, ori_caption)
     after_caption = cross_attention(sd, 'crossattn2.', ori_caption, video_embeds, video_kpm)
@@ -321,15 +385,15 @@ def video_get_features(sd, video_embeds, video_mask):
     """XVLMBase_video.get_features, vis_pooling='mean' (models/xvlm_video.py:260-272): masked mean over the frames ->
     vision_proj -> L2 normalise."""
     m = video_mask.unsqueeze(-1).to(video_embeds.dtype)
-    pooled = (video_embeds * m).sum(1) / m.sum(1)
-    return F.normalize(F.linear(pooled, sd['vision_proj.weight'], sd['vision_proj.bias']), dim=-1)
+    pooled = _r((video_embeds * m).sum(1) / m.sum(1))
+    return F.normalize(linear(pooled, sd['vision_proj.weight'], sd['vision_proj.bias'], keep_f32=True), dim=-1)
 
 
 def video_caption_vision_loss(sd, ori_caption, ori_video, idx):
     """caption_vision_loss of the video model (video_model_retrieval_caption.py:144-169): the image model's arithmetic on
     the LOCAL batch (its all-gathers are commented out), padded frames included as they are."""
-    cap = F.normalize(F.linear(ori_caption, sd['cproj.weight'], sd['cproj.bias']), dim=1)
-    vid = F.normalize(F.linear(ori_video, sd['vproj.weight'], sd['vproj.bias']), dim=1)
+    cap = F.normalize(linear(ori_caption, sd['cproj.weight'], sd['cproj.bias']), dim=1)
+    vid = F.normalize(linear(ori_video, sd['vproj.weight'], sd['vproj.bias']), dim=1)
     sim = torch.einsum('icd,jvd->ijcv', cap, vid).mean(-1).mean(-1)
     lab = soft_labels(idx.view(-1, 1))
     return -(torch.log_softmax(sim, 1) * lab).sum(1).mean()
@@ -350,7 +414,7 @@ def video_retrieval_forward(sd, cfg, video, video_mask, ids_s, mask_s, ids_t, ma
     l_vs = contrastive_loss(feat_v, feat_s, temp, idx)
     l_vt = contrastive_loss(feat_v, feat_t, temp, idx)
     l_st = contrastive_loss(feat_s, feat_t, temp, idx)
-    cq = F.linear(after_caption, sd['caption_proj1.weight'], sd['caption_proj1.bias'])
+    cq = linear(after_caption, sd['caption_proj1.weight'], sd['caption_proj1.bias'], keep_f32=True)
     l_c = caption_contrastive_loss(cq, feat_s, temp) + caption_contrastive_loss(cq, feat_t, temp)
     wd = cfg['weight_dstl_loss']
     l_vt = l_vt * (1 - wd) + dstl_loss(feat_v, cq, feat_s, feat_t) * wd

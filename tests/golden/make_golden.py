@@ -396,18 +396,130 @@ def fixture_video_w1():
     print('video_tiny_w1 losses', out['losses'])
 
 
+# ----------------------------------------------------------------------------- full-geometry fixtures
+B16_VIT_1L = dict(embed_dim=512, image_resolution=384, vision_layers=1, vision_width=768, vision_patch_size=16,
+                  context_length=8, vocab_size=32, transformer_width=64, transformer_heads=1, transformer_layers=1)
+B16_VIT = dict(B16_VIT_1L, vision_layers=12)
+MBERT = dict(vocab_size=119547, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+             max_position_embeddings=512, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
+FULL_CFG = {'embed_dim': 256, 'temp': 0.07, 'use_one_cl_proj_only': False, 'caption_encoder_name': 'mbert',
+            'num_queries': 4, 'caption_ca_layer': 3, 'caption_interaction_layer': 2, 'weight_reg_loss': 0.01,
+            'weight_caption_loss': 0.01, 'weight_dstl_loss': 0.5, 'weight_cv_loss': 0.01}      # = leccr_amd.synthetic.MULTI30K_CFG
+
+def fixture_vit_b16_1layer(clip_model):
+    """The reference's CLIP ViT at the REAL B/16 geometry (577 tokens, width 768, 12 heads, patch 16, res 384;
+    clip/model.py:408-445), one layer, b = 2: checks the 577-token tiling of the production kernels.  Weights and inputs
+    come from tests.helpers.seeded_fill_ / a seeded generator (rebuilt by the tests), outputs are stored as slices."""
+    from tests.golden_slices import B16_GRAD_SLICES
+    from tests.helpers import seeded_fill_
+    torch.manual_seed(0)
+    clip = clip_model.CLIP(**B16_VIT_1L).float().eval()
+    sums = seeded_fill_(clip.visual.named_parameters(), 51)
+    g = torch.Generator().manual_seed(52)
+    image = torch.randn(2, 3, 384, 384, generator=g)
+    cls, hidden = clip.encode_image(image, return_hidden=True)
+    trunk = clip.visual(image)
+    probe = torch.randn(hidden.shape, generator=g)
+    (hidden * probe).sum().backward()
+    rows = [0, 1, 288, 575, 576]
+    out = {'hidden_rows': hidden[:, rows, :].detach().numpy(), 'rows': np.array(rows), 'hidden_cols16': hidden[:, :, ::16].detach().numpy(),
+           'trunk_cols16': trunk[:, :, ::16].detach().numpy(), 'hidden_sq_sum': np.array(float((hidden.double() ** 2).sum())),
+           'wsum_names': np.array(sorted(sums)), 'wsum': np.array([sums[k] for k in sorted(sums)])}
+    named = dict(clip.visual.named_parameters())
+    for k, sl in B16_GRAD_SLICES.items():
+        gk = named[k].grad
+        out['g/' + k] = (gk if sl is None else gk[sl]).detach().numpy()
+        out['gn/' + k] = np.array(float(gk.double().norm()))
+    np.savez_compressed(os.path.join(OUT, 'vit_b16_1layer.npz'), **out)
+    print('vit_b16_1layer', hidden.shape, float(hidden.abs().mean()), os.path.getsize(os.path.join(OUT, 'vit_b16_1layer.npz')))
+
+
+def fixture_full_step_b16(clip_model, xvlm):
+    """SURVEY 8(c) `full_step_b16`: the reference RetrievalModel at the REAL ViT-B/16@384 + mBERT geometry (12 + 12 layers,
+    vocab 119 547, 4 queries, 3 + 2 + 2 interaction layers), b = 4, L_t = L_c = 12, seeded weights (tests.helpers.seeded_fill_):
+    its five losses, the three feature matrices and norms / slices of a few gradients.  No weight payload: the GPU test
+    rebuilds the same weights from the seed and must reproduce these numbers with the HIP model directly."""
+    from tests.helpers import full_step_batch, seeded_fill_
+
+    def _clip(config=None):
+        return clip_model.CLIP(**B16_VIT).float(), B16_VIT['embed_dim']
+
+    def _bert(config=None):
+        from transformers import BertConfig, BertModel
+        return BertModel(BertConfig(**MBERT)), MBERT['hidden_size']
+
+    xvlm.build_clip_encoder = _clip
+    xvlm.build_text_encoder = _bert
+    from models.model_retrieval_caption import RetrievalModel
+    torch.manual_seed(61)
+    model = RetrievalModel(dict(FULL_CFG))
+    model.init_caption_encoder()
+    sums = seeded_fill_(model.named_parameters(), 61)
+    model.eval()
+    batch = full_step_batch()
+    with torch.no_grad():
+        v, _ = model.get_vision_embeds(batch['image'])
+        c = model.get_caption_embeds(batch['ids_c'], batch['mask_c'])
+        a_img, a_cap, o_cap = model.interaction_with_caption(image_embeds=v, caption_embeds=c,
+                                                             key_padding_mask=~batch['mask_c'].bool())
+        feat_v = model.get_features(a_img.transpose(0, 1).contiguous(), None)
+        feat_s = model.get_features(None, model.get_text_embeds(batch['ids_s'], batch['mask_s']))
+        feat_t = model.get_features(None, model.get_text_embeds(batch['ids_t'], batch['mask_t']))
+    losses = run_forward(model, batch)
+    sum(losses).backward()
+    named = dict(model.named_parameters())
+    out = {'losses': np.array([float(l) for l in losses], dtype=np.float64), 'feat_v': feat_v.numpy(), 'feat_s': feat_s.numpy(),
+           'feat_t': feat_t.numpy(), 'vision_cols32': v[:, :, ::32].numpy(), 'caption_hidden_cols32': c[:, :, ::32].numpy(),
+           'after_caption': a_cap.numpy(), 'ori_caption_cols8': o_cap[:, :, ::8].numpy(),
+           'wsum_names': np.array(sorted(sums)), 'wsum': np.array([sums[k] for k in sorted(sums)])}
+    from tests.golden_slices import FULL_STEP_GRAD_SLICES as keep
+    for k, sl in keep.items():
+        gk = named[k].grad
+        out['g/' + k] = np.asarray((gk if sl is None else gk[sl]).detach().numpy())
+        out['gn/' + k] = np.array(float(gk.double().norm()))
+    np.savez_compressed(os.path.join(OUT, 'full_step_b16.npz'), **out)
+    print('full_step_b16 losses', out['losses'], os.path.getsize(os.path.join(OUT, 'full_step_b16.npz')))
+
+
+def fixture_pos_embed(clip_model):
+    """interpolate_pos_embed (clip/model.py:456-481) on seeded tables: the ViT-B/16 (14x14 -> 24x24), B/32 (7x7 -> 12x12)
+    and L/14 (16x16 -> 27x27) cases of build_model at its hard-coded 384 resolution."""
+    out = {}
+    g = torch.Generator().manual_seed(71)
+    for name, g0, g1, d in (('b16', 14, 24, 48), ('b32', 7, 12, 48), ('l14', 16, 27, 32)):
+        pe = torch.randn(1, 1 + g0 * g0, d, generator=g)
+        out[name + '/in'] = pe.numpy()
+        out[name + '/out'] = clip_model.interpolate_pos_embed(pe, num_patches=g1 * g1, num_extra_tokens=1).numpy()
+    np.savez_compressed(os.path.join(OUT, 'pos_embed.npz'), **out)
+    print('pos_embed', {k: v.shape for k, v in out.items()})
+
+
 def main():
+    if os.path.dirname(os.path.dirname(OUT)) not in sys.path:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))          # tests.helpers (seeded_fill_)
+    only = set(sys.argv[1:])
     torch.set_num_threads(4)
     clip_model, xvlm = import_reference()
     if not dist.is_initialized():
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29610')
         dist.init_process_group('gloo', rank=0, world_size=1)
+    if only:            # python tests/golden/make_golden.py full  -> only the full-geometry fixtures (minutes of CPU)
+        assert only <= {'full'}, only
+        torch.set_num_threads(8)
+        fixture_pos_embed(clip_model)
+        fixture_vit_b16_1layer(clip_model)
+        fixture_full_step_b16(clip_model, xvlm)
+        dist.destroy_process_group()
+        return
     fixture_vit(clip_model)
     fixture_bert()
     fixture_model_w1(clip_model, xvlm)
     fixture_losses(clip_model, xvlm)
     fixture_itm_eval()
     fixture_video_w1()
+    fixture_pos_embed(clip_model)
+    fixture_vit_b16_1layer(clip_model)
+    fixture_full_step_b16(clip_model, xvlm)
     dist.destroy_process_group()
     fixture_model_w2()
 

@@ -43,3 +43,79 @@ def grad_close(a, b, rtol, atol=1e-6):
     """|a-b| <= atol + rtol*max|b|  (mathematically-zero gradients, e.g. BERT key biases, are ~1e-8 noise)."""
     b_ = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
     return max_err(a, b) <= atol + rtol * float(np.max(np.abs(b_)))
+
+
+def seeded_fill_(named_params, seed, std=0.03):
+    """Deterministic, geometry-independent weights for FULL-SIZE parity runs, so that no weight file has to be committed:
+    every parameter is filled from its own generator, seeded by crc32(name) ^ seed - the same values whatever module tree
+    yields the names (the reference's classes in tests/golden/make_golden.py, this project's model in the GPU tests, the
+    oracle's flat state dict).  LayerNorm gains 1 + 0.1 r, `temp` and `logit_scale` kept, everything else N(0, std).
+    Returns a small checksum dict that the fixtures store, so a drifted RNG fails as "weights differ", not as a parity error."""
+    import zlib
+    sums = {}
+    with torch.no_grad():
+        for n, p in named_params:
+            if n == 'temp' or n.endswith('logit_scale'):
+                continue
+            g = torch.Generator().manual_seed((zlib.crc32(n.encode()) ^ seed) & 0x7FFFFFFF)
+            r = torch.randn(p.shape, generator=g)
+            if p.dim() == 1 and ('ln' in n.lower() or 'norm' in n.lower()) and n.endswith('weight'):
+                p.copy_(1.0 + 0.1 * r)
+            else:
+                p.copy_(std * r)
+            if p.numel() >= 1 << 16:
+                sums[n] = float(p.detach().double().sum())
+    return sums
+
+
+def seeded_tokens(seed, b, L, vocab, min_len=3):
+    """[CLS]=101 first, [SEP]=102 at a per-row length, 0 padding after; row 0 full length.  -> (ids, mask) int64."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1000, vocab, (b, L), generator=g)
+    lens = torch.randint(min_len, L + 1, (b,), generator=g)
+    lens[0] = L
+    mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+    ids[:, 0] = 101
+    ids[torch.arange(b), lens - 1] = 102
+    return ids * mask, mask
+
+
+# ----------------------------------------------------------------------------------------- full-geometry parity (SURVEY.md 8c)
+MBERT_VOCAB = 119547
+B16_GEOMETRY = dict(embed_dim=512, image_resolution=384, vision_layers=12, vision_width=768, vision_patch_size=16,
+                    context_length=8, vocab_size=32, transformer_width=64, transformer_heads=1, transformer_layers=1)
+MBERT_CONFIG = dict(vocab_size=MBERT_VOCAB, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                    intermediate_size=3072, max_position_embeddings=512)
+
+
+def full_step_batch(b=4, L_t=12, L_c=12):
+    """Inputs of the `full_step_b16` fixture (tests/golden/make_golden.py feeds exactly these to the reference)."""
+    g = torch.Generator().manual_seed(62)
+    image = torch.randn(b, 3, 384, 384, generator=g)
+    ids_s, m_s = seeded_tokens(63, b, L_t, MBERT_VOCAB)
+    ids_t, m_t = seeded_tokens(64, b, L_t, MBERT_VOCAB)
+    ids_c, m_c = seeded_tokens(65, b, L_c, MBERT_VOCAB)
+    idx = torch.arange(b) + 7
+    idx[b - 1] = idx[1]
+    return dict(image=image, ids_s=ids_s, mask_s=m_s, ids_t=ids_t, mask_t=m_t, ids_c=ids_c, mask_c=m_c, idx=idx)
+
+
+def check_weight_sums(sums, z):
+    """The seeded weights rebuilt here are the ones the fixture was captured with (else: RNG drift, not a parity failure)."""
+    names = [str(n) for n in z['wsum_names']]
+    assert set(names) <= set(sums), sorted(set(names) - set(sums))[:4]
+    for n, want in zip(names, z['wsum']):
+        assert abs(sums[n] - float(want)) <= 1e-6 * (1.0 + abs(float(want))), ('seeded weights differ from the fixture', n)
+
+
+def full_geometry_model(compute_dtype='fp32', vision_layers=12, seed=61, text_config=None):
+    """This project's RetrievalModel at the real ViT-B/16@384 + mBERT geometry with the `full_step_b16` seeded weights (CPU;
+    the caller moves it to the GPU).  -> (model, checksum dict)."""
+    from leccr_amd.models import RetrievalModel
+    from leccr_amd.synthetic import MULTI30K_CFG
+    cfg = dict(MULTI30K_CFG, clip_geometry=dict(B16_GEOMETRY, vision_layers=vision_layers), text_config=dict(text_config or MBERT_CONFIG),
+               compute_dtype=compute_dtype)
+    model = RetrievalModel(cfg)
+    model.init_caption_encoder()
+    sums = seeded_fill_(model.named_parameters(), seed)
+    return model, sums

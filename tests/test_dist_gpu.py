@@ -75,7 +75,6 @@ def _train_worker(rank, world, port, fused, ret):
         opt.zero_grad()
         sum(losses).backward()
         opt.step()
-    ops.on_early_grads_final = None
     a = model.arena
     ret[(fused, rank)] = (a.data.detach().cpu().numpy().copy(), a.step_count)
     dist.barrier()

@@ -127,10 +127,11 @@ def _gather_worker(rank, world, port, ret):
         class arena:
             grad = torch.full((10,), float(rank + 1))
             early_numel = 6                                              # [0,6) early region, [6,10) late (ViT) region
+            on_late_backward_start = on_vit_block_backward = None
         grad_sync, grad_scale = None, 1.0
     from leccr_amd import ops
     opt = attach_grad_sync(FakeOpt)
-    ops.on_late_backward_start()                                         # what the first ViT backward node triggers
+    FakeOpt.arena.on_late_backward_start()                               # what the first ViT backward node fires (ops._fire)
     opt.grad_sync()
     ok &= torch.allclose(FakeOpt.arena.grad * opt.grad_scale, torch.full((10,), 1.5))   # mean over the 2 ranks
     ret[rank] = bool(ok)
@@ -156,6 +157,15 @@ def test_launcher_and_script_cli_match_the_reference_flags():
     t = task.build_parser().parse_args(['--config', 'c.yaml', '--bs', '128', '--epoch', '2', '--evaluate'])
     assert t.bs == 128 and t.evaluate and t.checkpoint == 'null' and t.distributed is True and t.seed == 42
     assert {'train', 'evaluation_coarse', 'itm_eval', 'main'} <= set(dir(task))
+    # run.py:108-114,141-142 / run_video.sh:4: the video task goes to the double-sim script with the same flags
+    v = run.build_parser().parse_args(['--dist', 'f2', '--task', 'itr_video_caption', '--config', 'configs/cclm-base-ft/Retrieval_msrvtt.yaml',
+                                       '--output_dir', 'outputs/msrvtt/full', '--bs', '128', '--seed', '42', '--epoch', '50',
+                                       '--checkpoint', 'null'])
+    vcmd = run.build_command(v)
+    assert 'video_Retrieval_caption_double_sim.py' in vcmd and '--nproc-per-node=2' in vcmd and 'CUDA_VISIBLE_DEVICES=0,1' in vcmd
+    assert '--bs 128' in vcmd and '--epoch 50' in vcmd and '--config configs/cclm-base-ft/Retrieval_msrvtt.yaml' in vcmd
+    with pytest.raises(NotImplementedError):                    # run.py:144-145
+        run.build_command(run.build_parser().parse_args(['--task', 'itr_nope', '--dist', '1']))
 
 
 def test_prefetcher_and_deferred_scalars_passthrough_on_cpu():

@@ -286,7 +286,9 @@ def _unit(shape, seed):
 
 @pytest.mark.parametrize('G,D,use_idx,both', [(6, 16, True, True), (70, 256, True, True), (256, 256, False, True),
                                               (130, 512, True, False), (33, 64, False, False), (70, 768, True, False),
-                                              (40, 1024, False, True), (600, 4096, True, False)])
+                                              (40, 1024, False, True), (600, 4096, True, False),
+                                              # BASELINE configs C / E: the global contrastive batch over 8 GPUs (models/xvlm.py:260-292)
+                                              (1024, 256, True, True), (2048, 256, True, True), (2048, 768, True, False)])
 def test_sim_infonce(K, G, D, use_idx, both):
     a, b = _unit((G, D), 70), _unit((G, D), 71)
     idx = torch.arange(G)
@@ -329,7 +331,7 @@ def test_sim_infonce(K, G, D, use_idx, both):
         assert abs(dt_sum - float(dtemp)) <= 1e-4 * abs(float(dtemp)) + 1e-6
 
 
-@pytest.mark.parametrize('b,n,D', [(6, 4, 16), (70, 4, 256), (256, 2, 256)])
+@pytest.mark.parametrize('b,n,D', [(6, 4, 16), (70, 4, 256), (256, 2, 256), (256, 4, 256)])
 def test_capsim(K, b, n, D):
     c, t = _rand((b, n, D), torch.float32, 72, 0.2), _unit((b, D), 73)
     cd, tdd = c.double().requires_grad_(True), t.double().requires_grad_(True)
@@ -347,7 +349,7 @@ def test_capsim(K, b, n, D):
         assert e <= 1e-4 * s + 1e-7, (name, e, s)
 
 
-@pytest.mark.parametrize('G,n,D', [(6, 4, 16), (70, 4, 256), (256, 4, 256)])
+@pytest.mark.parametrize('G,n,D', [(6, 4, 16), (70, 4, 256), (256, 4, 256), (1024, 4, 256), (2048, 4, 256)])   # G = 1024 / 2048: configs C / E
 def test_dstl(K, G, n, D):
     v, s, t = _unit((G, D), 74), _unit((G, D), 75), _unit((G, D), 76)
     c = _rand((G, n, D), torch.float32, 77, 0.2)

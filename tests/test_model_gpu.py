@@ -289,7 +289,6 @@ def test_optimizer_fused_into_backward_moves_parameters_identically(dtype):
             opt.step()
             sched.step()
         from leccr_amd import ops
-        ops.on_early_grads_final = None
         a = model.arena
         return a.data.clone(), a.state_m.clone(), a.state_v.clone(), a.step_count, float(losses[0].detach())
     pf, mf, vf, nf, lf = train(True)

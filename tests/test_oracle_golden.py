@@ -173,3 +173,89 @@ def test_video_full_forward_backward_w1():
             checked += 1
     assert checked > 90
     assert any(k.startswith('g/vid_encoder.layers.1.') for k in z) and not any(k.startswith('w/clip_encoder.') for k in z)
+
+
+# ----------------------------------------------------------------------------------------- full geometry
+def _fill_oracle_state(module_named_params, seed):
+    from tests.helpers import seeded_fill_
+    named = list(module_named_params)
+    sums = seeded_fill_(named, seed)
+    return {n: p.detach().clone() for n, p in named}, sums
+
+
+def test_vit_b16_one_layer_real_geometry_vs_reference():
+    """The oracle's ViT at the REAL B/16 geometry (577 tokens, 768 wide, 12 heads of 64, patch 16 at 384) against the
+    reference's CLIP class on the same seeded weights / image (tests/golden/vit_b16_1layer.npz): trunk, hidden, gradients."""
+    from leccr_amd.models.clip_vit import CLIP
+    from tests.helpers import B16_GEOMETRY, check_weight_sums
+    z = load_npz('vit_b16_1layer.npz')
+    clip = CLIP(text_tower=False, **dict(B16_GEOMETRY, vision_layers=1))
+    sd, sums = _fill_oracle_state(clip.visual.named_parameters(), 51)
+    check_weight_sums(sums, z)
+    for v in sd.values():
+        v.requires_grad_(True)
+    g = torch.Generator().manual_seed(52)
+    image = torch.randn(2, 3, 384, 384, generator=g)
+    trunk = O.vit_trunk(sd, '', image)
+    assert max_err(trunk[:, :, ::16], z['trunk_cols16']) < 5e-5
+    hidden = O.encode_image(sd, '', image)
+    assert max_err(hidden[:, [int(r) for r in z['rows']], :], z['hidden_rows']) < 5e-5
+    assert max_err(hidden[:, :, ::16], z['hidden_cols16']) < 5e-5
+    assert abs(float((hidden.double() ** 2).sum()) - float(z['hidden_sq_sum'])) < 1e-5 * float(z['hidden_sq_sum'])
+    probe = torch.randn(hidden.shape, generator=g)
+    (hidden * probe).sum().backward()
+    from tests.golden_slices import B16_GRAD_SLICES
+    n = 0
+    for k, sl in B16_GRAD_SLICES.items():
+        gk = sd[k].grad
+        assert abs(float(gk.double().norm()) - float(z['gn/' + k])) <= 2e-4 * float(z['gn/' + k]), k
+        assert grad_close(gk if sl is None else gk[sl], z['g/' + k], GRAD_TOL), k
+        n += 1
+    assert n == 10
+
+
+def test_full_step_b16_mbert_forward_vs_reference():
+    """SURVEY 8(c) `full_step_b16`: the oracle at the real ViT-B/16@384 + mBERT geometry (12 + 12 layers, vocab 119 547) on the
+    seeded weights reproduces the REFERENCE's features and five losses (forward only here: ~20 s of CPU; the gradients of this
+    fixture are checked against the HIP model on the GPU)."""
+    from tests.helpers import check_weight_sums, full_geometry_model, full_step_batch
+    z = load_npz('full_step_b16.npz')
+    model, sums = full_geometry_model()
+    check_weight_sums(sums, z)
+    sd = {k: v.detach() for k, v in model.state_dict().items() if not k.startswith('caption_encoder.')}
+    del model
+    b = full_step_batch()
+    torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    with torch.no_grad():
+        vis = O.encode_image(sd, 'clip_encoder.visual.', b['image'])
+        assert max_err(vis[:, :, ::32], z['vision_cols32']) < 1e-4
+        cap = O.bert_forward(sd, 'text_encoder.', b['ids_c'], b['mask_c'], 12)
+        assert max_err(cap[:, :, ::32], z['caption_hidden_cols32']) < 1e-4
+        after_image, after_caption, ori_caption = O.interaction_with_caption(sd, vis, cap, ~b['mask_c'].bool())
+        assert max_err(after_caption.transpose(0, 1), z['after_caption']) < 1e-4
+        assert max_err(O.get_features(sd, image_embeds=after_image), z['feat_v']) < 2e-5
+        assert max_err(O.get_features(sd, text_embeds=O.bert_forward(sd, 'text_encoder.', b['ids_s'], b['mask_s'], 12)), z['feat_s']) < 2e-5
+        losses = O.retrieval_forward(sd, TINY_CFG, b['image'], b['ids_s'], b['mask_s'], b['ids_t'], b['mask_t'], b['ids_c'],
+                                     b['mask_c'], b['idx'], text_heads=12)
+    got = np.array([float(l) for l in losses])
+    assert np.max(np.abs(got - z['losses'])) < 1e-4, (got, z['losses'])
+
+
+def test_interpolate_pos_embed_vs_reference():
+    """leccr_amd.models.clip_vit.interpolate_pos_embed (own separable cubic-convolution resampling) against the reference's
+    function (clip/model.py:456-481, F.interpolate bicubic) on the B/16, B/32 and L/14 grid sizes; build_model applies it."""
+    from leccr_amd.models.clip_vit import CLIP, build_model, interpolate_pos_embed
+    z = load_npz('pos_embed.npz')
+    for name, n_out in (('b16', 576), ('b32', 144), ('l14', 729)):
+        got = interpolate_pos_embed(T(z[name + '/in']), n_out)
+        assert got.shape == z[name + '/out'].shape and max_err(got, z[name + '/out']) < 2e-5, name
+    same = T(z['b16/out'])
+    assert interpolate_pos_embed(same, 576) is same                       # already 24 x 24: returned unchanged
+    # a raw (224-resolution, 14 x 14 grid) CLIP state dict loads into the 384-resolution tower
+    torch.manual_seed(0)
+    raw = CLIP(32, 224, 1, 64, 16, 8, 32, 64, 1, 1, text_tower=False).state_dict()
+    assert raw['visual.positional_embedding'].shape == (197, 64)
+    clip = build_model(raw)
+    assert clip.visual.positional_embedding.shape == (577, 64) and clip.visual.input_resolution == 384
+    assert torch.equal(clip.visual.positional_embedding[0], raw['visual.positional_embedding'][0])
+    assert torch.equal(clip.visual.conv1.weight, raw['visual.conv1.weight'])
