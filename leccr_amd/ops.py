@@ -129,20 +129,24 @@ def join_wgrad_stream(stream=None):
         cur.wait_stream(s)
 
 
-def lin_dw(dy2, x2, w, b=None, scale=1.0):
-    """dW += scale * dY^T X (f32, into the gradient arena) and db += scale * colsum(dY)."""
+def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None):
+    """dW += scale * dY^T X (f32, into the gradient arena) and db += scale * colsum(dY).
+    dy_bias: the tensor whose column sums are the bias gradient when it is not dy2 itself (an f32 head's incoming gradient,
+    of which dy2 is the bf16 GEMM operand: the bias sum cancels heavily and is taken from the unrounded values)."""
     global _wgrad_stream, _wgrad_join_queued
     if not (wgrad_overlap and dy2.is_cuda):
-        return _lin_dw(dy2, x2, w, b, scale)
+        return _lin_dw(dy2, x2, w, b, scale, dy_bias)
     main = torch.cuda.current_stream()
     if _wgrad_stream is None:
         _wgrad_stream = torch.cuda.Stream(device=dy2.device)
     side = _wgrad_stream
     side.wait_stream(main)                      # dY and X were produced on the main stream
     with torch.cuda.stream(side):
-        _lin_dw(dy2, x2, w, b, scale)
+        _lin_dw(dy2, x2, w, b, scale, dy_bias)
     dy2.record_stream(side)                     # the caching allocator must not recycle them under the side stream
     x2.record_stream(side)
+    if dy_bias is not None:
+        dy_bias.record_stream(side)
     if not _wgrad_join_queued:
         # once per backward pass: when the autograd engine has run every node, the main stream waits for the side stream,
         # so whatever follows backward() (optimizer, gradient all-reduce, a test reading .grad) sees complete gradients
@@ -157,15 +161,16 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0):
             main.wait_stream(side)
 
 
-def _lin_dw(dy2, x2, w, b, scale):
+def _lin_dw(dy2, x2, w, b, scale, dy_bias=None):
     K.gemm(dy2, x2, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale)
     _mark(w)
     if b is not None:
+        src = dy2 if dy_bias is None else dy_bias
         if scale == 1.0:
-            K.colsum(dy2, b._g.reshape(-1))
+            K.colsum(src, b._g.reshape(-1))
         else:
             tmp = torch.zeros(b._g.numel(), device=dy2.device, dtype=torch.float32)
-            K.colsum(dy2, tmp)
+            K.colsum(src, tmp)
             K.axpy(tmp, b._g.reshape(-1), scale)
         _mark(b)
 
@@ -210,11 +215,11 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x2,) = ctx.saved_tensors
-        dy2 = _rows(dy.contiguous())
+        dy2 = dyf = _rows(dy.contiguous())
         if dy2.dtype != x2.dtype:               # f32 head output: the GEMM operands share the compute dtype
             dy2 = dy2.to(x2.dtype)
         dx = lin_dx(dy2, ctx.w).view(ctx.shape) if ctx.needs_input_grad[0] else None
-        lin_dw(dy2, x2, ctx.w, ctx.b, ctx.scale)
+        lin_dw(dy2, x2, ctx.w, ctx.b, ctx.scale, dy_bias=None if dyf is dy2 else dyf)
         return dx, None, None, None, None
 
 

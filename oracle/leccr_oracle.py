@@ -99,6 +99,41 @@ def gelu_erf(x):
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
+class _FlashBF16(torch.autograd.Function):
+    """lowp() only: the storage model of a bf16 flash attention (attention kernels).  Forward: f32
+    scores from bf16 q / k, probabilities rounded to bf16 for the PV product, the normaliser summed from those rounded
+    values, the output stored in bf16.  Backward: probabilities recomputed in f32 from the saved log-sum-exp, the softmax row
+    constant taken as rowsum(dO * O) from the STORED (bf16) output - not as sum_j P_ij dP_ij - and dS / P rounded to bf16 as
+    operands of the dQ / dK / dV products.  q, k, v: [b, h, L, hd] (bf16-representable values)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale):
+        s = (q @ k.transpose(-1, -2)) * scale
+        if mask is not None:
+            s = s.masked_fill(mask[:, None, None, :], float('-inf'))
+        m = s.amax(-1, keepdim=True)
+        e = torch.exp(s - m).bfloat16().float()
+        l = e.sum(-1, keepdim=True)
+        o = ((e @ v) / l).bfloat16().float()
+        ctx.save_for_backward(q, k, v, o, m + torch.log(l))
+        ctx.mask, ctx.scale = mask, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        do = do.bfloat16().float()
+        s = (q @ k.transpose(-1, -2)) * ctx.scale
+        if ctx.mask is not None:
+            s = s.masked_fill(ctx.mask[:, None, None, :], float('-inf'))
+        p = torch.exp(s - lse)
+        dp = do @ v.transpose(-1, -2)
+        delta = (do * o).sum(-1, keepdim=True)
+        ds = (p * (dp - delta)).bfloat16().float()
+        r = lambda t: t.bfloat16().float()
+        return r((ds @ k) * ctx.scale), r((ds.transpose(-1, -2) @ q) * ctx.scale), r(p.bfloat16().float().transpose(-1, -2) @ do), None, None
+
+
 def attention_core(q, k, v, heads, key_padding_mask=None):
     """Scaled dot-product attention, batch-major.  q [b,Lq,d], k/v [b,Lk,d]; mask [b,Lk] True = ignore.
 
@@ -114,13 +149,12 @@ def attention_core(q, k, v, heads, key_padding_mask=None):
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float('-inf'))
-    if _LOWP:       # the PV product takes bf16 probabilities; the normaliser is the sum of those same rounded values
-        e = _r(torch.exp(s - s.amax(-1, keepdim=True)))
-        o = (e @ vh) / e.sum(-1, keepdim=True)
+    if _LOWP:
+        o = _FlashBF16.apply(qh, kh, vh, key_padding_mask, 1.0 / math.sqrt(hd))
     else:
         p = torch.softmax(s, dim=-1)
         o = p @ vh
-    return _r(o.permute(0, 2, 1, 3).reshape(b, Lq, d))
+    return o.permute(0, 2, 1, 3).reshape(b, Lq, d)
 
 
 def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None, keep_f32=False):

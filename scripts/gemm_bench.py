@@ -33,4 +33,18 @@ for name, tn, m, n, k in SH:
     for _ in range(reps): f()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f'{name:12s} M={m:6d} N={n:5d} K={k:6d}  {ms*1e3:9.1f} us  {2*m*n*k/ms/1e9:8.1f} TFLOP/s', flush=True)
+    lib_tf = float('nan')
+    if os.environ.get('LIBCMP', '0') != '0':
+        # measurement only: what the vendor library (torch.mm -> hipBLASLt / rocBLAS) reaches on the same operands, as a yardstick
+        # for this kernel's headroom.  Not a product path.
+        if tn:
+            g = lambda: torch.mm(a.t(), b)            # [m,k]x[k,n], bf16 out (no f32 accumulate-into-C: an easier job)
+        else:
+            g = lambda: torch.mm(a, b.t())
+        for _ in range(2): g()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps): g()
+        e1.record(); torch.cuda.synchronize()
+        lib_tf = 2 * m * n * k / (e0.elapsed_time(e1) / reps) / 1e9
+    print(f'{name:12s} M={m:6d} N={n:5d} K={k:6d}  {ms*1e3:9.1f} us  {2*m*n*k/ms/1e9:8.1f} TFLOP/s   vendor lib {lib_tf:8.1f}', flush=True)

@@ -18,7 +18,7 @@ def show(title, rows, k=12):
     worst = sorted(live, key=lambda r: -(r[1] / r[2]))[:k]
     for n, err, rn, cos, nz in worst:
         print(f'  rel {err / rn:9.3e}  noise {((nz or 0) / rn):9.3e}  ratio {(err / nz if nz else float("nan")):6.2f}  cos {cos:.5f}  |g|/gmax {rn / gmax:8.2e}  {n}')
-    if live[0][4] is not None:
+    if live and live[0][4] is not None:
         worst = sorted(live, key=lambda r: -(r[1] / (3 * r[4] + 1e-3 * r[2])))[:k]
         print('  -- by err / (3 noise + 1e-3 |g|)')
         for n, err, rn, cos, nz in worst:
@@ -26,20 +26,21 @@ def show(title, rows, k=12):
 
 
 if __name__ == '__main__':
-    for temp in (0.07, 1.0):
+    for temp in ((0.07, 1.0) if 'mid' in sys.argv else ()):
         (got, ref, noise), rows = F.bf16_vs_noise_model(temp)
         print('temp', temp, 'losses hip', got, '\n   ref', ref, '\n   noise', noise)
         show(f'MID bf16 temp {temp}', rows)
-    for dtype in ('fp32', 'bf16'):
+    for dtype in ('bf16',):
         model, _ = F.full_geometry_model(dtype)
         model = model.to('cuda').eval()
         batch = F.multi30k_batch(4)
         torch.set_num_threads(16)
         ref_losses, sd = F.oracle_step(model.state_dict(), batch, 12)
+        sd_noise = F.oracle_step(model.state_dict(), batch, 12, lowp=True)[1] if dtype == 'bf16' else None
         losses = F._forward(model, batch)
         model.arena.zero_grad()
         sum(losses).backward()
         print(dtype, 'full losses hip', [float(l) for l in losses], 'ref', ref_losses)
-        show(f'FULL {dtype}', F.grad_table(model, sd))
+        show(f'FULL {dtype}', F.grad_table(model, sd, sd_noise), k=20)
         del model
         torch.cuda.empty_cache()

@@ -119,3 +119,28 @@ def full_geometry_model(compute_dtype='fp32', vision_layers=12, seed=61, text_co
     model.init_caption_encoder()
     sums = seeded_fill_(model.named_parameters(), seed)
     return model, sums
+
+
+# ----------------------------------------------------------------------------------------- bf16 gradients vs the oracle's noise model
+def grad_rows(model, sd_ref, sd_noise=None):
+    """[(name, |g_hip - g_ref|, |g_ref|, cos(g_hip, g_ref), |g_noise - g_ref| or None)] over every trained parameter.
+    sd_ref / sd_noise: the oracle's state dicts after backward (fp32 / oracle.lowp = bf16 storage model)."""
+    rows = []
+    for name, p in model.named_parameters():
+        r = sd_ref[name].grad
+        if r is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0, name
+            continue
+        g, r = p.grad.detach().cpu().double(), r.double()
+        noise = None if sd_noise is None else float((sd_noise[name].grad.double() - r).norm())
+        rows.append((name, float((g - r).norm()), float(r.norm()), float((g * r).sum() / (g.norm() * r.norm() + 1e-30)), noise))
+    return rows
+
+
+def outside_noise_model(rows, factor=3.0, floor=2e-3):
+    """The tensors whose bf16 HIP gradient is further from the fp32 oracle than `factor` x what bf16 storage alone does to that
+    SAME tensor in the oracle (oracle.lowp) + `floor` of its norm.  One rule for every tensor, large or small norm; gradients
+    under 1e-6 of the largest (mathematically zero: BERT key biases) are skipped."""
+    gmax = max(r[2] for r in rows)
+    return [(n, err / rn, nz / rn, cos, rn / gmax) for n, err, rn, cos, nz in rows
+            if rn >= 1e-6 * gmax and err > factor * nz + floor * rn]

@@ -325,7 +325,7 @@ def test_sim_infonce(K, G, D, use_idx, both):
             das, dbs = K.sim_infonce_bwd(a.to(DEV), b.to(DEV), ia, temp, ws, 1.7, both, dts, rows=(r0, r1 - r0))
             # same rows, possibly another number of reduction slices (f32 atomics): equal to summation-order noise
             for got_, full_ in ((das, da), (dbs, db)):
-                assert float((got_[r0:r1] - full_[r0:r1]).abs().max()) <= 2e-6 * float(full_.abs().max())
+                assert float((got_[r0:r1] - full_[r0:r1]).abs().max()) <= 5e-6 * float(full_.abs().max())
             assert float(das[:r0].abs().sum() + das[r1:].abs().sum() + dbs[:r0].abs().sum() + dbs[r1:].abs().sum()) == 0
             dt_sum += float(dts)
         assert abs(dt_sum - float(dtemp)) <= 1e-4 * abs(float(dtemp)) + 1e-6
