@@ -93,6 +93,11 @@ typedef struct leccr_gemm_params {
     int32_t reserved;
     float* colsum;               /* optional [N] f32: += column sums of the C written (the bias gradient when C is a
                                     dY); currently one extra pass over C on the same stream */
+    float* asum;                 /* optional [M] f32, trans_a = 1 only: asum[m] += alpha * sum_k A(m,k) - the column sums of
+                                    the stored [K,M] matrix over the reduction index.  When the product is a weight gradient
+                                    dW = dY^T X this is the bias gradient colsum(dY) (autograd of F.linear's bias: clip/model.py:
+                                    175-191, HF BERT dense layers); the 256x256 kernel computes it on the matrix cores beside
+                                    the product (an all-ones B fragment), other paths run leccr_colsum over A */
 } leccr_gemm_params;
 
 int leccr_gemm(const leccr_gemm_params* p, void* stream);

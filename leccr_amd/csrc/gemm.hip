@@ -350,6 +350,7 @@ extern bool g_force_generic_attn;
 bool gemm256_wanted(const leccr_gemm_params& p);
 bool gemm256_legal(const leccr_gemm_params& p);
 bool gemm256_fuses_colsum(const leccr_gemm_params& p);
+bool gemm256_fuses_asum(const leccr_gemm_params& p);
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
 void gemm256_set_max_blocks(int n, int64_t launches);
 int gemm256_max_blocks();
@@ -433,9 +434,15 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     if (p.M == 0 || p.N == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     LECCR_REQUIRE(!(p.colsum && p.accumulate), LECCR_EINVAL, "gemm: colsum with accumulate is not defined");
+    LECCR_REQUIRE(!(p.asum && !p.trans_a), LECCR_EINVAL, "gemm: asum is defined for trans_a = 1 only");
     bool colsum_fused = false;
     int rc = gemm_dispatch(p, st, &colsum_fused);
     if (rc == LECCR_OK && p.colsum && !colsum_fused)     // paths without the fused epilogue: one pass over the C just written
         rc = leccr_colsum(p.C, p.colsum, p.M, p.N, p.ldc, p.c_dtype, stream);
+    if (rc == LECCR_OK && p.asum && !(g_last_kernel == 2 && gemm256_fuses_asum(p))) {
+        // kernels without the fused sum: one pass over A ([K, M] row-major), scaled like the product
+        if (p.alpha == 1.0f) rc = leccr_colsum(p.A, p.asum, p.K, p.M, p.lda, p.ab_dtype, stream);
+        else { set_error("gemm: asum with alpha != 1 needs the 256x256 kernel"); rc = LECCR_EINVAL; }
+    }
     return rc;
 }

@@ -56,6 +56,7 @@ struct Args {
     int tiles_m, tiles_n, splits, nkt;   // nkt = K-tiles per item (uniform; reduction tail reads zeros)
     int n_items;
     unsigned long long* stamps;          // diagnostic builds only (LECCR_G256_STAMPS): per-segment cycle sums
+    float* asum;                         // TRANS = 1 with F_ASUM: asum[m] += alpha * sum_k A[k, m] (the bias gradient), or null
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page256[512];
@@ -265,7 +266,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 
 // FLAGS (compile-time epilogue shape, so the per-item epilogue carries no runtime branches):
-constexpr int F_ATOMIC = 1, F_RES = 2, F_AUXOUT = 4, F_ACCUM = 8;
+constexpr int F_ATOMIC = 1, F_RES = 2, F_AUXOUT = 4, F_ACCUM = 8, F_ASUM = 16;
 
 template <int TRANS, typename TC, int EPI, int FLAGS>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
@@ -382,6 +383,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
         // (The software-pipelined NT schedule below needs 96 fragment registers; the transposed reads return register
         //  PAIRS and the allocator spills ~80 registers inside the K loop with it - measured 3x slower.)
         bf16x8 af[4][2], b0v[2][2], b1v[2][2];
+        // F_ASUM: column sums of A over the reduction index (= the bias gradient colsum(dY) when this product is dW = dY^T X),
+        // on the matrix cores: one more MFMA per k-step with an all-ones fragment in place of the B fragment gives
+        // D[n][m] = sum_k A[k][m] for every n.  The four waves of a wave row hold the same A fragments, so wave column wc
+        // takes 16-row group mi = wc of each 64-row half: 4 extra MFMAs per K-tile and wave (+6 %), only in the items of tile
+        // column 0 (each A panel is summed once per split), inside the COMPUTE segments.  It replaces a separate HBM pass
+        // over dY (leccr_colsum: 139 launches, 5.7 ms of a 143 ms step).
+        [[maybe_unused]] f32x4 cs_lo = {0.f, 0.f, 0.f, 0.f}, cs_hi = {0.f, 0.f, 0.f, 0.f};
+        [[maybe_unused]] const bool do_cs = (FLAGS & F_ASUM) != 0 && a.asum != nullptr && cur.n0 == 0;
+#define ASUM_STEP(CS)                                                                                                  \
+        do {                                                                                                         \
+            if constexpr ((FLAGS & F_ASUM) != 0) {                                                                   \
+                if (do_cs) {                                                                                         \
+                    const bf16x8 ones = {(bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f, (bf16_t)1.f}; \
+                    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                 \
+                        if (wc == mi) {                                                                              \
+                            CS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mi][0], CS, 0, 0, 0);              \
+                            CS = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[mi][1], CS, 0, 0, 0);              \
+                        }                                                                                            \
+                }                                                                                                    \
+            }                                                                                                        \
+        } while (0)
 
 #define MMA_QUAD(BF, NI0, MI0)                                                                                       \
         do {                                                                                                         \
@@ -409,6 +431,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             WAIT_LDS();
             SEG_BARRIER();
             MMA_QUAD(b0v, 0, 0);
+            ASUM_STEP(cs_lo);                                    // af = A rows 0-63 of this wave row's half
             SEG_BARRIER();
 
             // ---- L2: B rows 32-63 (4 reads; last read of this wave column's B half) | C(0,1)
@@ -426,6 +449,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             WAIT_LDS();
             SEG_BARRIER();
             MMA_QUAD(b1v, 2, 4);
+            ASUM_STEP(cs_hi);                                    // af = A rows 64-127
             SEG_BARRIER();
 
             // ---- L4: no reads (B rows 0-31 are still in registers); issue A(t+2); the K-tile's one counted wait | C(1,0)
@@ -436,6 +460,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
             SEG_BARRIER();
             MMA_QUAD(b0v, 0, 4);
             SEG_BARRIER();
+        }
+        if constexpr ((FLAGS & F_ASUM) != 0) {
+            // lanes 0-15 hold D[n = 0..3][m = lane] (all n equal): one f32 atomic per A column and split
+            if (do_cs && lane < 16) {
+                const int64_t m = cur.m0 + wr * 128 + wc * 16 + lane;
+                if (m < a.M) atomicAdd(a.asum + m, cs_lo[0] * a.alpha);
+                if (m + 64 < a.M) atomicAdd(a.asum + m + 64, cs_hi[0] * a.alpha);
+            }
         }
         } else {
         // One K-tile = four quads of 16 MFMAs (k-step 0 of the quad's 8 accumulators, then k-step 1); every LDS read and
@@ -825,6 +857,8 @@ bool gemm256_legal(const leccr_gemm_params& p) {
 // (all NT GEMMs 2x slower); per-item global atomics were worse still (14,000 adders per address).  leccr_gemm runs the
 // colsum pass over C instead.
 bool gemm256_fuses_colsum(const leccr_gemm_params&) { return false; }
+// The column sums of A over the reduction index (leccr_gemm_params.asum, trans_a = 1) ARE fused into the TN instantiations.
+bool gemm256_fuses_asum(const leccr_gemm_params& p) { return p.trans_a == 1 && p.asum != nullptr; }
 
 bool gemm256_wanted(const leccr_gemm_params& p) {
     const int64_t tm = cdiv(p.M, g256::BM), tn = cdiv(p.N, g256::BN);
@@ -873,6 +907,7 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc;
     a.bias = p.bias; a.aux = p.aux; a.ldaux = p.ldaux; a.aux_out = p.aux_out; a.residual = p.residual; a.ldr = p.ldr;
     a.alpha = p.alpha; a.accumulate = p.accumulate;
+    a.asum = p.trans_a == 1 ? p.asum : nullptr;
     a.tiles_m = (int)cdiv(p.M, BM); a.tiles_n = (int)cdiv(p.N, BN);
     const int64_t ktiles = cdiv(p.K, BK);
     const int tiles = a.tiles_m * a.tiles_n;
@@ -889,7 +924,10 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     const int grid = a.n_items < cap ? a.n_items : cap;              // < cap: one item per block (any count)
     const int f = flags_of(p);
     if (p.trans_a == 1) {
-        if (splits > 1) launch_inst<1, float, LECCR_EPI_NONE, F_ATOMIC>(a, grid, st);
+        if (a.asum) {
+            if (splits > 1) launch_inst<1, float, LECCR_EPI_NONE, F_ATOMIC | F_ASUM>(a, grid, st);
+            else launch_inst<1, float, LECCR_EPI_NONE, F_ACCUM | F_ASUM>(a, grid, st);
+        } else if (splits > 1) launch_inst<1, float, LECCR_EPI_NONE, F_ATOMIC>(a, grid, st);
         else launch_inst<1, float, LECCR_EPI_NONE, F_ACCUM>(a, grid, st);
     } else if (p.c_dtype == LECCR_F32) {
         launch_inst<0, float, LECCR_EPI_NONE, 0>(a, grid, st);

@@ -21,7 +21,7 @@ def _rows2d(t):
 
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
-         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None):
+         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None):
     """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major."""
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -53,6 +53,9 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     if colsum is not None:
         assert colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous() and not accumulate
     p.colsum = ptr(colsum)
+    if asum is not None:        # [M] f32 += alpha * column sums of the stored [K, M] A over K (the bias gradient beside a dW product)
+        assert trans_a and asum.dtype == torch.float32 and asum.numel() == M and asum.is_contiguous()
+    p.asum = ptr(asum)
     check(lib().leccr_gemm(C.byref(p), stream()), 'leccr_gemm')
     return out
 

@@ -75,6 +75,7 @@ def lin_dx(dy2, w, **kw):
 # partial round of tiles (6-7 % of a 1731-tile launch) - the other stream's workgroups fill those CUs.  Measured on the batch-256
 # step: 155.0 -> 150.8 ms.  LECCR_DW_STREAM=0 keeps everything on one stream.
 wgrad_overlap = os.environ.get('LECCR_DW_STREAM', '1') != '0'
+fuse_bias_grad = os.environ.get('LECCR_FUSE_BIAS_GRAD', '1') != '0'      # bias gradients inside the dW GEMM (0: separate colsum launches)
 # The text towers (caption BERT forward, text BERT forward + backward: small-M GEMMs that leave CUs idle) run on a third stream
 # beside the image tower (150.8 -> 148.7 ms on the batch-256 step).  LECCR_TEXT_STREAM=0 keeps them on the main stream.
 text_overlap = os.environ.get('LECCR_TEXT_STREAM', '1') != '0'
@@ -162,9 +163,15 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None):
 
 
 def _lin_dw(dy2, x2, w, b, scale, dy_bias=None):
-    K.gemm(dy2, x2, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale)
+    # the bias gradient colsum(dY) rides in the dW GEMM (leccr_gemm_params.asum: on the matrix cores beside the product in the
+    # 256x256 kernel, a colsum pass inside leccr_gemm otherwise) unless it comes from another tensor or carries a scale
+    fused = b is not None and dy_bias is None and scale == 1.0 and fuse_bias_grad
+    K.gemm(dy2, x2, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale,
+           asum=b._g.reshape(-1) if fused else None)
     _mark(w)
-    if b is not None:
+    if b is not None and fused:
+        _mark(b)
+    elif b is not None:
         src = dy2 if dy_bias is None else dy_bias
         if scale == 1.0:
             K.colsum(src, b._g.reshape(-1))

@@ -547,6 +547,36 @@ def test_gemm256_tn(K, force256, Kt, M, N):
     assert e <= 1e-4 * s, (e, s)
 
 
+@pytest.mark.parametrize('Kt,M,N,alpha', [(20000, 768, 768, 1.0), (577 * 16, 2304, 768, 1.0), (64 * 300, 3072, 512, 1.0),
+                                          (5000, 264, 520, 1.0), (16384, 768, 3072, 1.0), (9000, 1000, 256, 2.0),
+                                          (1000, 768, 768, 1.0), (300, 100, 72, 1.0)])
+def test_gemm_tn_fused_bias_gradient(K, Kt, M, N, alpha):
+    """leccr_gemm_params.asum: asum[m] += alpha * sum_k A[k, m] beside the dW product (the bias gradient colsum(dY)): on the
+    matrix cores inside the 256x256 TN kernel (split-K and single-split, M tails, tile column 0 only), by a colsum pass on the
+    128x128 / generic paths.  Both the product and the sums ACCUMULATE into their outputs."""
+    from leccr_amd import _lib
+    dy, x = _rand((Kt, M), torch.bfloat16, 294), _rand((Kt, N), torch.bfloat16, 295)
+    dy[:, 5] += 0.25                                     # a column whose sum does not cancel
+    base = _rand((M, N), torch.float32, 296)
+    out, bsum = base.clone().to(DEV), torch.full((M,), 3.0, device=DEV)
+    if alpha != 1.0 and Kt < 4096:
+        pytest.skip('scaled sums need the 256x256 kernel')
+    K.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True, out=out, accumulate=True, alpha=alpha, asum=bsum)
+    kernel = _lib.lib().leccr_last_gemm_kernel()
+    assert kernel == (2 if Kt >= 4096 and M >= 256 and N >= 256 else kernel)
+    e, s_ = _err(out, base.double() + alpha * (dy.double().t() @ x.double()))
+    assert e <= 1e-4 * s_, (e, s_)
+    want = 3.0 + alpha * dy.double().sum(0)
+    err = float((bsum.cpu().double() - want).abs().max())
+    assert err <= 2e-5 * float(dy.double().abs().sum(0).max()) + 1e-5, (kernel, err)
+    # twice: accumulation, and no state left behind by the first launch
+    K.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True, out=out, accumulate=True, alpha=alpha, asum=bsum)
+    err = float((bsum.cpu().double() - (2 * want - 3.0)).abs().max())
+    assert err <= 4e-5 * float(dy.double().abs().sum(0).max()) + 1e-5, (kernel, err)
+    with pytest.raises((AssertionError, RuntimeError)):  # defined for trans_a = 1 only
+        K.gemm(dy.t().contiguous().to(DEV), x.t().contiguous().to(DEV), asum=bsum)
+
+
 def test_gemm256_with_fewer_workgroups(K):
     """leccr_set_gemm_max_blocks: the persistent GEMMs on 240 of the 256 CUs (what the all-reduce overlap window uses) give the
     same results - NT bit for bit (same per-tile arithmetic), split-K TN to summation order."""
