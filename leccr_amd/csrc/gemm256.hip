@@ -386,11 +386,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
         // F_ASUM: column sums of A over the reduction index (= the bias gradient colsum(dY) when this product is dW = dY^T X),
         // on the matrix cores: one more MFMA per k-step with an all-ones fragment in place of the B fragment gives
         // D[n][m] = sum_k A[k][m] for every n.  The four waves of a wave row hold the same A fragments, so wave column wc
-        // takes 16-row group mi = wc of each 64-row half: 4 extra MFMAs per K-tile and wave (+6 %), only in the items of tile
-        // column 0 (each A panel is summed once per split), inside the COMPUTE segments.  It replaces a separate HBM pass
-        // over dY (leccr_colsum: 139 launches, 5.7 ms of a 143 ms step).
+        // takes 16-row group mi = wc of each 64-row half: 4 extra MFMAs per K-tile and wave, inside the COMPUTE segments.  The
+        // tiles_n items that share an A panel (same tile row and split) share the work: the item of tile column c sums the
+        // K-tiles kt = c (mod tiles_n), so every workgroup carries the same 1/tiles_n of it (with the sums in tile column 0
+        // alone those workgroups ran 6 % longer than the rest of the launch: +2 ms of GEMM time per step).  It replaces a
+        // separate HBM pass over dY (leccr_colsum: 139 launches, 5.7 ms of a 143 ms step).
         [[maybe_unused]] f32x4 cs_lo = {0.f, 0.f, 0.f, 0.f}, cs_hi = {0.f, 0.f, 0.f, 0.f};
-        [[maybe_unused]] const bool do_cs = (FLAGS & F_ASUM) != 0 && a.asum != nullptr && cur.n0 == 0;
+        [[maybe_unused]] const bool cs_on = (FLAGS & F_ASUM) != 0 && a.asum != nullptr;
+        [[maybe_unused]] int cs_ctr = (int)(cur.n0 >> 8);      // K-tiles until this item's next turn (BN = 256)
+        [[maybe_unused]] bool do_cs = false;
 #define ASUM_STEP(CS)                                                                                                  \
         do {                                                                                                         \
             if constexpr ((FLAGS & F_ASUM) != 0) {                                                                   \
@@ -417,6 +421,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
         } while (0)
 
         for (int kt = 0; kt < a.nkt; ++kt, ++t) {
+            if constexpr ((FLAGS & F_ASUM) != 0) {
+                do_cs = cs_on && cs_ctr == 0;
+                cs_ctr = cs_ctr == 0 ? a.tiles_n - 1 : cs_ctr - 1;
+            }
             const uint32_t so_ = (t & 1) * SLOT;                 // this K-tile's slot; K-tile t+1 lives in SLOT - so_
             const uint32_t a0 = la.nt[0] + offA + so_, a1 = la.nt[1] + offA + so_, at = la.tbase + offA + so_;
             const uint32_t b0 = la.nt[0] + offB + so_ + bwin_nt, b1 = la.nt[1] + offB + so_ + bwin_nt;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
         }
         if constexpr ((FLAGS & F_ASUM) != 0) {
             // lanes 0-15 hold D[n = 0..3][m = lane] (all n equal): one f32 atomic per A column and split
-            if (do_cs && lane < 16) {
+            if (cs_on && lane < 16) {
                 const int64_t m = cur.m0 + wr * 128 + wc * 16 + lane;
                 if (m < a.M) atomicAdd(a.asum + m, cs_lo[0] * a.alpha);
                 if (m + 64 < a.M) atomicAdd(a.asum + m + 64, cs_hi[0] * a.alpha);
