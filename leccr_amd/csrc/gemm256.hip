@@ -29,6 +29,7 @@
 // TRANS = 0: C = A[M,K] B[N,K]^T (forward and dX).   TRANS = 1: C += A[K,M]^T B[K,N] (weight gradients, split-K with
 // f32 atomics).  Same epilogues as gemm.hip.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace leccr {
@@ -54,6 +55,7 @@ struct Args {
     float alpha;
     int accumulate;
     int tiles_m, tiles_n, splits, nkt;   // nkt = K-tiles per item (uniform; reduction tail reads zeros)
+    int band_rows, col_group;            // NT item order (decode): tile rows per XCD band, tile columns per group; col_group 0 = row-major
     int n_items;
     unsigned long long* stamps;          // diagnostic builds only (LECCR_G256_STAMPS): per-segment cycle sums
     float* asum;                         // TRANS = 1 with F_ASUM: asum[m] += alpha * sum_k A[k, m] (the bias gradient), or null
@@ -79,9 +81,35 @@ __device__ __forceinline__ void decode(const Args& a, int first_item, int stride
     const int tiles = a.tiles_m * a.tiles_n;
     c.split = item / tiles;
     const int tile = item - c.split * tiles;
-    const int tm = tile / a.tiles_n;
+    int tm, tn;
+    if (TRANS == 0 && a.col_group > 0) {
+        // Column-grouped order (forward / dX with many tile columns).  The tile rows are cut into 8 bands (one per XCD, as the
+        // XCD-contiguous item ranges are); inside a band the tiles are walked one GROUP of `col_group` tile columns at a time,
+        // row by row.  The XCD's 32 workgroups then share col_group weight panels (<= 1.6 MB: they stay in its 4 MiB L2 for the
+        // whole group) and stream the band's activation panels past them, once per group.  In plain row-major order a round of 32
+        // workgroups touches EVERY weight panel (3.5 - 4.7 MB for N = 2304 / 3072 at K = 768) next to its own rows and the
+        // streaming output, so each XCD re-fetches the whole weight matrix from the fabric every round: measured 1.33 / 2.16 GB
+        // read per launch against 0.23 GB algorithmic (profiles/r02_gemm256_traffic_by_shape.txt).  Opt-in: see gemm256_launch.
+        const int per_band = a.band_rows * a.tiles_n;
+        int band = tile / per_band;
+        const int nb = (a.tiles_m + a.band_rows - 1) / a.band_rows;
+        if (band > nb - 1) band = nb - 1;
+        const int within = tile - band * per_band;
+        const int rows_b = min(a.band_rows, a.tiles_m - band * a.band_rows);
+        const int full = a.tiles_n / a.col_group;                      // full-width groups
+        int g = within / (rows_b * a.col_group);
+        if (g > full) g = full;
+        const int cw = g < full ? a.col_group : a.tiles_n - full * a.col_group;
+        const int wg = within - g * rows_b * a.col_group;
+        const int row = wg / cw;
+        tm = band * a.band_rows + row;
+        tn = g * a.col_group + (wg - row * cw);
+    } else {
+        tm = tile / a.tiles_n;
+        tn = tile - tm * a.tiles_n;
+    }
     c.m0 = (int64_t)tm * BM;
-    c.n0 = (int64_t)(tile - tm * a.tiles_n) * BN;
+    c.n0 = (int64_t)tn * BN;
     c.k0 = (int64_t)c.split * a.nkt * BK + (int64_t)c.kt * BK;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
@@ -927,6 +955,18 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
         if (splits < 1) splits = 1;
     }
     a.splits = splits;
+    a.band_rows = (a.tiles_m + 7) / 8;
+    a.col_group = 0;
+    if (p.trans_a == 0) {
+        // Opt-in (LECCR_G256_COLGROUP=c): walk the tile columns in groups of c inside each XCD band (decode()).  Measured on
+        // MI355X (profiles/r02_gemm256_colgroup_sweep.txt): it cuts the fabric reads of the wide-N shapes as intended (qkv 1.35 ->
+        // 0.81-0.95 GB, fc1 2.16 -> 1.04-1.25 GB per launch against 0.23 GB algorithmic) and makes them no faster (qkv 587 us
+        // row-major vs 602-640 grouped, fc1 688 vs 684-738): the re-fetched weight panels are Infinity-Cache hits, and the K loop is
+        // not waiting for them.  Row-major stays the default.
+        static const int env_group = [] { const char* e = getenv("LECCR_G256_COLGROUP"); return e ? atoi(e) : 0; }();
+        const int cg = env_group > 0 && env_group < a.tiles_n ? env_group : 0;
+        a.col_group = cg;
+    }
     a.nkt = (int)cdiv(ktiles, splits);
     a.n_items = tiles * splits;
     const int grid = a.n_items < cap ? a.n_items : cap;              // < cap: one item per block (any count)
