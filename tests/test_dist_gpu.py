@@ -13,10 +13,23 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, ret):
+def _init(rank, world, port):
+    """Rendezvous of one test rank.  Default: gloo, every rank on cuda:0 (the one-GPU development box).  With
+    LECCR_TEST_BACKEND=nccl (tests/test_rccl_gpu.py, nodes with >= 2 GPUs): RCCL, one rank per device - the production layout."""
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    backend = os.environ.get('LECCR_TEST_BACKEND', 'gloo')
+    if backend == 'nccl':
+        from leccr_amd.parallel import setup_rccl_env
+        setup_rccl_env()
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', rank))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+
+
+def _worker(rank, world, port, ret):
+    _init(rank, world, port)
     from leccr_amd.optim import create_optimizer
     from leccr_amd.parallel import attach_grad_sync
     from tests.helpers import grad_close, load_npz, weights
@@ -56,9 +69,7 @@ def test_two_rank_losses_and_gradients_match_reference_ddp():
 
 
 def _train_worker(rank, world, port, fused, ret):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    _init(rank, world, port)
     from leccr_amd import ops
     from leccr_amd.optim import create_optimizer
     from leccr_amd.parallel import attach_grad_sync
@@ -97,9 +108,7 @@ def test_two_rank_training_with_the_optimizer_fused_into_backward():
 
 def _eval_worker(rank, world, port, ret):
     import types
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    _init(rank, world, port)
     from leccr_amd.evaluation import evaluation_coarse
     from tests.helpers import load_npz, weights
     from tests.test_model_gpu import MODEL_VIT, TINY_BERT, build

@@ -207,3 +207,15 @@ def test_bigfile_reader_matches_the_reference_semantics(tmp_path):
     (tmp_path / 'shape.txt').write_text(f'{rows + 1} {dims}\n')
     with pytest.raises((AssertionError, ValueError)):
         BigFile(str(tmp_path))
+
+
+def test_bench_refuses_to_report_a_multi_gpu_number_it_cannot_measure():
+    """`python bench.py --gpus 8` with no launcher and fewer GPUs than asked: non-zero exit, no JSON line (round 1 printed a
+    one-rank result with exit code 0 here).  With enough GPUs it starts the ranks itself (tests/test_rccl_gpu.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LECCR_BENCH_BACKEND')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == '' and 'refusing' in r.stderr
