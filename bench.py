@@ -32,8 +32,11 @@ sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
 HBM_PEAK_TBS = 8.0                  # HBM3E, same guide
-F_PAIR_GFLOP = {'image': 389.9,     # algorithmic FLOPs per pair per train step, B/16 + mBERT
-                'video_vit': 2718.0}   # config D: 8 x B/16 frames + mBERT (same table)
+F_PAIR_GFLOP = {('image', 'ViT-B/16', 'mbert'): 389.9,      # algorithmic FLOPs per pair per train step
+                ('video_vit', 'ViT-B/16', 'mbert'): 2718.0,  # config D: 8 x B/16 frames + mBERT
+                ('image', 'ViT-L/14', 'xlmr-large'): 1674.6}  # config E: L/14 + XLM-R-large
+XLMR_LARGE = dict(vocab_size=250002, hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                  max_position_embeddings=512)
 
 
 def parse():
@@ -44,6 +47,8 @@ def parse():
     ap.add_argument('--model', default='image', choices=['image', 'video', 'video_vit'])
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (image: 256 = BASELINE configs[1]; video: 128; video_vit: 64)')
     ap.add_argument('--clip', default='ViT-B/16')
+    ap.add_argument('--text', default='mbert', choices=['mbert', 'xlmr-large'],
+                    help="text tower geometry: mBERT (configs A-D) | XLM-R-large shaped BERT (BASELINE configs[4]: hidden 1024, 24 layers, 16 heads, FFN 4096, vocab 250002)")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
@@ -126,11 +131,13 @@ def build_workload(args, device, rank):
         from leccr_amd.models import RetrievalModel
         cfg = dict(MULTI30K_CFG)
         cfg.update(clip_name=args.clip, compute_dtype=args.dtype, clip_text_tower=False)
+        if args.text == 'xlmr-large':
+            cfg['text_config'] = dict(XLMR_LARGE)
         model = RetrievalModel(cfg)
-        cpu = make_batch(args.batch, rank=rank)
+        cpu = make_batch(args.batch, rank=rank, vocab=250002 if args.text == 'xlmr-large' else 119547)
         batch = {'image': cpu['image'].to(device)}
         fwd = lambda m, b: m(b['image'], b['text'], captions=b['captions'], idx=b['idx'])
-        what = f'Multi30K en-de shaped, {args.clip}@384 + mBERT'
+        what = f'Multi30K en-de shaped, {args.clip}@384 + ' + ('mBERT' if args.text == 'mbert' else 'XLM-R-large shaped BERT')
     elif args.model == 'video':
         from leccr_amd.models.video_model_retrieval_caption import RetrievalModel
         # configs/cclm-base-ft/Retrieval_msrvtt.yaml:36-66: vision_width 4096, vision_layer 1, num_queries 2, 2+2 interaction layers
@@ -179,13 +186,13 @@ def _oracle_losses(args, cfg, sd, batch, rows):
     txt = (t0.input_ids[s], t0.attention_mask[s], t1.input_ids[s], t1.attention_mask[s], c.input_ids[s], c.attention_mask[s],
            batch['idx'][s])
     if args.model == 'image':
-        return O.retrieval_forward(sd, wl, batch['image'][s], *txt, text_heads=12)
+        return O.retrieval_forward(sd, wl, batch['image'][s], *txt, text_heads=16 if args.text == 'xlmr-large' else 12)
     video = batch['video'][s]
     if args.model == 'video_vit':
         b, F = video.shape[:2]
         hidden = O.encode_image(sd, 'clip_encoder.visual.', video.reshape(b * F, *video.shape[2:]))
         video = hidden[:, 0, :].reshape(b, F, -1)
-    return O.video_retrieval_forward(sd, wl, video, batch['video_mask'][s], *txt, text_heads=12)
+    return O.video_retrieval_forward(sd, wl, video, batch['video_mask'][s], *txt, text_heads=16 if args.text == 'xlmr-large' else 12)
 
 
 def cpu_baseline(args, cfg, model):
@@ -201,7 +208,7 @@ def cpu_baseline(args, cfg, model):
     opt = torch.optim.AdamW(params, lr=1e-5, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
     b = args.cpu_batch
     if args.model == 'image':
-        batch = make_batch(b)
+        batch = make_batch(b, vocab=250002 if args.text == 'xlmr-large' else 119547)
     else:
         batch = make_video_batch(b, frames=8, width=4096 if args.model == 'video' else 8)
         if args.model == 'video_vit':
@@ -220,7 +227,7 @@ def cpu_baseline(args, cfg, model):
     t = sorted(timed)[len(timed) // 2]
     return {'value': round(b / t, 4), 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'sample': f'{len(timed)} full train step(s) (fwd+bwd+AdamW) of batch {b} (BASELINE config A) after '
-                      f'{1 if len(times) > 1 else 0} warm-up, same {args.clip}+mBERT geometry, fp32; {how}',
+                      f'{1 if len(times) > 1 else 0} warm-up, same {args.clip}+{args.text} geometry, fp32; {how}',
             's_per_step': round(t, 3), 'step_times_s': [round(x, 2) for x in times]}
 
 
@@ -247,7 +254,7 @@ def parity_probe(args, cfg, model, batch, fwd, rows=2):
     return {'rows': rows, 'max_abs_loss_err': round(err, 6), 'tolerance': tol, 'ok': bool(err <= tol),
             'losses_hip': [round(x, 5) for x in got], 'losses_oracle_fp32': [round(x, 5) for x in ref],
             'what': f'{args.dtype} HIP path (eval mode) vs CPU oracle fp32, same weights (after the timed steps) and inputs, '
-                    f'full {args.clip}@384 + mBERT geometry'}
+                    f'full {args.clip}@384 + {args.text} geometry'}
 
 
 HBM_KINDS = ['layernorm_fwd', 'layernorm_bwd', 'colsum', 'bert_embed_fwd', 'adamw', 'dropout']
@@ -361,7 +368,7 @@ def _main(args, real_stdout):
             rccl = '.'.join(map(str, torch.cuda.nccl.version())) if world > 1 else None
         except Exception:                                                            # noqa: BLE001 (reporting only)
             rccl = None
-        fpair = F_PAIR_GFLOP.get(args.model) if args.clip == 'ViT-B/16' else None
+        fpair = F_PAIR_GFLOP.get((args.model, args.clip, args.text))
         out = {
             'metric': 'image-text pairs/sec (train step)' if args.model == 'image' else 'video-text pairs/sec (train step)',
             'value': round(value, 2), 'unit': 'pairs/s',

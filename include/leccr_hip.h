@@ -179,8 +179,9 @@ int leccr_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void*
 /* ---- similarity + contrastive losses (f32 in, f32 out) ----------------------------------------------------
  * sim_infonce: get_contrastive_loss (models/xvlm.py:260-292).  a,b [G,D] L2-normalised, idx [G] int64 or NULL.
  *   logits = a b^T / temp ; labels = eq(idx,idx^T)/rowsum (or identity) ; loss = (CE_rows + CE_cols)/2.
- *   `ws` (>= 2*G + G*G floats): row / column log-sum-exps (the part the backward reads), then a G x G scratch for the
- *   forward's logits tiles (f32 products on the matrix cores, one direction at a time).
+ *   `ws` (>= 2*G + 4 + 8*G*ceil(G/64) floats): row / column log-sum-exps (the part the backward reads), then the forward's per-tile
+ *   online-softmax partials: ONE f32 matrix-core product serves both directions, reduced 64 x 64 tile by tile along its rows and
+ *   its columns - the G x G logits are never in memory (D % 8 != 0 falls back to a row-at-a-time kernel).
  *   loss: 1 float.  Backward gives da, db [G,D] (full gathered rows; the caller keeps its local slice,
  *   xvlm.py:62-67) and dtemp (1 float), all scaled by `gscale`.
  * capsim: get_caption_contrastive_loss (model_retrieval_caption.py:145-152).  c [b,n,D], t [b,D]:

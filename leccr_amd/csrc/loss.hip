@@ -160,6 +160,126 @@ __global__ __launch_bounds__(256) void sim_rowstat_kernel(const float* __restric
     }
 }
 
+
+// ----------------------------------------------------------------------------------------------- sim_infonce forward, one product
+// get_contrastive_loss's forward (models/xvlm.py:273-292) without a G x G logits matrix in memory: ONE f32 matrix-core product
+// a b^T serves both softmax directions.  A block computes a 64 x 64 score tile (the f32_nt_tile_kernel loop), parks it in the
+// LDS the operands occupied and reduces it twice - along its rows (image -> text direction: row i over the tile's 64 columns) and
+// along its columns (text -> image: column j over the tile's 64 rows) - into online-softmax partials (max, sum of exp, sum of the
+// matching logits, match count).  sim_merge_kernel combines a row's (column's) partials over the tiles into lse and the loss.
+// Workspace: 2 G (lse) + 2 * G * ceil(G / 64) * 4 floats (2 MB at G = 2048, against 16.8 MB of logits written and read twice).
+__global__ __launch_bounds__(256) void sim_tile_stats_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                             const int64_t* __restrict__ idx, int G, int D, float inv_temp,
+                                                             f32x4* __restrict__ part, int both_dirs) {
+    extern __shared__ float sm[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int T = gridDim.x;                                  // tiles per row of the score matrix (= per column: it is square)
+    constexpr int LD = kScoreKC + 4;
+    float* As = sm;
+    float* Bs = sm + 64 * LD;
+    f32x16_t acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < D; k0 += kScoreKC) {
+        const int kc = min(kScoreKC, D - k0), q4 = kc >> 2;          // D % 8 == 0 (launcher)
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * q4; e += 256) {
+            const int r = e / q4, c = (e - r * q4) * 4;
+            const int ra = m0 + r < G ? m0 + r : G - 1, rb = n0 + r < G ? n0 + r : G - 1;
+            *reinterpret_cast<f32x4*>(As + r * LD + c) = *reinterpret_cast<const f32x4*>(A + (int64_t)ra * D + k0 + c);
+            *reinterpret_cast<f32x4*>(Bs + r * LD + c) = *reinterpret_cast<const f32x4*>(B + (int64_t)rb * D + k0 + c);
+        }
+        __syncthreads();
+        const int half = kc >> 1;
+        const float* ap = As + (wr * 32 + (lane & 31)) * LD + (lane >> 5) * half;
+        const float* bp = Bs + (wc * 32 + (lane & 31)) * LD + (lane >> 5) * half;
+        for (int s4 = 0; s4 < half; s4 += 4) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ap + s4), bv = *reinterpret_cast<const f32x4*>(bp + s4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv[e], acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();                                          // every wave is done with the operand tiles: reuse their LDS
+    constexpr int SL = 65;                                    // score tile row stride (floats)
+    float* S = sm;
+XX
+    {
+        const int n = wc * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) S[(wr * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * SL + n] = acc[i] * inv_temp;
+        if (threadIdx.x < 128) {
+            const int g = (threadIdx.x < 64 ? m0 : n0 - 64) + threadIdx.x;
+            ids[threadIdx.x] = g < G ? (idx ? idx[g] : (int64_t)g) : (int64_t)-1 - threadIdx.x;      // padding matches nothing
+        }
+    }
+    __syncthreads();
+    // thread t: line t >> 2 (a row in pass 0, a column in pass 1), elements 16 (t & 3) .. + 15 of it; 4 threads merge by shuffle
+    const int line = threadIdx.x >> 2, q = threadIdx.x & 3;
+    for (int pass = 0; pass < (both_dirs ? 2 : 1); ++pass) {
+        const int gl = (pass == 0 ? m0 : n0) + line;          // global index of this line
+        const int o0 = pass == 0 ? n0 : m0;                   // global index of the other axis' first element
+        const int64_t my = ids[pass * 64 + line];
+        const int64_t* other = ids + (1 - pass) * 64;
+        float m = -INFINITY, l = 0.f, pos = 0.f, cnt = 0.f;
+        float v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int o = q * 16 + e;
+            const float s = pass == 0 ? S[line * SL + o] : S[o * SL + line];
+            v[e] = o0 + o < G ? s : -INFINITY;
+            m = fmaxf(m, v[e]);
+            if (other[o] == my) {
+                pos += s;
+                cnt += 1.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) l += v[e] == -INFINITY ? 0.f : __expf(v[e] - m);
+#pragma unroll
+        for (int d = 1; d < 4; d <<= 1) {                     // merge the 4 quarter-lines (adjacent lanes)
+            const float m2 = __shfl_xor(m, d), l2 = __shfl_xor(l, d);
+            pos += __shfl_xor(pos, d);
+            cnt += __shfl_xor(cnt, d);
+            const float mn = fmaxf(m, m2);
+            l = (m == -INFINITY ? 0.f : l * __expf(m - mn)) + (m2 == -INFINITY ? 0.f : l2 * __expf(m2 - mn));
+            m = mn;
+        }
+        if (q == 0 && gl < G) {
+            const int tile = pass == 0 ? blockIdx.x : blockIdx.y;
+            part[((int64_t)pass * G + gl) * T + tile] = f32x4{m, l, pos, cnt};
+        }
+    }
+}
+
+// lse and loss of line i (a row: dir 0, a column: dir 1) from its per-tile partials.  One wave per line.
+__global__ __launch_bounds__(256) void sim_merge_kernel(const f32x4* __restrict__ part, int G, int T, float* __restrict__ ws,
+                                                        float* __restrict__ loss, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), dir = blockIdx.y;
+    if (i >= G) return;
+    const f32x4* p = part + ((int64_t)dir * G + i) * T;
+    float m = -INFINITY, l = 0.f, pos = 0.f, cnt = 0.f;
+    for (int t = lane; t < T; t += 64) {
+        const f32x4 v = p[t];
+        const float mn = fmaxf(m, v[0]);
+        l = (m == -INFINITY ? 0.f : l * __expf(m - mn)) + (v[0] == -INFINITY ? 0.f : v[1] * __expf(v[0] - mn));
+        m = mn;
+        pos += v[2];
+        cnt += v[3];
+    }
+    const float M = wave_max(m);
+    l = wave_sum(m == -INFINITY ? 0.f : l * __expf(m - M));
+    pos = wave_sum(pos);
+    cnt = wave_sum(cnt);
+    if (lane == 0) {
+        const float lse = M + __logf(l);
+        ws[dir * G + i] = lse;
+        atomicAdd(loss, scale * (lse - pos / cnt));
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- sim_infonce
 // dir 0: rows of a vs all b ; dir 1: rows of b vs all a.   For row i: lse_i, pos_i = sum_j lab_ij logit_ij.
 // loss += scale * (lse_i - pos_i).   ws: [lse dir0 (G) | lse dir1 (G)]
@@ -857,15 +977,20 @@ extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("sim_infonce memset");
     const float scale = both_dirs ? 0.5f / G : 1.f / G;
     if ((D & 7) == 0) {
-        // logits = a b^T / temp on the matrix cores into the scratch behind the row statistics (ws: [lse dir0 G | lse dir1 G |
-        // G x G scratch]), then one coalesced pass per row; the column direction is the same with the operands swapped
-        float* logits = ws + 2 * G;
-        for (int dir = 0; dir < (both_dirs ? 2 : 1); ++dir) {
-            const int rc = launch_f32_nt(dir == 0 ? a : b, D, dir == 0 ? b : a, D, logits, G, G, G, D, 1.f / temp, false, st);
-            if (rc != LECCR_OK) return rc;
-            hipLaunchKernelGGL(sim_rowstat_kernel, dim3((unsigned)cdiv(G, 4)), dim3(256), 0, st, logits, idx, (int)G, ws + dir * G,
-                               loss, scale);
+        // one product a b^T / temp on the matrix cores, reduced tile by tile along rows AND columns (both softmax directions), then
+        // a merge of the per-tile partials: no G x G logits in memory (ws: [lse dir0 G | lse dir1 G | partials 2 x G x T x 4])
+        const int T = (int)cdiv(G, 64);
+        f32x4* part = reinterpret_cast<f32x4*>(ws + ((2 * G + 3) & ~(int64_t)3));
+        static bool attr = false;
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)sim_tile_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr = true;
         }
+        const size_t lds = (size_t)2 * 64 * (kScoreKC + 4) * sizeof(float);
+        hipLaunchKernelGGL(sim_tile_stats_kernel, dim3((unsigned)T, (unsigned)T), dim3(256), lds, st, a, b, idx, (int)G, (int)D,
+                           1.f / temp, part, both_dirs);
+        hipLaunchKernelGGL(sim_merge_kernel, dim3((unsigned)cdiv(G, 4), both_dirs ? 2 : 1), dim3(256), 0, st, part, (int)G, T, ws,
+                           loss, scale);
         return check_launch("sim_infonce_fwd");
     }
     const size_t lds_f = (size_t)(4 * D + 64 * (D + 4)) * sizeof(float);      // 4 own rows + the staged 64-row tile

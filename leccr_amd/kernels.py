@@ -209,7 +209,8 @@ def sim_infonce_fwd(a, b, idx, temp, both_dirs=True):
     G, D = _f32c(a).shape
     _f32c(b)
     loss = torch.empty(1, device=a.device, dtype=torch.float32)
-    ws = torch.empty(2 * G + G * G, device=a.device, dtype=torch.float32)       # row statistics | G x G logits scratch
+    # row / column log-sum-exps (what the backward reads) | per-tile online-softmax partials of the forward: 2 x G x ceil(G/64) x 4
+    ws = torch.empty(2 * G + 4 + 8 * G * ((G + 63) // 64), device=a.device, dtype=torch.float32)
     check(lib().leccr_sim_infonce_fwd(ptr(a), ptr(b), ptr(idx), float(temp), G, D, int(both_dirs), ptr(loss),
                                       ptr(ws), stream()), 'leccr_sim_infonce_fwd')
     return loss, ws

@@ -229,3 +229,47 @@ def test_bf16_gradients_stay_within_the_bf16_storage_noise_model(temp):
     assert len(rows) > 100 and not bad, (len(bad), bad[:8])
     # and the yardstick itself is not vacuous: at least 3/4 of the tensors have noise under 15 % of their norm
     assert sum(1 for _, _, rn, _, nz in rows if nz <= 0.15 * rn) >= 0.75 * len(rows)
+
+
+# ----------------------------------------------------------------------------------------- BASELINE configs[4] geometry
+L14_GEOMETRY = dict(embed_dim=768, image_resolution=384, vision_layers=2, vision_width=1024, vision_patch_size=14,
+                    context_length=8, vocab_size=32, transformer_width=64, transformer_heads=1, transformer_layers=1)
+XLMR_LARGE_2L = dict(vocab_size=250002, hidden_size=1024, num_hidden_layers=2, num_attention_heads=16, intermediate_size=4096,
+                     max_position_embeddings=512)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_config_e_geometry_vit_l14_xlmr_large_vs_oracle(dtype):
+    """BASELINE configs[4]'s geometry at full width: ViT-L/14 @384 (730 tokens = 27 x 27 patches of 14 + [CLS], the 6 edge pixels
+    dropped; width 1024, 16 heads, 588 -> 640-wide padded patch rows, vision_width 768: 8 interaction heads of 96 and the wide
+    contrastive backward) + an XLM-R-large shaped BERT (hidden 1024, 16 heads, FFN 4096, vocabulary 250 002), two layers of each,
+    b = 2, L_t = 32, L_c = 64, against the oracle: losses and every parameter gradient (bf16: the noise-model rule)."""
+    from leccr_amd.models import RetrievalModel
+    from leccr_amd.synthetic import MULTI30K_CFG, make_batch
+    torch.manual_seed(17)
+    model = RetrievalModel(dict(MULTI30K_CFG, clip_geometry=L14_GEOMETRY, text_config=XLMR_LARGE_2L, compute_dtype=dtype,
+                                clip_text_tower=False))
+    model.init_caption_encoder()
+    seeded_fill_(model.named_parameters(), 91)
+    assert model.vision_width == 768 and model.clip_encoder.visual.positional_embedding.shape == (730, 1024)
+    model = model.to(DEV).eval()
+    m = make_batch(2, vocab=250002)
+    batch = dict(image=m['image'], ids_s=m['text'][0].input_ids, mask_s=m['text'][0].attention_mask, ids_t=m['text'][1].input_ids,
+                 mask_t=m['text'][1].attention_mask, ids_c=m['captions'].input_ids, mask_c=m['captions'].attention_mask, idx=m['idx'])
+    torch.set_num_threads(16)
+    ref_losses, sd = oracle_step(model.state_dict(), batch, 16)
+    sd_noise = oracle_step(model.state_dict(), batch, 16, lowp=True)[1] if dtype == 'bf16' else None
+    losses = _forward(model, batch)
+    tol = 1e-3 if dtype == 'fp32' else 3e-2
+    for a, r in zip([float(l) for l in losses], ref_losses):
+        assert abs(a - r) <= tol * max(1.0, abs(r)), (dtype, [float(l) for l in losses], ref_losses)
+    model.arena.zero_grad()
+    sum(losses).backward()
+    rows = grad_rows(model, sd, sd_noise)
+    assert len(rows) > 150
+    if dtype == 'fp32':
+        gmax = max(r[2] for r in rows)
+        bad = [(n, err / rn, cos, rn / gmax) for n, err, rn, cos, _ in rows if rn >= 1e-6 * gmax and err > 2e-3 * rn]
+    else:
+        bad = outside_noise_model(rows)
+    assert not bad, (len(bad), bad[:8])
