@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void sim_tile_stats_kernel(const float* __rest
     __syncthreads();                                          // every wave is done with the operand tiles: reuse their LDS
     constexpr int SL = 65;                                    // score tile row stride (floats)
     float* S = sm;
-XX
+    int64_t* ids = reinterpret_cast<int64_t*>(sm + 64 * SL);             // [0..63] the tile's rows, [64..127] its columns (byte 16640)
     {
         const int n = wc * 32 + (lane & 31);
 #pragma unroll
