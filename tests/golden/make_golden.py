@@ -494,6 +494,86 @@ def fixture_pos_embed(clip_model):
     print('pos_embed', {k: v.shape for k, v in out.items()})
 
 
+def caption_store_spec():
+    """A small annotation store in the reference's layout (Multi30K-style and mscoco-style), as {relative path: text}."""
+    ids = ['1000092795', '10002456', 'a-b_c7', '33']
+    files = {'img_id/train_id.txt': '\n'.join(ids) + '\n', 'img_id/val_id.txt': '\n'.join(ids[1:]) + '\n',
+             'img_id/test_id_2016.txt': '\n'.join(ids[:3]) + '\n'}
+    caps_en = ['Two young, White males are outside near many bushes.', 'A man in an orange hat starring at something!',
+               "A <person> is sitting; it's a dog/cat - really?  (yes)", 'x ' * 40 + 'end', 'Several men in hard hats are operating a giant pulley system.']
+    caps_de = ['Zwei junge weiße Männer sind im Freien in der Nähe vieler Büsche.', 'Ein Mann mit einem orangefarbenen Hut, der etwas anstarrt.',
+               'Eine Person sitzt; es ist ein Hund/Katze - wirklich?', 'y ' * 35 + 'ende', 'Mehrere Männer mit Schutzhelmen bedienen ein Antriebsradsystem.']
+    order = [(0, 0), (1, 1), (2, 2), (3, 3), (0, 4)]          # (image, caption): image 0 has two captions
+    files['train_enc.txt'] = ''.join(f'{ids[i]}.jpg#enc#{k} {caps_en[c]}\n' for k, (i, c) in enumerate(order))
+    files['train_enc2de.txt'] = ''.join(f'{ids[i]}.jpg#enc2de#{k} {caps_de[c]}\n' for k, (i, c) in enumerate(order))
+    files['val_de.txt'] = ''.join(f'{ids[i]}.jpg#enc2de#{k} {caps_de[c]}\n' for k, (i, c) in enumerate([(1, 1), (2, 2), (1, 0), (3, 3)]))
+    files['val_de_trans.txt'] = ''.join(f'{ids[i]}.jpg#enc#{k} {caps_en[c]}\n' for k, (i, c) in enumerate([(1, 1), (2, 2), (1, 0), (3, 3)]))
+    for i in ids:
+        files[f'gen/{i}.txt'] = f'a generated caption for image {i}.\n'
+    # mscoco flavour: ids map to file names through img_id/image_ids.txt; generated captions are named after the FILE
+    coco = {'c1': 'COCO_val2014_000000391895.jpg', 'c2': 'jpeg_COCO_000000522418.jpg'}
+    files['coco/img_id/image_ids.txt'] = ''.join(f'{k} {v}\n' for k, v in coco.items())
+    files['coco/img_id/train_id.txt'] = 'c1\nc2\n'
+    files['coco/img_id/ja_val_id.txt'] = 'c2\nc1\n'
+    files['coco/train_enc.txt'] = 'c1#enc#0 A woman riding a bike.\nc2#enc#1 A plate of food, with a fork.\n'
+    files['coco/train_enc2ja.txt'] = 'c1#enc2ja#0 jitensha ni noru josei\nc2#enc2ja#1 fooku to ryouri no sara\n'
+    files['coco/val_ja.txt'] = 'c2#enc2ja#0 ryouri no sara\nc1#enc2ja#1 jitensha\nc2#enc2ja#2 fooku\n'
+    for k, v in coco.items():
+        files['coco/gen/' + v.strip('.jpg') + '.txt'] = f'generated for {k}\n'
+    return files, ids, coco
+
+
+def fixture_caption_store():
+    """The reference's re_train_dataset_caption / re_eval_dataset_caption (dataset/retrieval_dataset.py:30-264) and pre_caption
+    (dataset/utils.py:31-55) run on a generated annotation store: what leccr_amd.captions must reproduce.  The class sources are
+    compiled from the reference file with a namespace that supplies their imports (the `dataset` package itself needs
+    torchvision); images are 4x4 JPEGs written here, `transform` returns the image size."""
+    import ast
+    import tempfile
+    from PIL import Image
+    from torch.utils.data import Dataset
+    ns = {'re': __import__('re')}
+    tree = ast.parse(open(os.path.join(REF, 'dataset/utils.py')).read())
+    exec(compile(ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == 'pre_caption'], type_ignores=[]),
+                 'utils.py', 'exec'), ns)
+    ns.update(os=os, np=np, torch=torch, time=__import__('time'), Image=Image, Dataset=Dataset, json=json)
+    tree = ast.parse(open(os.path.join(REF, 'dataset/retrieval_dataset.py')).read())
+    keep = [n for n in tree.body if getattr(n, 'name', None) in ('getVideoId', 're_train_dataset_caption', 're_eval_dataset_caption')]
+    exec(compile(ast.Module(body=keep, type_ignores=[]), 'retrieval_dataset.py', 'exec'), ns)
+    files, ids, coco = caption_store_spec()
+    out = {'files': files, 'pre_caption': {}}
+    for text in ["A <person>, sitting - on/a BENCH!!  (twice)", 'x ' * 40, 'Hello;World:~ok', "don't #stop*"]:
+        out['pre_caption'][text] = ns['pre_caption'](text, 30)
+    with tempfile.TemporaryDirectory() as d:
+        for rel, text in files.items():
+            os.makedirs(os.path.dirname(os.path.join(d, rel)), exist_ok=True)
+            open(os.path.join(d, rel), 'w').write(text)
+        os.makedirs(os.path.join(d, 'images'))
+        for name in [i + '.jpg' for i in ids] + list(coco.values()):
+            Image.new('RGB', (4, 4), (10, 20, 30)).save(os.path.join(d, 'images', name))
+        tf = lambda im: im.size
+        for tag, cfg, trains, ev in (
+                ('m30k', dict(root_dir=d, image_root=os.path.join(d, 'images'), dataset='multi30k', generated_caption_dir=os.path.join(d, 'gen'),
+                              generated_caption_type='text', train_file=['train_enc.txt', 'train_enc2de.txt']),
+                 None, ('val_de.txt', os.path.join(d, 'val_de_trans.txt'))),
+                ('coco', dict(root_dir=os.path.join(d, 'coco'), image_root=os.path.join(d, 'images'), dataset='mscoco',
+                              generated_caption_dir=os.path.join(d, 'coco/gen'), generated_caption_type='text',
+                              train_file=['train_enc.txt', 'train_enc2ja.txt']), None, ('val_ja.txt', None))):
+            tr = ns['re_train_dataset_caption'](cfg, tf, 30)
+            recs = []
+            for i in range(len(tr)):
+                size, caps, gen, img_idx, cap_id = tr[i]
+                recs.append([list(size), caps, gen, img_idx, cap_id])
+            e = ns['re_eval_dataset_caption'](cfg, ev[0], tf, 30, test_trans_file=ev[1], type='eval')
+            erecs = [[list(e[i][0]), e[i][1], e[i][2]] for i in range(len(e))]
+            out[tag] = {'train_len': len(tr), 'train_records': recs, 'languages': tr.languages, 'img_ids': tr.img_ids,
+                        'eval_text': e.text, 'eval_image': e.image, 'txt2img': {str(k): v for k, v in e.txt2img.items()},
+                        'img2txt': {str(k): v for k, v in e.img2txt.items()}, 'eval_cap_ids': e.cap_ids, 'eval_records': erecs,
+                        'text_trans': getattr(e, 'text_trans', None)}
+    json.dump(out, open(os.path.join(OUT, 'caption_store.json'), 'w'), indent=1, ensure_ascii=False)
+    print('caption_store', {k: (v['train_len'], len(v['eval_text'])) for k, v in out.items() if k in ('m30k', 'coco')})
+
+
 def main():
     if os.path.dirname(os.path.dirname(OUT)) not in sys.path:
         sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))          # tests.helpers (seeded_fill_)
@@ -504,7 +584,11 @@ def main():
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29610')
         dist.init_process_group('gloo', rank=0, world_size=1)
     if only:            # python tests/golden/make_golden.py full  -> only the full-geometry fixtures (minutes of CPU)
-        assert only <= {'full'}, only
+        assert only <= {'full', 'captions'}, only
+        if only == {'captions'}:
+            fixture_caption_store()
+            dist.destroy_process_group()
+            return
         torch.set_num_threads(8)
         fixture_pos_embed(clip_model)
         fixture_vit_b16_1layer(clip_model)
@@ -520,6 +604,7 @@ def main():
     fixture_pos_embed(clip_model)
     fixture_vit_b16_1layer(clip_model)
     fixture_full_step_b16(clip_model, xvlm)
+    fixture_caption_store()
     dist.destroy_process_group()
     fixture_model_w2()
 

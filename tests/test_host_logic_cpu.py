@@ -219,3 +219,46 @@ def test_bench_refuses_to_report_a_multi_gpu_number_it_cannot_measure():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], capture_output=True, text=True, env=env,
                        timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == '' and 'refusing' in r.stderr
+
+
+def test_caption_txt_store_reader_matches_the_reference_dataset_classes(tmp_path):
+    """leccr_amd.captions on the store of tests/golden/caption_store.json (written out here from the fixture): the records, texts,
+    id maps and ground-truth tables equal what the reference's re_train_dataset_caption / re_eval_dataset_caption produced on
+    it (dataset/retrieval_dataset.py:30-264), Multi30K-style and mscoco-style, pre_caption included."""
+    import json
+    from leccr_amd.captions import EvalAnnotations, TrainAnnotations, get_video_id, pre_caption
+    z = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'caption_store.json')))
+    for raw, want in z['pre_caption'].items():
+        assert pre_caption(raw, 30) == want
+    with pytest.raises(ValueError):
+        pre_caption(' ., ', 30)
+    assert get_video_id('abc.jpg#enc#3') == 'abc' and get_video_id('v7.mp4#enc2zh#0') == 'v7' and get_video_id('c1#enc#0') == 'c1'
+    d = str(tmp_path)
+    for rel, text in z['files'].items():
+        os.makedirs(os.path.dirname(os.path.join(d, rel)), exist_ok=True)
+        open(os.path.join(d, rel), 'w').write(text)
+    images = os.path.join(d, 'images')
+    cfgs = {'m30k': (dict(root_dir=d, image_root=images, dataset='multi30k', generated_caption_dir=os.path.join(d, 'gen'),
+                          generated_caption_type='text', train_file=['train_enc.txt', 'train_enc2de.txt']),
+                     'val_de.txt', os.path.join(d, 'val_de_trans.txt')),
+            'coco': (dict(root_dir=os.path.join(d, 'coco'), image_root=images, dataset='mscoco',
+                          generated_caption_dir=os.path.join(d, 'coco/gen'), generated_caption_type='text',
+                          train_file=['train_enc.txt', 'train_enc2ja.txt']), 'val_ja.txt', None)}
+    for tag, (cfg, ann, trans) in cfgs.items():
+        ref = z[tag]
+        tr = TrainAnnotations(cfg, 30)
+        assert len(tr) == ref['train_len'] and tr.languages == ref['languages'] and tr.img_ids == ref['img_ids']
+        for i, (_, caps, gen, img_idx, cap_id) in enumerate(ref['train_records']):
+            path, caps2, gen2, img_idx2, cap_id2 = tr.record(i)
+            assert (caps2, gen2, img_idx2, cap_id2) == (caps, gen, img_idx, cap_id), (tag, i)
+            assert path.startswith(images + '/') and path.endswith('.jpg')
+        ev = EvalAnnotations(cfg, ann, 30, test_trans_file=trans, type='eval')
+        assert ev.text == ref['eval_text'] and ev.image == ref['eval_image'] and ev.cap_ids == ref['eval_cap_ids']
+        assert {str(k): v for k, v in ev.txt2img.items()} == ref['txt2img']
+        assert {str(k): v for k, v in ev.img2txt.items()} == ref['img2txt']
+        assert getattr(ev, 'text_trans', None) == ref['text_trans'] and len(ev) == len(ref['eval_records'])
+        for i, (_, gen, idx) in enumerate(ref['eval_records']):
+            path, gen2, idx2 = ev.record(i)
+            assert (gen2, idx2) == (gen, idx) and path.startswith(images + '/')
+    # the mscoco image path goes through img_id/image_ids.txt
+    assert TrainAnnotations(cfgs['coco'][0]).record(0)[0].endswith('COCO_val2014_000000391895.jpg')
