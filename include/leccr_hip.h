@@ -24,6 +24,8 @@ extern "C" {
 
 #define LECCR_F32 0
 #define LECCR_BF16 1
+#define LECCR_FP8 2         /* leccr_gemm ab_dtype only: A and B are OCP e4m3 bytes (gfx950: e4m3fn, not MI300's fnuz) */
+#define LECCR_FP8_BF8A 3    /* leccr_gemm ab_dtype only: A is OCP e5m2 (gradients), B is OCP e4m3 (weights) */
 
 #define LECCR_OK 0
 #define LECCR_EINVAL (-1)      /* bad shape / null pointer / unsupported combination */
@@ -78,7 +80,11 @@ typedef struct leccr_gemm_params {
     void* C;
     int64_t M, N, K;
     int64_t lda, ldb, ldc;
-    int32_t ab_dtype;            /* dtype of A and B */
+    int32_t ab_dtype;            /* dtype of A and B.  LECCR_FP8 / LECCR_FP8_BF8A (BASELINE configs[4]: fp8 MFMA GEMM inputs): 1-byte
+                                    operands quantised by leccr_quantize_fp8 with per-tensor scales sa, sb; pass alpha = 1 / (sa sb).
+                                    trans_a = trans_b = 0, bf16 C, M, N >= 256, K % 128 == 0, lda / ldb % 16 == 0 only: the product runs on
+                                    v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 1.0) in the 4-wave 256x256 kernel, f32 accumulation, the forward /
+                                    dX epilogues of the bf16 path.  lda / ldb / K count fp8 ELEMENTS (= bytes). */
     int32_t c_dtype;             /* dtype of C, aux, aux_out, residual */
     int32_t trans_a, trans_b;
     const float* bias;           /* [N] f32 or NULL */
@@ -98,6 +104,8 @@ typedef struct leccr_gemm_params {
                                     dW = dY^T X this is the bias gradient colsum(dY) (autograd of F.linear's bias: clip/model.py:
                                     175-191, HF BERT dense layers); the 256x256 kernel computes it on the matrix cores beside
                                     the product (an all-ones B fragment), other paths run leccr_colsum over A */
+    const float* alpha_dev[2];   /* optional device scalars multiplied into alpha when the kernel starts (fp8 operands: the two
+                                    inverse quantisation scales live on the device, leccr_fp8_* below; no host read) */
 } leccr_gemm_params;
 
 int leccr_gemm(const leccr_gemm_params* p, void* stream);
@@ -251,6 +259,21 @@ int leccr_axpy(const void* x, void* y, float a, int64_t n, int dtype, void* stre
 /* Elementwise dropout y[i] = keep(seed, i) ? x[i] / (1-p) : 0 (nn.Dropout at attention.py:29-37,92-100; HF
  * hidden_dropout_prob).  The same call on the incoming gradient is the backward.  y may alias x. */
 int leccr_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dtype, void* stream);
+
+/* ---- fp8 GEMM operands (BASELINE configs[4]: "fp8 MFMA") --------------------------------------------------------
+ * Per-tensor scaled OCP fp8 copies of the bf16 GEMM operands, delayed scaling.  A quantisation SITE is 4 floats of device
+ * memory {amax, scale, 1/scale, format (0 = e4m3, max 448; 1 = e5m2, max 57344)}:
+ *   fp8_amax     : site.amax = max(site.amax, max |x|)                      (first use of a site: scale it from the data itself)
+ *   fp8_update   : for each of n sites with amax > 0: scale = 2^floor(log2(fmax / amax)), 1/scale; amax = 0   (once per step)
+ *   fp8_quantize : y = fp8(clamp(x * site.scale)) row by row (ldx, ldy in elements; fmt = the site's format), and site.amax accumulates max |x| for the
+ *                  NEXT step's scale.  x is bf16 (dtype LECCR_BF16) or f32.
+ * leccr_gemm then takes the 1-byte operands with ab_dtype = LECCR_FP8 / LECCR_FP8_BF8A and alpha_dev = {&siteA[2], &siteB[2]}.
+ * LayerNorm, softmax, the residual stream, every reduction and the losses stay bf16 / f32 as in the bf16 path.
+ */
+int leccr_fp8_amax(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, float* site, void* stream);
+int leccr_fp8_update(float* sites, int64_t n, void* stream);
+int leccr_fp8_quantize(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, int dtype, int fmt,
+                       float* site, void* stream);
 
 #ifdef __cplusplus
 }

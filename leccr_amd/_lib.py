@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libleccr_hip.so')
 
-F32, BF16 = 0, 1
+F32, BF16, FP8, FP8_BF8A = 0, 1, 2, 3      # FP8 / FP8_BF8A: leccr_gemm operand codes only (e4m3 x e4m3 / A e5m2 x B e4m3)
 EPI_NONE, EPI_QUICKGELU, EPI_GELU, EPI_DQUICKGELU, EPI_DGELU = 0, 1, 2, 3, 4
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
@@ -21,7 +21,7 @@ class GemmParams(C.Structure):
     _fields_ = [('A', vp), ('B', vp), ('C', vp), ('M', i64), ('N', i64), ('K', i64), ('lda', i64), ('ldb', i64),
                 ('ldc', i64), ('ab_dtype', i32), ('c_dtype', i32), ('trans_a', i32), ('trans_b', i32), ('bias', vp),
                 ('epilogue', i32), ('accumulate', i32), ('aux', vp), ('ldaux', i64), ('aux_out', vp),
-                ('residual', vp), ('ldr', i64), ('alpha', f32), ('reserved', i32), ('colsum', vp), ('asum', vp)]
+                ('residual', vp), ('ldr', i64), ('alpha', f32), ('reserved', i32), ('colsum', vp), ('asum', vp), ('alpha_dev', vp * 2)]
 
 
 _SIGS = {
@@ -49,6 +49,9 @@ _SIGS = {
     'leccr_bert_embed_fwd': ([vp, vp, vp, vp, vp, i64, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_bert_embed_bwd': ([vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_colsum': ([vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),
+    'leccr_fp8_amax': ([vp, i64, i64, i64, C.c_int, vp, vp], C.c_int),
+    'leccr_fp8_update': ([vp, i64, vp], C.c_int),
+    'leccr_fp8_quantize': ([vp, vp, i64, i64, i64, i64, C.c_int, C.c_int, vp, vp], C.c_int),
     'leccr_l2norm_fwd': ([vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),
     'leccr_l2norm_bwd': ([vp, vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),
     'leccr_sim_infonce_fwd': ([vp, vp, vp, f32, i64, i64, C.c_int, vp, vp, vp], C.c_int),

@@ -350,6 +350,7 @@ extern bool g_force_generic_attn;
 bool gemm256_wanted(const leccr_gemm_params& p);
 bool gemm256_legal(const leccr_gemm_params& p);
 bool gemm256_fuses_colsum(const leccr_gemm_params& p);
+bool gemm256w4_fp8_legal(const leccr_gemm_params& p);
 bool gemm256_fuses_asum(const leccr_gemm_params& p);
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
 void gemm256_set_max_blocks(int n, int64_t launches);
@@ -424,6 +425,17 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     const leccr_gemm_params& p = *pp;
     LECCR_REQUIRE(p.A && p.B && p.C, LECCR_EINVAL, "gemm: null operand");
     LECCR_REQUIRE(p.M >= 0 && p.N >= 0 && p.K >= 0, LECCR_EINVAL, "gemm: negative size");
+    if (p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A) {
+        // fp8 MFMA GEMM inputs: only the 4-wave 256x256 kernel has them (no generic / small-shape fp8 path: callers keep those in bf16)
+        LECCR_REQUIRE(gemm256w4_fp8_legal(p), LECCR_EINVAL, "gemm: fp8 operands need trans_a = trans_b = 0, a bf16 C, M, N >= 256, K %% 128 == 0, "
+                      "16-byte aligned rows and a compiled epilogue");
+        LECCR_REQUIRE(!p.colsum && !p.asum, LECCR_EINVAL, "gemm: fp8 operands with colsum / asum");
+        if (p.M == 0 || p.N == 0) return LECCR_OK;
+        hipStream_t st8 = as_stream(stream);
+        ProfScope prof(PROF_GEMM_NT, 2.0 * (double)p.M * (double)p.N * (double)p.K, st8);
+        g_last_kernel = 4;
+        return gemm256w4_launch(p, st8);
+    }
     LECCR_REQUIRE(p.ab_dtype == LECCR_F32 || p.ab_dtype == LECCR_BF16, LECCR_EINVAL, "gemm: bad ab_dtype");
     LECCR_REQUIRE(p.c_dtype == LECCR_F32 || p.c_dtype == LECCR_BF16, LECCR_EINVAL, "gemm: bad c_dtype");
     LECCR_REQUIRE(!(p.accumulate && p.c_dtype != LECCR_F32), LECCR_EINVAL, "gemm: accumulate needs an f32 C");

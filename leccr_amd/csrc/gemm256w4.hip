@@ -33,6 +33,10 @@ constexpr int HALF = 16384, SLOT = 4 * HALF, NTH = 256;
 constexpr int STG_WAVE = 16 * 128 * 4;                      // 16 rows x 128 f32 per wave
 constexpr int LDS_BYTES = 2 * SLOT + 4 * STG_WAVE;          // 131072 + 32768 = 163840 = all of the CU's LDS
 constexpr int F_RES = 2, F_AUXOUT = 4;
+// F_FP8: operands are OCP fp8 bytes (B e4m3; A e4m3, or e5m2 with F_BF8A): BASELINE configs[4]'s "fp8 MFMA" GEMM inputs.  A K-tile is
+// 128 fp8 = the same 128-byte LDS rows as 64 bf16, so staging, swizzle and fragment read addresses are byte-identical to the bf16
+// kernel (the launcher passes K / 2, lda / 2, ldb / 2 in bf16 units); only the MFMA differs - see the K loop.
+constexpr int F_FP8 = 32, F_BF8A = 64;
 
 struct Args {
     const bf16_t* A;
@@ -47,6 +51,7 @@ struct Args {
     int64_t ldr;
     float alpha;
     int tiles_m, tiles_n, nkt, n_items;
+    const float* alpha_dev[2];           // device scalars folded into alpha at kernel start (fp8 inverse scales), or null
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -172,6 +177,10 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
         n_mine = 1;
     }
     if (n_mine == 0) return;
+    if constexpr ((FLAGS & F_FP8) != 0) {              // alpha carries 1 / (scale_A scale_B), both kept on the device
+        if (a.alpha_dev[0]) a.alpha *= *a.alpha_dev[0];
+        if (a.alpha_dev[1]) a.alpha *= *a.alpha_dev[1];
+    }
 
     const uint32_t smem_off = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t wave_off = smem_off + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
@@ -201,15 +210,36 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
     const uint32_t offA = smem_off + wr * HALF, offB = smem_off + (2 + wc) * HALF;
 
     bf16x8 fa[2][4], fb[2][4];      // [k-step parity][32-row tile]
+    // fp8: a fragment is the 32-byte operand of v_mfma_scale_f32_32x32x64_f8f6f4 = the two 16-byte reads that the bf16 path makes
+    // for k-steps 2S and 2S + 1 (chunks 4S + kg and 4S + 2 + kg of the row).  Which 32 of a k-step's 64 k a lane group holds is
+    // immaterial as long as A and B agree (scripts/mb/mfma_fp8_probe.hip), so nothing but the MFMA changes.  One such MFMA takes
+    // the cycles of two bf16 32x32x16 at four times their k: the K-tile's 2048 MFMA cycles now cover 128 k instead of 64.
+    typedef __attribute__((ext_vector_type(8))) int v8i_t;
+    [[maybe_unused]] v8i_t xa[2][4], xb[2][4];      // [k-step parity][32-row tile]
+    auto frag8 = [](const bf16x8& lo, const bf16x8& hi) {
+        const int4_t l = __builtin_bit_cast(int4_t, lo), h = __builtin_bit_cast(int4_t, hi);
+        return v8i_t{l[0], l[1], l[2], l[3], h[0], h[1], h[2], h[3]};
+    };
+#define RD_FRAGS8(buf, S, KS8, i)                                                                                                   \
+    do {                                                                                                                            \
+        if ((i) < 4) xa[buf][(i) & 3] = frag8(lds_b128<((i) & 3) * 4096>(la[2 * (KS8)] + offA + (S)), lds_b128<((i) & 3) * 4096>(la[2 * (KS8) + 1] + offA + (S))); \
+        else xb[buf][(i) & 3] = frag8(lds_b128<((i) & 3) * 4096>(la[2 * (KS8)] + offB + (S)), lds_b128<((i) & 3) * 4096>(la[2 * (KS8) + 1] + offB + (S)));         \
+    } while (0)
 #define RD_FRAGS(buf, S, KS, i)                                                              \
     do {                                                                                       \
         if ((i) < 4) fa[buf][(i) & 3] = lds_b128<((i) & 3) * 4096>(la[KS] + offA + (S));       \
         else fb[buf][(i) & 3] = lds_b128<((i) & 3) * 4096>(la[KS] + offB + (S));               \
     } while (0)
     // k-step 0 of K-tile 0
-    static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; RD_FRAGS(0, 0u, 0, i); });
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]));
+    if constexpr ((FLAGS & F_FP8) != 0) {
+        static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; RD_FRAGS8(0, 0u, 0, i); });
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(xa[0][0]), "+v"(xa[0][1]), "+v"(xa[0][2]), "+v"(xa[0][3]), "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[0][2]), "+v"(xb[0][3]));
+    } else {
+        static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; RD_FRAGS(0, 0u, 0, i); });
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]));
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     int t = 0;
@@ -224,6 +254,45 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             const uint32_t sc = (t & 1) * SLOT, sn = SLOT - sc;
             // per-lane address pieces go through an opaque asm each K-tile so that the derived addresses are formed at their use
             asm volatile("" : "+v"(la[0]), "+v"(la[1]), "+v"(la[2]), "+v"(la[3]));
+            if constexpr ((FLAGS & F_FP8) != 0) {
+                // fp8: two k-steps of 64 k per K-tile, 16 scaled MFMAs each; fill(i) behind MFMA i loads one whole fragment (i < 8) or
+                // issues one DMA piece (i >= 8), as in the bf16 schedule with its k-steps 0..2 folded into one:
+                //   K0 (buffer 0): reads k-step 1 of this slot; the rest (pieces 8-15) of K-tile t+1  -> wait; vmcnt(0); BARRIER
+                //   K1 (buffer 1): reads k-step 0 of K-tile t+1; pieces 0-7 of K-tile t+2 into the slot the barrier freed
+                constexpr int AFMT = (FLAGS & F_BF8A) != 0 ? 1 : 0;      // format of the activation / gradient operand: 0 e4m3, 1 e5m2
+                auto kstep8 = [&](auto ks_tag, auto&& fill) {
+                    constexpr int cb = decltype(ks_tag)::value & 1;
+                    static_for<0, 16>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, ni = i >> 2, mi = i & 3;
+                        acc[ni * 4 + mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xb[cb][ni], xa[cb][mi], acc[ni * 4 + mi], 0, AFMT, 0,
+                                                                                           0x7F7F7F7F, 0, 0x7F7F7F7F);
+                        __builtin_amdgcn_sched_barrier(0);
+                        fill(ic);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                };
+#define WAIT_FRAGS8(buf)                                                                                                    \
+    do {                                                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                     : "+v"(xa[buf][0]), "+v"(xa[buf][1]), "+v"(xa[buf][2]), "+v"(xa[buf][3]), "+v"(xb[buf][0]),            \
+                       "+v"(xb[buf][1]), "+v"(xb[buf][2]), "+v"(xb[buf][3]));                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    } while (0)
+#define FILL8(KSP, buf, S, RKS8, slot)                                                        \
+    [&](auto ic) {                                                                            \
+        constexpr int i = decltype(ic)::value;                                                \
+        if constexpr (i < 8) RD_FRAGS8(buf, S, RKS8, i);                                      \
+        if constexpr (piece_at(KSP, i) >= 0) ISSUE_PN(piece_at(KSP, i), slot);                \
+    }
+                kstep8(std::integral_constant<int, 0>{}, FILL8(0, 1, sc, 1, sn));
+                advance(a, first_item, stride, n_mine, cB);           // cB -> K-tile t+2
+                WAIT_FRAGS8(1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of K-tile t+1 have landed
+                SEG_BARRIER();                                        // slot sc is free, slot sn is complete
+                kstep8(std::integral_constant<int, 1>{}, FILL8(3, 0, sn, 0, sc));
+                WAIT_FRAGS8(0);
+                continue;
+            }
             // k-step KS: 16 MFMAs on buffer KS & 1; fill(i) after MFMA i
             auto kstep = [&](auto ks_tag, auto&& fill) {
                 constexpr int KS = decltype(ks_tag)::value, cb = KS & 1;
@@ -371,6 +440,21 @@ static void launch_inst(const Args& a, int grid, hipStream_t st) {
 
 static int w4_flags(const leccr_gemm_params& p) { return (p.residual ? g4::F_RES : 0) | (p.aux_out ? g4::F_AUXOUT : 0); }
 
+// fp8 operands (LECCR_FP8: e4m3 x e4m3; LECCR_FP8_BF8A: A e5m2 x B e4m3): whole 128-element K-tiles, 16-byte aligned rows, and the
+// epilogues a forward (e4m3 activations) or a dX (e5m2 gradients) product needs
+bool gemm256w4_fp8_legal(const leccr_gemm_params& p) {
+    if (p.ab_dtype != LECCR_FP8 && p.ab_dtype != LECCR_FP8_BF8A) return false;
+    if (p.trans_a != 0 || p.trans_b != 0 || p.c_dtype != LECCR_BF16 || p.accumulate) return false;
+    if (p.M < 256 || p.N < 256 || (p.N & 31) || (p.ldc & 7) || (p.ldr & 7) || (p.ldaux & 7) || (p.K & 127) || (p.lda & 15) || (p.ldb & 15)) return false;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda >= (1 << 23) || p.ldb >= (1 << 23)) return false;
+    const int f = w4_flags(p);
+    if (p.ab_dtype == LECCR_FP8)
+        return (p.epilogue == LECCR_EPI_NONE && (f == 0 || f == g4::F_RES)) ||
+               ((p.epilogue == LECCR_EPI_QUICKGELU || p.epilogue == LECCR_EPI_GELU) && f == g4::F_AUXOUT);
+    return (p.epilogue == LECCR_EPI_NONE && (f == 0 || f == g4::F_RES)) ||
+           ((p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU) && f == 0);
+}
+
 bool gemm256w4_legal(const leccr_gemm_params& p) {
     if (p.trans_a != 0 || p.trans_b != 0 || p.c_dtype != LECCR_BF16 || p.ab_dtype != LECCR_BF16 || p.accumulate) return false;
     if (p.M < 256 || p.N < 256 || (p.N & 31) || (p.ldc & 7) || (p.ldr & 7) || (p.ldaux & 7) || (p.K % g4::BK)) return false;
@@ -398,6 +482,24 @@ int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st) {
     a.n_items = a.tiles_m * a.tiles_n;
     const int grid = a.n_items < 256 ? a.n_items : 256;
     const int f = w4_flags(p);
+    a.alpha_dev[0] = p.alpha_dev[0]; a.alpha_dev[1] = p.alpha_dev[1];
+    if (p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A) {
+        // the bf16 problem with half the columns: byte-identical staging (see F_FP8)
+        a.K = p.K / 2; a.lda = p.lda / 2; a.ldb = p.ldb / 2;
+        a.nkt = (int)(a.K / BK);
+        if (p.ab_dtype == LECCR_FP8) {
+            if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_inst<LECCR_EPI_NONE, F_RES | F_FP8>(a, grid, st);
+            else if (p.epilogue == LECCR_EPI_NONE) launch_inst<LECCR_EPI_NONE, F_FP8>(a, grid, st);
+            else if (p.epilogue == LECCR_EPI_QUICKGELU) launch_inst<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8>(a, grid, st);
+            else launch_inst<LECCR_EPI_GELU, F_AUXOUT | F_FP8>(a, grid, st);
+        } else {
+            if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_inst<LECCR_EPI_NONE, F_RES | F_FP8 | F_BF8A>(a, grid, st);
+            else if (p.epilogue == LECCR_EPI_NONE) launch_inst<LECCR_EPI_NONE, F_FP8 | F_BF8A>(a, grid, st);
+            else if (p.epilogue == LECCR_EPI_DQUICKGELU) launch_inst<LECCR_EPI_DQUICKGELU, F_FP8 | F_BF8A>(a, grid, st);
+            else launch_inst<LECCR_EPI_DGELU, F_FP8 | F_BF8A>(a, grid, st);
+        }
+        return check_launch("gemm256w4 fp8");
+    }
     switch (p.epilogue) {
         case LECCR_EPI_NONE:
             if (f == F_RES) launch_inst<LECCR_EPI_NONE, F_RES>(a, grid, st);

@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from ._lib import (BF16, EPI_DGELU, EPI_DQUICKGELU, EPI_GELU, EPI_NONE, EPI_QUICKGELU, F32, check, dtype_code, lib,
+from ._lib import (BF16, EPI_DGELU, EPI_DQUICKGELU, EPI_GELU, EPI_NONE, EPI_QUICKGELU, F32, FP8, FP8_BF8A, check, dtype_code, lib,
                    ptr, stream)
 
 
@@ -21,21 +21,30 @@ def _rows2d(t):
 
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
-         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None):
+         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None):
     """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major."""
-    assert a.dim() == 2 and b.dim() == 2 and a.dtype == b.dtype
+    assert a.dim() == 2 and b.dim() == 2 and (a.dtype == b.dtype or a.dtype == torch.float8_e5m2)
     assert a.stride(1) == 1 and b.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     N, Kb = (b.shape[1], b.shape[0]) if trans_b else b.shape
     assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
+    fp8 = a.dtype in (torch.float8_e4m3fn, torch.float8_e5m2)
     if out is None:
-        out = torch.empty(M, N, device=a.device, dtype=out_dtype or a.dtype)
+        out = torch.empty(M, N, device=a.device, dtype=out_dtype or (torch.bfloat16 if fp8 else a.dtype))
     assert out.shape == (M, N) and out.stride(1) == 1
     p = L.GemmParams()
     p.A, p.B, p.C = ptr(a), ptr(b), ptr(out)
     p.M, p.N, p.K = M, N, K
     p.lda, p.ldb, p.ldc = a.stride(0), b.stride(0), out.stride(0)
-    p.ab_dtype, p.c_dtype = dtype_code(a), dtype_code(out)
+    if fp8:     # fp8 operands (quantize_fp8): b e4m3, a e4m3 (forward) or e5m2 (gradients); alpha_dev = their two inverse scales
+        assert b.dtype == torch.float8_e4m3fn and not trans_a and not trans_b
+        p.ab_dtype, p.c_dtype = (FP8 if a.dtype == torch.float8_e4m3fn else FP8_BF8A), dtype_code(out)
+    else:
+        p.ab_dtype, p.c_dtype = dtype_code(a), dtype_code(out)
+    if alpha_dev is not None:
+        for i, t in enumerate(alpha_dev):
+            assert t.dtype == torch.float32 and t.numel() >= 1 and t.is_cuda
+            p.alpha_dev[i] = t.data_ptr()
     p.trans_a, p.trans_b = int(trans_a), int(trans_b)
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
@@ -351,3 +360,48 @@ def dropout(x, p, seed, out=None):
     out = torch.empty_like(x) if out is None else out
     check(lib().leccr_dropout(ptr(x), ptr(out), x.numel(), float(p), int(seed), dtype_code(x), stream()), 'leccr_dropout')
     return out
+
+
+# --------------------------------------------------------------------------------------- fp8 GEMM operands
+class Fp8Sites:
+    """A block of quantisation sites ({amax, scale, 1/scale, format} x n, one f32 tensor on the device; see leccr_hip.h).
+    new(fmt) hands out one site; update() turns the amax every site has seen into its next scale (once per step)."""
+
+    E4M3, E5M2 = 0, 1
+
+    def __init__(self, device, capacity=4096):
+        self.state = torch.zeros(capacity, 4, device=device, dtype=torch.float32)
+        self.state[:, 1:3] = 1.0
+        self.n = 0
+
+    def new(self, fmt):
+        assert self.n < self.state.shape[0]
+        i, self.n = self.n, self.n + 1
+        self.state[i, 3] = float(fmt)
+        return Fp8Site(self.state[i], fmt)
+
+    def update(self):
+        if self.n:
+            check(lib().leccr_fp8_update(ptr(self.state), self.n, stream()), 'leccr_fp8_update')
+
+
+class Fp8Site:
+    def __init__(self, row, fmt):
+        self.row, self.fmt, self.primed = row, fmt, False
+        self.inv_scale = row[2:3]                                    # device scalar handed to leccr_gemm (alpha_dev)
+
+    def quantize(self, x, out=None):
+        """x [rows, cols] (bf16 or f32, unit inner stride) -> its fp8 copy under this site's scale.  The first use scales from the
+        tensor itself (amax pass + update); afterwards the scale is the one the previous step's amax gave (delayed scaling)."""
+        assert x.dim() == 2 and x.stride(1) == 1
+        rows, cols = x.shape
+        dt = torch.float8_e4m3fn if self.fmt == Fp8Sites.E4M3 else torch.float8_e5m2
+        y = torch.empty(rows, cols, device=x.device, dtype=dt) if out is None else out
+        assert y.shape == (rows, cols) and y.stride(1) == 1 and y.dtype == dt
+        if not self.primed:
+            check(lib().leccr_fp8_amax(ptr(x), rows, cols, x.stride(0), dtype_code(x), ptr(self.row), stream()), 'leccr_fp8_amax')
+            check(lib().leccr_fp8_update(ptr(self.row), 1, stream()), 'leccr_fp8_update')
+            self.primed = True
+        check(lib().leccr_fp8_quantize(ptr(x), ptr(y), rows, cols, x.stride(0), y.stride(0), dtype_code(x), self.fmt, ptr(self.row),
+                                       stream()), 'leccr_fp8_quantize')
+        return y

@@ -664,3 +664,118 @@ def test_attention_dropout_matches_masked_reference(K, dtype, hd, Lq, Lk):
     for name, got, r in (('dq', dq, qr.grad), ('dk', dk, kr.grad), ('dv', dv, vr.grad)):
         e, s = _err(got, r)
         assert e <= (1e-4 if dtype == torch.float32 else 3e-2) * s, (name, e, s)
+
+
+# ------------------------------------------------------------------------------------------ fp8 GEMM operands (BASELINE configs[4])
+def _fp8_deq(t8, site):
+    """What the fp8 bytes mean: value = float(byte) / scale (exact in f64)."""
+    return t8.float().double().cpu() * float(site.row[2])
+
+
+@pytest.mark.parametrize('fmt', [0, 1])
+def test_fp8_quantize_scales_saturates_and_tracks_amax(K, fmt):
+    """leccr_fp8_amax / update / quantize: power-of-two scale from the tensor's own amax on first use, round-to-nearest OCP
+    e4m3 / e5m2 bytes equal to torch's own conversion of x * scale, amax of the CURRENT tensor recorded for the next step's scale,
+    clamping (not NaN) when a later tensor outgrows the delayed scale."""
+    sites = K.Fp8Sites(DEV, 8)
+    site = sites.new(fmt)
+    x = _rand((300, 256), torch.bfloat16, 500, 3.0).to(DEV)
+    y = site.quantize(x)
+    fmax = 57344.0 if fmt else 448.0
+    amax = float(x.float().abs().max())
+    scale = float(site.row[1])
+    assert scale == 2.0 ** math.floor(math.log2(fmax / amax)) and abs(float(site.row[2]) * scale - 1.0) < 1e-7
+    want = (x.float() * scale).to(y.dtype)
+    assert torch.equal(y.view(torch.uint8), want.view(torch.uint8))
+    assert abs(float(site.row[0]) - amax) < 1e-6 * amax                  # recorded for the next update
+    sites.update()
+    assert float(site.row[0]) == 0.0 and float(site.row[1]) == scale
+    big = (x.float() * 64).to(torch.bfloat16)                            # outgrows the delayed scale: clamped to +-fmax, finite
+    yb = site.quantize(big)
+    assert bool(torch.isfinite(yb.float()).all()) and float(yb.float().abs().max()) == fmax
+    sites.update()
+    assert float(site.row[1]) == scale / 64                              # ... and the next step's scale follows
+    # f32 input, strided rows
+    xf = _rand((64, 512), torch.float32, 501).to(DEV)
+    s2 = sites.new(fmt)
+    y2 = s2.quantize(xf[:, :256])
+    assert torch.equal(y2.view(torch.uint8), (xf[:, :256] * float(s2.row[1])).to(y2.dtype).view(torch.uint8))
+
+
+@pytest.mark.parametrize('M,N,K_,case', [(256, 256, 128, 'plain'), (1154, 768, 1024, 'plain'), (2000, 3072, 768, 'act'),
+                                         (1460, 1024, 4096, 'res'), (730 * 4, 4096, 1024, 'gelu'), (1154, 2304, 768, 'bias')])
+def test_gemm_fp8_forward_operands(K, M, N, K_, case):
+    """leccr_gemm with ab_dtype LECCR_FP8 (e4m3 x e4m3, v_mfma_scale_f32_32x32x64_f8f6f4): against the f64 product of the
+    DEQUANTISED operands - what the quantised operands mean exactly - so the only differences are f32 accumulation order and the
+    bf16 rounding of C.  Epilogues of a forward Linear: bias, QuickGELU / GELU with the saved pre-activation, residual."""
+    from leccr_amd import _lib
+    sites = K.Fp8Sites(DEV, 8)
+    sa, sb = sites.new(0), sites.new(0)
+    a = _rand((M, K_), torch.bfloat16, 510).to(DEV)
+    b = _rand((N, K_), torch.bfloat16, 511, 0.05).to(DEV)
+    a8, b8 = sa.quantize(a), sb.quantize(b)
+    bias = _rand((N,), torch.float32, 512).to(DEV)
+    u = _fp8_deq(a8, sa) @ _fp8_deq(b8, sb).t() + bias.double().cpu()
+    kw, ref, pre = {}, u, None
+    if case == 'res':
+        res = _rand((M, N), torch.bfloat16, 513)
+        kw, ref = dict(residual=res.to(DEV)), u + res.double()
+    elif case in ('act', 'gelu'):
+        epi = 1 if case == 'act' else 2
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        kw, ref = dict(epilogue=epi, aux_out=pre), ACT[epi](u)
+    out = K.gemm(a8, b8, bias=bias, alpha_dev=(sa.inv_scale, sb.inv_scale), **kw)
+    assert _lib.lib().leccr_last_gemm_kernel() == 4 and out.dtype == torch.bfloat16
+    e, s = _err(out, ref)
+    assert e <= 1.2e-2 * s, (case, e, s)                  # bf16 output rounding (2^-8 of the largest magnitude)
+    if pre is not None:
+        e, s = _err(pre, u)
+        assert e <= 1.2e-2 * s
+    # and the quantisation itself is a small perturbation of the bf16 product (e4m3: 3 mantissa bits, K-fold averaging)
+    full = a.double().cpu() @ b.double().cpu().t() + bias.double().cpu()
+    assert float((u - full).norm() / full.norm()) < 0.06
+
+
+@pytest.mark.parametrize('M,N,K_,case', [(1154, 768, 3072, 'plain'), (1460, 1024, 1024, 'res'), (2000, 3072, 768, 'dact'),
+                                         (1154, 4096, 1024, 'dgelu')])
+def test_gemm_fp8_gradient_operands(K, M, N, K_, case):
+    """ab_dtype LECCR_FP8_BF8A: A (the incoming gradient dY) in e5m2, B (the [in, out] weight copy) in e4m3 - the dX product
+    with its epilogues: residual gradient, derivative of QuickGELU / GELU at the saved pre-activation."""
+    from leccr_amd import _lib
+    sites = K.Fp8Sites(DEV, 8)
+    sa, sb = sites.new(1), sites.new(0)
+    a = _rand((M, K_), torch.bfloat16, 520, 1e-3).to(DEV)                  # gradients are small: the scale must lift them
+    b = _rand((N, K_), torch.bfloat16, 521, 0.05).to(DEV)
+    a8, b8 = sa.quantize(a), sb.quantize(b)
+    assert a8.dtype == torch.float8_e5m2 and float(sa.row[1]) > 1e3
+    u = _fp8_deq(a8, sa) @ _fp8_deq(b8, sb).t()
+    kw, ref = {}, u
+    if case == 'res':
+        res = _rand((M, N), torch.bfloat16, 522, 1e-2)
+        kw, ref = dict(residual=res.to(DEV)), u + res.double()
+    elif case in ('dact', 'dgelu'):
+        x = _rand((M, N), torch.bfloat16, 523)
+        xd = x.double()
+        if case == 'dact':
+            sg = torch.sigmoid(1.702 * xd)
+            d = sg * (1 + 1.702 * xd * (1 - sg))
+        else:
+            d = 0.5 * (1 + torch.erf(xd / math.sqrt(2))) + xd * torch.exp(-0.5 * xd * xd) / math.sqrt(2 * math.pi)
+        kw, ref = dict(epilogue=3 if case == 'dact' else 4, aux=x.to(DEV)), u * d
+    out = K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), **kw)
+    assert _lib.lib().leccr_last_gemm_kernel() == 4
+    e, s = _err(out, ref)
+    assert e <= 1.2e-2 * s, (case, e, s)
+
+
+def test_gemm_fp8_rejects_what_it_does_not_implement(K):
+    sites = K.Fp8Sites(DEV, 4)
+    sa, sb = sites.new(0), sites.new(0)
+    a8 = sa.quantize(_rand((512, 256), torch.bfloat16, 530).to(DEV))
+    b8 = sb.quantize(_rand((512, 256), torch.bfloat16, 531).to(DEV))
+    with pytest.raises(RuntimeError):                       # K must be whole 128-element tiles
+        K.gemm(a8[:, :192].contiguous(), b8[:, :192].contiguous())
+    with pytest.raises(RuntimeError):                       # small N: no fp8 path below the 256-tile (callers keep those in bf16)
+        K.gemm(a8, b8[:128])
+    with pytest.raises((RuntimeError, AssertionError)):     # weight-gradient layout: not an fp8 product here
+        K.gemm(a8, b8, trans_a=True, trans_b=True, out=torch.zeros(256, 256, device=DEV), accumulate=True)
