@@ -99,13 +99,24 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
 
 using namespace leccr;
 
-static unsigned rows_grid(int64_t rows) { return (unsigned)(rows < 4096 ? (rows < 1 ? 1 : rows) : 4096); }
+static unsigned rows_grid(int64_t rows) { return (unsigned)(rows < 16384 ? (rows < 1 ? 1 : rows) : 16384); }
+// contiguous rows (ld == cols): the tensor is re-cut into pseudo-rows of 2048 elements so that every thread of a block has one
+// 8-element chunk (a 768- or 1024-wide row leaves half of a 256-thread block idle: 3.3 TB/s measured against 4.8 on 4096-wide rows)
+static void recut(int64_t& rows, int64_t& cols, int64_t& ldx, int64_t* ldy) {
+    if (ldx != cols || (ldy && *ldy != cols)) return;
+    const int64_t total = rows * cols;
+    if (total % 2048 == 0 && cols < 2048) {
+        rows = total / 2048; cols = 2048; ldx = 2048;
+        if (ldy) *ldy = 2048;
+    }
+}
 
 extern "C" int leccr_fp8_amax(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, float* site, void* stream) {
     LECCR_REQUIRE(x && site && rows >= 0 && cols > 0 && (cols & 7) == 0 && ldx >= cols && (ldx & 7) == 0, LECCR_EINVAL, "fp8_amax: bad argument (cols, ldx multiples of 8)");
     LECCR_REQUIRE(((uintptr_t)x & 15) == 0, LECCR_EALIGN, "fp8_amax: x must be 16-byte aligned");
     if (rows == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
+    recut(rows, cols, ldx, nullptr);
     if (dtype == LECCR_BF16) hipLaunchKernelGGL((fp8_amax_kernel<bf16_t>), dim3(rows_grid(rows)), dim3(256), 0, st, (const bf16_t*)x, rows, (int)cols, ldx, site);
     else if (dtype == LECCR_F32) hipLaunchKernelGGL((fp8_amax_kernel<float>), dim3(rows_grid(rows)), dim3(256), 0, st, (const float*)x, rows, (int)cols, ldx, site);
     else { set_error("fp8_amax: bad dtype"); return LECCR_EINVAL; }
@@ -127,6 +138,7 @@ extern "C" int leccr_fp8_quantize(const void* x, void* y, int64_t rows, int64_t 
     LECCR_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)y) & 7) == 0, LECCR_EALIGN, "fp8_quantize: misaligned");
     if (rows == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
+    recut(rows, cols, ldx, &ldy);
     const dim3 g(rows_grid(rows)), b(256);
     if (dtype == LECCR_BF16 && fmt == 0) hipLaunchKernelGGL((fp8_quantize_kernel<bf16_t, 0>), g, b, 0, st, (const bf16_t*)x, (uint8_t*)y, rows, (int)cols, ldx, ldy, site);
     else if (dtype == LECCR_BF16) hipLaunchKernelGGL((fp8_quantize_kernel<bf16_t, 1>), g, b, 0, st, (const bf16_t*)x, (uint8_t*)y, rows, (int)cols, ldx, ldy, site);

@@ -70,6 +70,7 @@ class BertLayer(nn.Module):
         super().__init__()
         d = c['hidden_size']
         self.heads, self.eps = c['num_attention_heads'], c['layer_norm_eps']
+        self.fp8 = False               # set by XVLMBase._ensure_runtime for compute_dtype 'fp8'
         self.hidden_dropout_p, self.attn_dropout_p = c['hidden_dropout_prob'], c['attention_probs_dropout_prob']
         self.attention = _Attention(d, self.eps)
         self.intermediate = _Intermediate(d, c['intermediate_size'])

@@ -34,6 +34,7 @@ class ResidualAttentionBlock(nn.Module):
     def __init__(self, d, heads):
         super().__init__()
         self.heads = heads
+        self.fp8 = False               # set by XVLMBase._ensure_runtime for compute_dtype 'fp8'
         self.attn = _MHAParams(d)
         self.ln_1 = LayerNormParams(d, 1e-5)
         self.mlp = _MLP(d)

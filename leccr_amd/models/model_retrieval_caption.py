@@ -108,6 +108,8 @@ class RetrievalModel(XVLMBase):
         self._ensure_runtime()
         begin_step_gathers()
         ops.begin_step()
+        if self.fp8_sites is not None:         # scales of this step = what the previous step's tensors asked for (delayed scaling)
+            self.fp8_sites.update()
         if self.training:          # fresh dropout masks per step and per rank (the reference seeds with seed + rank)
             self._step_count = getattr(self, '_step_count', 0) + 1
             rank, _ = _dist_info()

@@ -66,6 +66,8 @@ class RetrievalModel(_ImageRetrievalModel):
         self._ensure_runtime()
         begin_step_gathers()
         ops.begin_step()
+        if self.fp8_sites is not None:         # scales of this step = what the previous step's tensors asked for (delayed scaling)
+            self.fp8_sites.update()
         if self.training:
             self._step_count = getattr(self, '_step_count', 0) + 1
             rank, _ = _dist_info()

@@ -4,7 +4,9 @@ Extensions (all optional, defaults reproduce the reference's hard-coded choices)
   config['clip_name']      'ViT-B/32' (reference default, xvlm.py:85) | 'ViT-B/16' | 'ViT-L/14'
   config['text_config']    dict of BERT geometry overrides (default: bert-base-multilingual-cased geometry)
   config['clip_geometry']  dict of CLIP constructor arguments overriding clip_name (tiny parity fixtures)
-  config['compute_dtype']  'fp32' (reference precision, parity path) | 'bf16' (MFMA path)
+  config['compute_dtype']  'fp32' (reference precision, parity path) | 'bf16' (MFMA path) | 'fp8' (BASELINE configs[4]: the bf16 path with
+                           OCP fp8 operands - e4m3 forward, e5m2 gradients, per-tensor delayed scaling - in the forward and dX GEMMs of
+                           the ViT blocks and BERT layers; LayerNorm, softmax, residuals, weight gradients, heads and losses as in bf16)
   config['clip_text_tower'] keep the unused CLIP text tower's parameters for state_dict compatibility (default True)
 """
 import torch
@@ -192,7 +194,9 @@ class XVLMBase(nn.Module):
         # everything before them can be all-reduced while the ViT backward still runs (leccr_amd.parallel)
         self._arena_late_prefix = 'clip_encoder.visual.'
         dt = (config or {}).get('compute_dtype', 'fp32')
-        self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16}[dt]
+        self.compute_dtype = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp8': torch.bfloat16}[dt]
+        self.fp8 = dt == 'fp8'
+        self.fp8_sites = None
         self.arena = None
 
     # ------------------------------------------------------------------ runtime (arena + compute copies)
@@ -231,8 +235,37 @@ class XVLMBase(nn.Module):
                 a.need_transposed(p)
         for layer in self.text_encoder.encoder.layer:
             a.need_transposed(layer._qkv_w)
+        if self.fp8:
+            self._enable_fp8(a, dev)
         a.refresh()
         return a
+
+    def _enable_fp8(self, a, dev):
+        """fp8 GEMM operands for the encoder blocks: every big Linear gets an e4m3 copy of its weight in both layouts ([out, in] for the
+        forward product, [in, out] for dX; requantised after each optimizer step under one per-tensor site) and two activation sites
+        (its input, e4m3; its incoming gradient, e5m2).  Scales are delayed by one step (kernels.Fp8Sites), primed from the data on
+        first use."""
+        from ..kernels import Fp8Sites
+        holders = []
+        if self.clip_encoder is not None:
+            for blk in self.clip_encoder.visual.transformer.resblocks:
+                blk.fp8 = True
+                holders += [blk.attn.in_proj_weight, blk.attn.out_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight]
+        for layer in self.text_encoder.encoder.layer:
+            layer.fp8 = True
+            holders += [layer._qkv_w, layer.attention.output.dense.weight, layer.intermediate.dense.weight, layer.output.dense.weight]
+        self.fp8_sites = sites = Fp8Sites(dev, 3 * len(holders) + 8)
+        for h in holders:
+            assert h._lpt is not None and h._lp.dim() == 2
+            h._wsite, h._xsite, h._gsite = sites.new(Fp8Sites.E4M3), sites.new(Fp8Sites.E4M3), sites.new(Fp8Sites.E5M2)
+            h._q8 = torch.empty(h._lp.shape, device=dev, dtype=torch.float8_e4m3fn)
+            h._q8t = torch.empty(h._lpt.shape, device=dev, dtype=torch.float8_e4m3fn)
+
+        def requantise():
+            for h in holders:
+                h._wsite.quantize(h._lp, out=h._q8)
+                h._wsite.quantize(h._lpt, out=h._q8t)
+        a.post_refresh.append(requantise)
 
     def refresh_weights(self):
         """Re-derive the low-precision compute copies after the master weights changed (optimizer step / load)."""

@@ -58,13 +58,28 @@ def _bias(b):
     return None if b is None else b.data.reshape(-1)
 
 
-def lin_fwd(x2, w, b=None, **kw):
-    """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free)."""
+def _fp8_ok(x2, w8):
+    """The fp8 product exists for the large Linears only (leccr_gemm: M, N >= 256, whole 128-element K-tiles, N % 32 == 0)."""
+    return (x2.shape[0] >= 256 and w8.shape[0] >= 256 and w8.shape[0] % 32 == 0 and w8.shape[1] % 128 == 0 and x2.stride(1) == 1
+            and x2.stride(0) % 16 == 0)
+
+
+def lin_fwd(x2, w, b=None, fp8=False, **kw):
+    """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free).
+    fp8 (compute_dtype 'fp8', the encoder blocks' Linears): x2 is quantised to e4m3 under the Linear's activation site and
+    multiplied with the weight's e4m3 copy on the scaled-MFMA kernel; the saved-for-backward tensors stay bf16."""
+    if fp8 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8):
+        x8 = w._xsite.quantize(x2)
+        return K.gemm(x8, w._q8, bias=_bias(b), alpha_dev=(w._xsite.inv_scale, w._wsite.inv_scale), **kw)
     return K.gemm(x2, w._lp, bias=_bias(b), **kw)
 
 
-def lin_dx(dy2, w, **kw):
-    """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N]."""
+def lin_dx(dy2, w, fp8=False, **kw):
+    """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N].
+    fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
+    if fp8 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t):
+        g8 = w._gsite.quantize(dy2)
+        return K.gemm(g8, w._q8t, alpha_dev=(w._gsite.inv_scale, w._wsite.inv_scale), **kw)
     if w._lpt is not None:
         return K.gemm(dy2, w._lpt, **kw)
     return K.gemm(dy2, w._lp, trans_b=True, **kw)
@@ -320,13 +335,13 @@ class ViTBlockFn(torch.autograd.Function):
         b, N, d = x.shape
         M = b * N
         h1, mean1, rstd1, _ = K.layernorm_fwd(x, blk.ln_1.weight.data, blk.ln_1.bias.data, 1e-5)
-        qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias).view(b, N, 3 * d)
+        qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8).view(b, N, 3 * d)
         o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
-        x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, residual=_rows(x)).view(b, N, d)
+        x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, residual=_rows(x)).view(b, N, d)
         h2, mean2, rstd2, _ = K.layernorm_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5)
         pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
-        act = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, epilogue=EPI_QUICKGELU, aux_out=pre)
-        x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, residual=_rows(x1)).view(b, N, d)
+        act = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, epilogue=EPI_QUICKGELU, aux_out=pre)
+        x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, residual=_rows(x1)).view(b, N, d)
         ctx.save_for_backward(x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act)
         ctx.blk = blk
         return x2
@@ -339,24 +354,24 @@ class ViTBlockFn(torch.autograd.Function):
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
-        dpre = lin_dx(g2, blk.mlp.c_proj.weight, epilogue=EPI_DQUICKGELU, aux=pre)
+        dpre = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, epilogue=EPI_DQUICKGELU, aux=pre)
         # bias gradients of c_proj / out_proj = column sums of dx2 / dx1.  They ride the weight-gradient stream as 40 us HBM-bound
         # passes beside the dX chain: folded into the LayerNorm backward launches (whose `dres` operands those tensors are) they
         # cost that kernel a fifth of its occupancy - 253 us against 201 us per launch on the main chain
         lin_dw(g2, act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
-        dh2 = lin_dx(dpre, blk.mlp.c_fc.weight)
+        dh2 = lin_dx(dpre, blk.mlp.c_fc.weight, fp8=blk.fp8)
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
         lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
         dx1 = K.layernorm_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g,
                               blk.ln_2.bias._g, dres=dx2)
         g1 = _rows(dx1)
-        do = lin_dx(g1, blk.attn.out_proj.weight).view(b, N, d)
+        do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8).view(b, N, d)
         lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
-        dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight)
+        dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8)
         lin_dw(_rows(dqkv), _rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias)
         dx = K.layernorm_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g,
                              blk.ln_1.bias._g, dres=dx1)
@@ -437,28 +452,28 @@ class BertLayerFn(torch.autograd.Function):
         b, L, d = x.shape
         ph, pa = _p(layer, 'hidden_dropout_p'), _p(layer, 'attn_dropout_p')
         seeds = (_next_seed(), _next_seed(), _next_seed())
-        qkv = lin_fwd(_rows(x), layer._qkv_w, layer._qkv_b).view(b, L, 3 * d)
+        qkv = lin_fwd(_rows(x), layer._qkv_w, layer._qkv_b, fp8=layer.fp8).view(b, L, 3 * d)
         o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask, pa, seeds[0])
         ao = layer.attention.output
         if ph > 0:      # dense -> dropout -> + residual (inside the LayerNorm kernel)
-            a1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias)
+            a1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8)
             K.dropout(a1, ph, seeds[1], out=a1)
             x1, mean1, rstd1, s1 = K.layernorm_fwd(a1.view(b, L, d), ao.LayerNorm.weight.data, ao.LayerNorm.bias.data,
                                                    layer.eps, add=x, want_sum=True)
         else:
-            s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, residual=_rows(x)).view(b, L, d)
+            s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8, residual=_rows(x)).view(b, L, d)
             x1, mean1, rstd1, _ = K.layernorm_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps)
         pre = torch.empty(b * L, layer.intermediate.dense.weight.shape[0], device=x.device, dtype=x.dtype)
-        h = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, epilogue=EPI_GELU,
+        h = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, epilogue=EPI_GELU,
                     aux_out=pre)
         out = layer.output
         if ph > 0:
-            a2 = lin_fwd(h, out.dense.weight, out.dense.bias)
+            a2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8)
             K.dropout(a2, ph, seeds[2], out=a2)
             x2, mean2, rstd2, s2 = K.layernorm_fwd(a2.view(b, L, d), out.LayerNorm.weight.data, out.LayerNorm.bias.data,
                                                    layer.eps, add=x1, want_sum=True)
         else:
-            s2 = lin_fwd(h, out.dense.weight, out.dense.bias, residual=_rows(x1)).view(b, L, d)
+            s2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, residual=_rows(x1)).view(b, L, d)
             x2, mean2, rstd2, _ = K.layernorm_fwd(s2, out.LayerNorm.weight.data, out.LayerNorm.bias.data, layer.eps)
         ctx.save_for_backward(x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2)
         ctx.layer, ctx.drop = layer, (ph, pa, seeds)
@@ -475,20 +490,20 @@ class BertLayerFn(torch.autograd.Function):
                               out.LayerNorm.bias._g)
         g2 = _rows(ds2)                                   # gradient of the sum: the residual path takes it as is
         gd2 = K.dropout(g2, ph, seeds[2]) if ph > 0 else g2   # the dense path takes it through the dropout mask
-        dpre = lin_dx(gd2, out.dense.weight, epilogue=EPI_DGELU, aux=pre)
+        dpre = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, epilogue=EPI_DGELU, aux=pre)
         lin_dw(gd2, h, out.dense.weight, out.dense.bias)
-        dx1 = lin_dx(dpre, layer.intermediate.dense.weight, residual=g2)          # + residual path of s2 = .. + x1
+        dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, residual=g2)          # + residual path of s2 = .. + x1
         lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
         ds1 = K.layernorm_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                               ao.LayerNorm.bias._g)
         g1 = _rows(ds1)
         gd1 = K.dropout(g1, ph, seeds[1]) if ph > 0 else g1
-        do = lin_dx(gd1, ao.dense.weight).view(b, L, d)
+        do = lin_dx(gd1, ao.dense.weight, fp8=layer.fp8).view(b, L, d)
         lin_dw(gd1, _rows(o), ao.dense.weight, ao.dense.bias)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, layer.heads, kmask,
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], drop_p=pa, seed=seeds[0])
-        dx = lin_dx(_rows(dqkv), layer._qkv_w, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
+        dx = lin_dx(_rows(dqkv), layer._qkv_w, fp8=layer.fp8, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
         lin_dw(_rows(dqkv), _rows(x), layer._qkv_w, layer._qkv_b)
         for p in (out.LayerNorm.weight, out.LayerNorm.bias, ao.LayerNorm.weight, ao.LayerNorm.bias):
             _mark(p)

@@ -31,16 +31,54 @@ import torch.nn.functional as F
 # tests use it as the NOISE MODEL of the bf16 path: how far bf16 storage at those points moves each loss / gradient away
 # from the fp32 result is the yardstick the HIP bf16 path's own deviation is held against, tensor by tensor.
 _LOWP = False
+_FP8 = False
 
 
 class lowp:
+    """with lowp(): bf16 storage model.  with lowp(fp8=True): additionally the fp8 operand model of compute_dtype 'fp8' (BASELINE
+    configs[4]): the big Linears of the ViT blocks and BERT layers multiply per-tensor scaled OCP e4m3 copies of their input and
+    weight (power-of-two scale from the tensor's amax), and their dX product takes the incoming gradient in e5m2; weight gradients,
+    everything else as under lowp()."""
+
+    def __init__(self, fp8=False):
+        self.fp8 = fp8
+
     def __enter__(self):
-        global _LOWP
-        self.prev, _LOWP = _LOWP, True
+        global _LOWP, _FP8
+        self.prev, _LOWP, _FP8 = (_LOWP, _FP8), True, self.fp8
 
     def __exit__(self, *exc):
-        global _LOWP
-        _LOWP = self.prev
+        global _LOWP, _FP8
+        _LOWP, _FP8 = self.prev
+
+
+def _q8(t, dtype, fmax):
+    """fp8 copy of t as the product sees it: round(t * s) / s with s = 2^floor(log2(fmax / amax))."""
+    amax = float(t.detach().abs().max())
+    if amax == 0.0:
+        return t
+    sc = 2.0 ** math.floor(math.log2(fmax / amax))
+    return (t * sc).to(dtype).float() / sc
+
+
+class _Fp8Linear(torch.autograd.Function):
+    """y = q4(x) q4(w)^T + b;  dx = q5(dy) q4(w);  dw = dy^T x, db = colsum(dy) from the bf16 tensors (as the bf16 path)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        wr = w.bfloat16().float()
+        wq = _q8(wr, torch.float8_e4m3fn, 448.0)
+        ctx.save_for_backward(x, wq)
+        ctx.has_b = b is not None
+        y = F.linear(_q8(x, torch.float8_e4m3fn, 448.0), wq)
+        return y + b if b is not None else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wq = ctx.saved_tensors
+        dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
+        dx = (_q8(dy2, torch.float8_e5m2, 57344.0) @ wq).reshape(x.shape)
+        return dx, dy2.t() @ x2, (dy2.sum(0) if ctx.has_b else None)
 
 
 class _RoundAct(torch.autograd.Function):
@@ -75,9 +113,15 @@ def _w(w):
     return _RoundWeight.apply(w) if _LOWP else w
 
 
-def linear(x, w, b=None, keep_f32=False):
-    """F.linear; under lowp() on the weight's bf16 copy, result stored in bf16 unless keep_f32 (the heads feeding the losses)."""
-    y = F.linear(x, _w(w), b)
+def linear(x, w, b=None, keep_f32=False, fp8=False):
+    """F.linear; under lowp() on the weight's bf16 copy, result stored in bf16 unless keep_f32 (the heads feeding the losses).
+    fp8: an encoder-block Linear - under lowp(fp8=True) its product takes fp8 operands when the shape has an fp8 kernel
+    (rows >= 256, out >= 256 and % 32 == 0, in % 128 == 0: leccr_gemm's LECCR_FP8 rule)."""
+    rows = x.numel() // x.shape[-1]
+    if _LOWP and _FP8 and fp8 and rows >= 256 and w.shape[0] >= 256 and w.shape[0] % 32 == 0 and w.shape[1] % 128 == 0:
+        y = _Fp8Linear.apply(x, w, b)
+    else:
+        y = F.linear(x, _w(w), b)
     return y if keep_f32 else _r(y)
 
 
@@ -157,16 +201,20 @@ def attention_core(q, k, v, heads, key_padding_mask=None):
     return o.permute(0, 2, 1, 3).reshape(b, Lq, d)
 
 
-def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None, keep_f32=False):
+def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None, keep_f32=False, fp8=False):
     """nn.MultiheadAttention with packed in_proj ordered q,k,v (clip/model.py:175,187; attention.py:27,47).
     Batch-major in/out."""
     w, bias = sd[pre + 'in_proj_weight'], sd[pre + 'in_proj_bias']
     d = w.shape[1]
-    q = linear(query, w[:d], bias[:d])
-    k = linear(memory, w[d:2 * d], bias[d:2 * d])
-    v = linear(memory, w[2 * d:], bias[2 * d:])
+    if fp8 and query is memory:      # the ViT block's packed in_proj: one product, one weight scale (as the HIP path's packed GEMM)
+        qkv = linear(query, w, bias, fp8=True)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    else:
+        q = linear(query, w[:d], bias[:d])
+        k = linear(memory, w[d:2 * d], bias[d:2 * d])
+        v = linear(memory, w[2 * d:], bias[2 * d:])
     o = attention_core(q, k, v, heads, key_padding_mask)
-    return linear(o, sd[pre + 'out_proj.weight'], sd[pre + 'out_proj.bias'], keep_f32=keep_f32)
+    return linear(o, sd[pre + 'out_proj.weight'], sd[pre + 'out_proj.bias'], keep_f32=keep_f32, fp8=fp8)
 
 
 # --------------------------------------------------------------------------------------- CLIP ViT
@@ -191,10 +239,10 @@ def vit_trunk(sd, pre, image):
         bp = f'{pre}transformer.resblocks.{i}.'
         # ResidualAttentionBlock (clip/model.py:171-192): pre-LN attention + pre-LN QuickGELU MLP
         h = layer_norm(x, sd[bp + 'ln_1.weight'], sd[bp + 'ln_1.bias'], 1e-5)
-        x = _r(x + torch_mha(sd, bp + 'attn.', h, h, heads, keep_f32=True))      # residual added in the GEMM epilogue (f32)
+        x = _r(x + torch_mha(sd, bp + 'attn.', h, h, heads, keep_f32=True, fp8=True))      # residual added in the GEMM epilogue (f32)
         h = layer_norm(x, sd[bp + 'ln_2.weight'], sd[bp + 'ln_2.bias'], 1e-5)
-        h = _r(quick_gelu(linear(h, sd[bp + 'mlp.c_fc.weight'], sd[bp + 'mlp.c_fc.bias'], keep_f32=True)))
-        x = _r(x + linear(h, sd[bp + 'mlp.c_proj.weight'], sd[bp + 'mlp.c_proj.bias'], keep_f32=True))
+        h = _r(quick_gelu(linear(h, sd[bp + 'mlp.c_fc.weight'], sd[bp + 'mlp.c_fc.bias'], keep_f32=True, fp8=True)))
+        x = _r(x + linear(h, sd[bp + 'mlp.c_proj.weight'], sd[bp + 'mlp.c_proj.bias'], keep_f32=True, fp8=True))
         i += 1
     return x
 
@@ -222,15 +270,20 @@ def bert_forward(sd, pre, ids, mask, heads):
     i = 0
     while f'{pre}encoder.layer.{i}.attention.self.query.weight' in sd:
         lp = f'{pre}encoder.layer.{i}.'
-        q = linear(x, sd[lp + 'attention.self.query.weight'], sd[lp + 'attention.self.query.bias'])
-        k = linear(x, sd[lp + 'attention.self.key.weight'], sd[lp + 'attention.self.key.bias'])
-        v = linear(x, sd[lp + 'attention.self.value.weight'], sd[lp + 'attention.self.value.bias'])
+        if _LOWP and _FP8:      # the HIP path runs the three projections as one packed [3d, d] product: one weight scale
+            wqkv = torch.cat([sd[lp + f'attention.self.{n}.weight'] for n in ('query', 'key', 'value')], 0)
+            bqkv = torch.cat([sd[lp + f'attention.self.{n}.bias'] for n in ('query', 'key', 'value')], 0)
+            q, k, v = linear(x, wqkv, bqkv, fp8=True).split(x.shape[-1], -1)
+        else:
+            q = linear(x, sd[lp + 'attention.self.query.weight'], sd[lp + 'attention.self.query.bias'])
+            k = linear(x, sd[lp + 'attention.self.key.weight'], sd[lp + 'attention.self.key.bias'])
+            v = linear(x, sd[lp + 'attention.self.value.weight'], sd[lp + 'attention.self.value.bias'])
         a = attention_core(q, k, v, heads, kpm)
-        a = linear(a, sd[lp + 'attention.output.dense.weight'], sd[lp + 'attention.output.dense.bias'], keep_f32=True)
+        a = linear(a, sd[lp + 'attention.output.dense.weight'], sd[lp + 'attention.output.dense.bias'], keep_f32=True, fp8=True)
         x = layer_norm(_r(x + a), sd[lp + 'attention.output.LayerNorm.weight'],
                        sd[lp + 'attention.output.LayerNorm.bias'], 1e-12)
-        h = _r(gelu_erf(linear(x, sd[lp + 'intermediate.dense.weight'], sd[lp + 'intermediate.dense.bias'], keep_f32=True)))
-        h = linear(h, sd[lp + 'output.dense.weight'], sd[lp + 'output.dense.bias'], keep_f32=True)
+        h = _r(gelu_erf(linear(x, sd[lp + 'intermediate.dense.weight'], sd[lp + 'intermediate.dense.bias'], keep_f32=True, fp8=True)))
+        h = linear(h, sd[lp + 'output.dense.weight'], sd[lp + 'output.dense.bias'], keep_f32=True, fp8=True)
         x = layer_norm(_r(x + h), sd[lp + 'output.LayerNorm.weight'], sd[lp + 'output.LayerNorm.bias'], 1e-12)
         i += 1
     return x

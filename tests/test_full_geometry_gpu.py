@@ -134,8 +134,8 @@ def oracle_step(sd_src, batch, text_heads, lowp=False, temp=None):
             sd['temp'].fill_(temp)
     args = (sd, WL, batch['image'], batch['ids_s'], batch['mask_s'], batch['ids_t'], batch['mask_t'], batch['ids_c'],
             batch['mask_c'], batch['idx'], text_heads)
-    if lowp:
-        with O.lowp():
+    if lowp:        # True: bf16 storage model; 'fp8': + fp8 operands in the encoder blocks' Linears
+        with O.lowp(fp8=(lowp == 'fp8')):
             losses = O.retrieval_forward(*args)
             sum(losses).backward()
     else:
@@ -273,3 +273,45 @@ def test_config_e_geometry_vit_l14_xlmr_large_vs_oracle(dtype):
     else:
         bad = outside_noise_model(rows)
     assert not bad, (len(bad), bad[:8])
+
+
+def test_fp8_operand_path_vs_oracle_noise_model():
+    """compute_dtype 'fp8' (BASELINE configs[4]: "fp8 MFMA"): the ViT-L/14 + XLM-R-large shaped model (two layers each, b = 8 so
+    that every encoder Linear has >= 256 rows and takes the fp8 kernel) with e4m3 activations / weights in the forward products and
+    e5m2 gradients in the dX products.  Held against the fp32 oracle through the oracle's OWN fp8 operand model (oracle.lowp(fp8=
+    True): the same per-tensor power-of-two scaling and formats at the same Linears): losses within 3x what that model moves them,
+    every parameter gradient within 3x its noise."""
+    from leccr_amd import _lib
+    from leccr_amd.models import RetrievalModel
+    from leccr_amd.synthetic import MULTI30K_CFG, make_batch
+    torch.manual_seed(17)
+    model = RetrievalModel(dict(MULTI30K_CFG, clip_geometry=L14_GEOMETRY, text_config=dict(XLMR_LARGE_2L, vocab_size=30000),
+                                compute_dtype='fp8', clip_text_tower=False))
+    model.init_caption_encoder()
+    seeded_fill_(model.named_parameters(), 93)
+    model = model.to(DEV).eval()
+    m = make_batch(8, vocab=30000)
+    batch = dict(image=m['image'], ids_s=m['text'][0].input_ids, mask_s=m['text'][0].attention_mask, ids_t=m['text'][1].input_ids,
+                 mask_t=m['text'][1].attention_mask, ids_c=m['captions'].input_ids, mask_c=m['captions'].attention_mask, idx=m['idx'])
+    torch.set_num_threads(16)
+    ref_losses, sd = oracle_step(model.state_dict(), batch, 16)
+    noise_losses, sd_noise = oracle_step(model.state_dict(), batch, 16, lowp='fp8')
+    losses = _forward(model, batch)
+    # the fp8 kernel really ran: every encoder Linear's activation site was used, and the last product of the text tower was fp8
+    blk = model.clip_encoder.visual.transformer.resblocks[0]
+    lay = model.text_encoder.encoder.layer[1]
+    assert model.fp8_sites.n == 3 * (2 * 4 + 2 * 4)
+    assert all(h._xsite.primed for h in (blk.attn.in_proj_weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight, lay._qkv_w, lay.output.dense.weight))
+    got = [float(l) for l in losses]
+    for a, r, nz in zip(got, ref_losses, noise_losses):
+        assert abs(a - r) <= 3 * abs(nz - r) + 1e-2 * max(1.0, abs(r)), (got, ref_losses, noise_losses)
+    model.arena.zero_grad()
+    sum(losses).backward()
+    assert all(h._gsite.primed for h in (blk.attn.in_proj_weight, blk.mlp.c_proj.weight, lay._qkv_w, lay.intermediate.dense.weight))
+    rows = grad_rows(model, sd, sd_noise)
+    bad = outside_noise_model(rows)
+    assert len(rows) > 150 and not bad, (len(bad), bad[:8])
+    # a second step re-uses the delayed scales (update at the start of forward) and stays finite and close
+    losses2 = _forward(model, batch)
+    for a, b_ in zip([float(l) for l in losses2], got):
+        assert abs(a - b_) <= 2e-2 * max(1.0, abs(b_)), (got, [float(l) for l in losses2])
