@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+MFMA_FP8_PEAK_TFLOPS = 5000.0       # dense fp8 MFMA peak (block-scaled f8f6f4 form), same table
 HBM_PEAK_TBS = 8.0                  # HBM3E, same guide
 F_PAIR_GFLOP = {('image', 'ViT-B/16', 'mbert'): 389.9,      # algorithmic FLOPs per pair per train step
                 ('video_vit', 'ViT-B/16', 'mbert'): 2718.0,  # config D: 8 x B/16 frames + mBERT
@@ -351,6 +352,8 @@ def _main(args, real_stdout):
         union_ms, union_fl = busy.value, gwork.value
         gemm_ms, gemm_fl, gemm_n = leg_ms[0] + leg_ms[1], leg_work[0] + leg_work[1], leg_n[0] + leg_n[1]
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        # --dtype fp8: the GEMM family mixes fp8 (forward, dX) and bf16 (dW, heads) launches; it is priced against the fp8 peak
+        peak = MFMA_FP8_PEAK_TFLOPS if args.dtype == 'fp8' else MFMA_BF16_PEAK_TFLOPS
         traffic, traffic_src = None, None
         tj = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_gemm256_hbm_traffic.json') for r in (2, 1))
                    if os.path.exists(p)), '')
@@ -384,8 +387,8 @@ def _main(args, real_stdout):
                        'world': world, 'backend': backend if world > 1 else None, 'rccl_version': rccl,
                        'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'LECCR_RCCL_CUS': rccl_cus()},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm256_kernel (bf16 256x256x64 MFMA GEMM: NT forward/dX + TN weight-gradient instantiations)',
-                         'achieved': round(achieved, 1), 'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': traffic,
+                         'achieved': round(achieved, 1), 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': traffic_src,
                          'launches_per_step': gemm_n // max(1, leg),
                          'avg_launch_us': round(gemm_ms * 1e3 / max(1, gemm_n), 2),
