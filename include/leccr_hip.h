@@ -106,6 +106,14 @@ typedef struct leccr_gemm_params {
                                     the product (an all-ones B fragment), other paths run leccr_colsum over A */
     const float* alpha_dev[2];   /* optional device scalars multiplied into alpha when the kernel starts (fp8 operands: the two
                                     inverse quantisation scales live on the device, leccr_fp8_* below; no host read) */
+    void* c8;                    /* optional fp8 copy of the C written, for the NEXT product that consumes it (fp8 operand kernels
+                                    with an activation / d-activation epilogue only): c8[m,n] = fp8(clamp(C[m,n] * c8_site.scale)),
+                                    row stride ldc8 bytes, format c8_fmt (0 e4m3, 1 e5m2); c8_site.amax accumulates max |C| - the
+                                    same contract as leccr_fp8_quantize, without its pass over C */
+    int64_t ldc8;
+    float* c8_site;
+    int32_t c8_fmt;
+    int32_t reserved2;
 } leccr_gemm_params;
 
 int leccr_gemm(const leccr_gemm_params* p, void* stream);

@@ -351,6 +351,7 @@ bool gemm256_wanted(const leccr_gemm_params& p);
 bool gemm256_legal(const leccr_gemm_params& p);
 bool gemm256_fuses_colsum(const leccr_gemm_params& p);
 bool gemm256w4_fp8_legal(const leccr_gemm_params& p);
+bool gemm256w4_c8_legal(const leccr_gemm_params& p);
 bool gemm256_fuses_asum(const leccr_gemm_params& p);
 int gemm256_launch(const leccr_gemm_params& p, hipStream_t st);
 void gemm256_set_max_blocks(int n, int64_t launches);
@@ -430,6 +431,7 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
         LECCR_REQUIRE(gemm256w4_fp8_legal(p), LECCR_EINVAL, "gemm: fp8 operands need trans_a = trans_b = 0, a bf16 C, M, N >= 256, K %% 128 == 0, "
                       "16-byte aligned rows and a compiled epilogue");
         LECCR_REQUIRE(!p.colsum && !p.asum, LECCR_EINVAL, "gemm: fp8 operands with colsum / asum");
+        LECCR_REQUIRE(gemm256w4_c8_legal(p), LECCR_EINVAL, "gemm: c8 needs a site, 8-byte aligned rows and an (d-)activation epilogue of matching format");
         if (p.M == 0 || p.N == 0) return LECCR_OK;
         hipStream_t st8 = as_stream(stream);
         ProfScope prof(PROF_GEMM_NT, 2.0 * (double)p.M * (double)p.N * (double)p.K, st8);
@@ -437,6 +439,7 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
         return gemm256w4_launch(p, st8);
     }
     LECCR_REQUIRE(p.ab_dtype == LECCR_F32 || p.ab_dtype == LECCR_BF16, LECCR_EINVAL, "gemm: bad ab_dtype");
+    LECCR_REQUIRE(p.c8 == nullptr, LECCR_EINVAL, "gemm: c8 (fused fp8 copy of C) exists for fp8 operands only");
     LECCR_REQUIRE(p.c_dtype == LECCR_F32 || p.c_dtype == LECCR_BF16, LECCR_EINVAL, "gemm: bad c_dtype");
     LECCR_REQUIRE(!(p.accumulate && p.c_dtype != LECCR_F32), LECCR_EINVAL, "gemm: accumulate needs an f32 C");
     LECCR_REQUIRE(p.lda >= (p.trans_a ? p.M : p.K) && p.ldb >= (p.trans_b ? p.N : p.K) && p.ldc >= p.N, LECCR_EINVAL,

@@ -37,6 +37,8 @@ constexpr int F_RES = 2, F_AUXOUT = 4;
 // 128 fp8 = the same 128-byte LDS rows as 64 bf16, so staging, swizzle and fragment read addresses are byte-identical to the bf16
 // kernel (the launcher passes K / 2, lda / 2, ldb / 2 in bf16 units); only the MFMA differs - see the K loop.
 constexpr int F_FP8 = 32, F_BF8A = 64;
+// F_Q8: additionally write an fp8 copy of C for the product that consumes it (leccr_gemm_params.c8): saves that operand's quantise pass
+constexpr int F_Q8 = 128, F_Q8_BF8 = 256;       // F_Q8_BF8: the copy is e5m2 (a gradient), else e4m3
 
 struct Args {
     const bf16_t* A;
@@ -52,6 +54,9 @@ struct Args {
     float alpha;
     int tiles_m, tiles_n, nkt, n_items;
     const float* alpha_dev[2];           // device scalars folded into alpha at kernel start (fp8 inverse scales), or null
+    uint8_t* c8;                         // F_Q8: fp8 copy of C (row stride ldc8), quantised under c8_site = {amax, scale, 1/scale, fmt}
+    int64_t ldc8;
+    float* c8_site;
 };
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -242,6 +247,8 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
+    [[maybe_unused]] float q8_scale = 1.f, q8_amax = 0.f;
+    if constexpr ((FLAGS & F_Q8) != 0) q8_scale = a.c8_site[1];
     int t = 0;
     for (int j = 0; j < n_mine; ++j) {
         f32x16 acc[16];                      // [ni * 4 + mi]
@@ -406,6 +413,25 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { ov[e] = (bf16_t)v0[e]; ov[4 + e] = (bf16_t)v1[e]; }
                             if (ok) *reinterpret_cast<bf16x8*>(a.C + off) = ov;
+                            if constexpr ((FLAGS & F_Q8) != 0) {
+                                constexpr float FMAX = (FLAGS & F_Q8_BF8) != 0 ? 57344.f : 448.f;
+                                float q[8];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    if (ok) q8_amax = fmaxf(q8_amax, fmaxf(fabsf(v0[e]), fabsf(v1[e])));
+                                    q[e] = fminf(fmaxf(v0[e] * q8_scale, -FMAX), FMAX);
+                                    q[4 + e] = fminf(fmaxf(v1[e] * q8_scale, -FMAX), FMAX);
+                                }
+                                int w0 = 0, w1 = 0;
+                                if constexpr ((FLAGS & F_Q8_BF8) != 0) {
+                                    w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w0, true);
+                                    w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_bf8_f32(q[6], q[7], w1, true);
+                                } else {
+                                    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+                                    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+                                }
+                                if (ok) *reinterpret_cast<int2*>(a.c8 + m * a.ldc8 + ncol + 8 * h8) = int2{w0, w1};
+                            }
                         }
                     }
                 }
@@ -421,6 +447,13 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             cur.kt = 0;
             decode(a, first_item, stride, cur);
         }
+    }
+    if constexpr ((FLAGS & F_Q8) != 0) {               // one conditional atomic per wave and launch (see fp8.hip: block_amax)
+        float m = q8_amax;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+        if (lane == 0 && m > __builtin_nontemporal_load(a.c8_site))
+            atomicMax(reinterpret_cast<unsigned int*>(a.c8_site), __float_as_uint(m));
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail prefetches still target this block's LDS
 }
@@ -455,6 +488,15 @@ bool gemm256w4_fp8_legal(const leccr_gemm_params& p) {
            ((p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU) && f == 0);
 }
 
+// the fused fp8 copy of C: activation epilogues of a forward product (e4m3 copy) or derivative epilogues of a dX product (e5m2)
+bool gemm256w4_c8_legal(const leccr_gemm_params& p) {
+    if (!p.c8) return true;
+    if (!p.c8_site || (p.ldc8 & 7) || ((uintptr_t)p.c8 & 7) || p.ldc8 < p.N) return false;
+    if (p.ab_dtype == LECCR_FP8) return (p.epilogue == LECCR_EPI_QUICKGELU || p.epilogue == LECCR_EPI_GELU) && p.c8_fmt == 0;
+    if (p.ab_dtype == LECCR_FP8_BF8A) return (p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU) && p.c8_fmt == 1;
+    return false;
+}
+
 bool gemm256w4_legal(const leccr_gemm_params& p) {
     if (p.trans_a != 0 || p.trans_b != 0 || p.c_dtype != LECCR_BF16 || p.ab_dtype != LECCR_BF16 || p.accumulate) return false;
     if (p.M < 256 || p.N < 256 || (p.N & 31) || (p.ldc & 7) || (p.ldr & 7) || (p.ldaux & 7) || (p.K % g4::BK)) return false;
@@ -487,6 +529,14 @@ int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st) {
         // the bf16 problem with half the columns: byte-identical staging (see F_FP8)
         a.K = p.K / 2; a.lda = p.lda / 2; a.ldb = p.ldb / 2;
         a.nkt = (int)(a.K / BK);
+        a.c8 = (uint8_t*)p.c8; a.ldc8 = p.ldc8; a.c8_site = p.c8_site;
+        if (p.c8) {     // the C written is also the next product's fp8 operand: activation output (e4m3) / its gradient (e5m2)
+            if (p.ab_dtype == LECCR_FP8 && p.epilogue == LECCR_EPI_QUICKGELU) launch_inst<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st);
+            else if (p.ab_dtype == LECCR_FP8) launch_inst<LECCR_EPI_GELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st);
+            else if (p.epilogue == LECCR_EPI_DQUICKGELU) launch_inst<LECCR_EPI_DQUICKGELU, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st);
+            else launch_inst<LECCR_EPI_DGELU, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st);
+            return check_launch("gemm256w4 fp8 q8");
+        }
         if (p.ab_dtype == LECCR_FP8) {
             if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_inst<LECCR_EPI_NONE, F_RES | F_FP8>(a, grid, st);
             else if (p.epilogue == LECCR_EPI_NONE) launch_inst<LECCR_EPI_NONE, F_FP8>(a, grid, st);

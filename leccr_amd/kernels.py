@@ -21,7 +21,7 @@ def _rows2d(t):
 
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
-         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None):
+         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None, c8=None):
     """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major."""
     assert a.dim() == 2 and b.dim() == 2 and (a.dtype == b.dtype or a.dtype == torch.float8_e5m2)
     assert a.stride(1) == 1 and b.stride(1) == 1
@@ -65,6 +65,10 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     if asum is not None:        # [M] f32 += alpha * column sums of the stored [K, M] A over K (the bias gradient beside a dW product)
         assert trans_a and asum.dtype == torch.float32 and asum.numel() == M and asum.is_contiguous()
     p.asum = ptr(asum)
+    if c8 is not None:          # (fp8 tensor [M, N], Fp8Site): the fused fp8 copy of C for the product that consumes it
+        t8, site8 = c8
+        assert t8.shape == (M, N) and t8.stride(1) == 1 and t8.element_size() == 1
+        p.c8, p.ldc8, p.c8_site, p.c8_fmt = ptr(t8), t8.stride(0), ptr(site8.row), site8.fmt
     check(lib().leccr_gemm(C.byref(p), stream()), 'leccr_gemm')
     return out
 
@@ -389,6 +393,7 @@ class Fp8Site:
     def __init__(self, row, fmt):
         self.row, self.fmt, self.primed = row, fmt, False
         self.inv_scale = row[2:3]                                    # device scalar handed to leccr_gemm (alpha_dev)
+        self.torch_dtype = torch.float8_e4m3fn if fmt == Fp8Sites.E4M3 else torch.float8_e5m2
 
     def quantize(self, x, out=None):
         """x [rows, cols] (bf16 or f32, unit inner stride) -> its fp8 copy under this site's scale.  The first use scales from the

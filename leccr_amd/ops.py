@@ -58,31 +58,49 @@ def _bias(b):
     return None if b is None else b.data.reshape(-1)
 
 
+def _site(w, name):
+    """The quantisation site `name` of a weight holder, or None outside fp8 mode."""
+    return getattr(w, name, None)
+
+
 def _fp8_ok(x2, w8):
     """The fp8 product exists for the large Linears only (leccr_gemm: M, N >= 256, whole 128-element K-tiles, N % 32 == 0)."""
     return (x2.shape[0] >= 256 and w8.shape[0] >= 256 and w8.shape[0] % 32 == 0 and w8.shape[1] % 128 == 0 and x2.stride(1) == 1
             and x2.stride(0) % 16 == 0)
 
 
-def lin_fwd(x2, w, b=None, fp8=False, **kw):
+def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, **kw):
     """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free).
     fp8 (compute_dtype 'fp8', the encoder blocks' Linears): x2 is quantised to e4m3 under the Linear's activation site and
     multiplied with the weight's e4m3 copy on the scaled-MFMA kernel; the saved-for-backward tensors stay bf16."""
+    x8: x2's fp8 copy when the producer already wrote it (c8_site).  c8_site: the activation site of the Linear that CONSUMES this
+    output: once that site has a scale, the epilogue also writes the output's fp8 copy under it (no separate quantise pass over
+    it) and (y, y8) is returned; (y, None) otherwise."""
     if fp8 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8):
-        x8 = w._xsite.quantize(x2)
-        return K.gemm(x8, w._q8, bias=_bias(b), alpha_dev=(w._xsite.inv_scale, w._wsite.inv_scale), **kw)
-    return K.gemm(x2, w._lp, bias=_bias(b), **kw)
+        if x8 is None:
+            x8 = w._xsite.quantize(x2)
+        c8 = None
+        if c8_site is not None and c8_site.primed:
+            c8 = (torch.empty(x2.shape[0], w._q8.shape[0], device=x2.device, dtype=c8_site.torch_dtype), c8_site)
+        y = K.gemm(x8, w._q8, bias=_bias(b), alpha_dev=(w._xsite.inv_scale, w._wsite.inv_scale), c8=c8, **kw)
+        return (y, c8[0] if c8 is not None else None) if c8_site is not None else y
+    y = K.gemm(x2, w._lp, bias=_bias(b), **kw)
+    return (y, None) if c8_site is not None else y
 
 
-def lin_dx(dy2, w, fp8=False, **kw):
+def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, **kw):
     """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N].
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
     if fp8 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t):
-        g8 = w._gsite.quantize(dy2)
-        return K.gemm(g8, w._q8t, alpha_dev=(w._gsite.inv_scale, w._wsite.inv_scale), **kw)
-    if w._lpt is not None:
-        return K.gemm(dy2, w._lpt, **kw)
-    return K.gemm(dy2, w._lp, trans_b=True, **kw)
+        if g8 is None:
+            g8 = w._gsite.quantize(dy2)
+        c8 = None
+        if c8_site is not None and c8_site.primed:
+            c8 = (torch.empty(dy2.shape[0], w._q8t.shape[0], device=dy2.device, dtype=c8_site.torch_dtype), c8_site)
+        y = K.gemm(g8, w._q8t, alpha_dev=(w._gsite.inv_scale, w._wsite.inv_scale), c8=c8, **kw)
+        return (y, c8[0] if c8 is not None else None) if c8_site is not None else y
+    y = K.gemm(dy2, w._lpt, **kw) if w._lpt is not None else K.gemm(dy2, w._lp, trans_b=True, **kw)
+    return (y, None) if c8_site is not None else y
 
 
 # Weight-gradient launches (dW GEMM + bias column sums) run on a second HIP stream beside the dX chain of the backward pass:
@@ -340,8 +358,10 @@ class ViTBlockFn(torch.autograd.Function):
         x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, residual=_rows(x)).view(b, N, d)
         h2, mean2, rstd2, _ = K.layernorm_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5)
         pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
-        act = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, epilogue=EPI_QUICKGELU, aux_out=pre)
-        x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, residual=_rows(x1)).view(b, N, d)
+        # (fp8: the activation's e4m3 copy for c_proj comes out of c_fc's epilogue - no quantise pass over the 4d-wide tensor)
+        act, act8 = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, epilogue=EPI_QUICKGELU, aux_out=pre,
+                            c8_site=_site(blk.mlp.c_proj.weight, '_xsite'))
+        x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
         ctx.save_for_backward(x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act)
         ctx.blk = blk
         return x2
@@ -354,12 +374,12 @@ class ViTBlockFn(torch.autograd.Function):
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
-        dpre = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, epilogue=EPI_DQUICKGELU, aux=pre)
+        dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, epilogue=EPI_DQUICKGELU, aux=pre, c8_site=_site(blk.mlp.c_fc.weight, '_gsite'))
         # bias gradients of c_proj / out_proj = column sums of dx2 / dx1.  They ride the weight-gradient stream as 40 us HBM-bound
         # passes beside the dX chain: folded into the LayerNorm backward launches (whose `dres` operands those tensors are) they
         # cost that kernel a fifth of its occupancy - 253 us against 201 us per launch on the main chain
         lin_dw(g2, act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
-        dh2 = lin_dx(dpre, blk.mlp.c_fc.weight, fp8=blk.fp8)
+        dh2 = lin_dx(dpre, blk.mlp.c_fc.weight, fp8=blk.fp8, g8=dpre8)
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
         lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
@@ -464,16 +484,16 @@ class BertLayerFn(torch.autograd.Function):
             s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8, residual=_rows(x)).view(b, L, d)
             x1, mean1, rstd1, _ = K.layernorm_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps)
         pre = torch.empty(b * L, layer.intermediate.dense.weight.shape[0], device=x.device, dtype=x.dtype)
-        h = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, epilogue=EPI_GELU,
-                    aux_out=pre)
+        h, h8 = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, epilogue=EPI_GELU,
+                        aux_out=pre, c8_site=_site(layer.output.dense.weight, '_xsite'))
         out = layer.output
         if ph > 0:
-            a2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8)
+            a2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8)
             K.dropout(a2, ph, seeds[2], out=a2)
             x2, mean2, rstd2, s2 = K.layernorm_fwd(a2.view(b, L, d), out.LayerNorm.weight.data, out.LayerNorm.bias.data,
                                                    layer.eps, add=x1, want_sum=True)
         else:
-            s2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, residual=_rows(x1)).view(b, L, d)
+            s2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8, residual=_rows(x1)).view(b, L, d)
             x2, mean2, rstd2, _ = K.layernorm_fwd(s2, out.LayerNorm.weight.data, out.LayerNorm.bias.data, layer.eps)
         ctx.save_for_backward(x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2)
         ctx.layer, ctx.drop = layer, (ph, pa, seeds)
@@ -490,9 +510,9 @@ class BertLayerFn(torch.autograd.Function):
                               out.LayerNorm.bias._g)
         g2 = _rows(ds2)                                   # gradient of the sum: the residual path takes it as is
         gd2 = K.dropout(g2, ph, seeds[2]) if ph > 0 else g2   # the dense path takes it through the dropout mask
-        dpre = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, epilogue=EPI_DGELU, aux=pre)
+        dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, epilogue=EPI_DGELU, aux=pre, c8_site=_site(layer.intermediate.dense.weight, '_gsite'))
         lin_dw(gd2, h, out.dense.weight, out.dense.bias)
-        dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, residual=g2)          # + residual path of s2 = .. + x1
+        dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
         lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
         ds1 = K.layernorm_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                               ao.LayerNorm.bias._g)

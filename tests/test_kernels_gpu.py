@@ -779,3 +779,36 @@ def test_gemm_fp8_rejects_what_it_does_not_implement(K):
         K.gemm(a8, b8[:128])
     with pytest.raises((RuntimeError, AssertionError)):     # weight-gradient layout: not an fp8 product here
         K.gemm(a8, b8, trans_a=True, trans_b=True, out=torch.zeros(256, 256, device=DEV), accumulate=True)
+
+
+@pytest.mark.parametrize('grad', [False, True])
+def test_gemm_fp8_fused_copy_of_the_output(K, grad):
+    """leccr_gemm_params.c8: the (d-)activation epilogue of an fp8 product also writes the fp8 copy of its output under the
+    CONSUMER's site - bytes equal to quantising the f32 epilogue values, amax recorded - so the consumer's quantise pass over the
+    4d-wide tensor disappears (forward: QuickGELU output -> e4m3 for c_proj; backward: its gradient -> e5m2 for c_fc's dX)."""
+    M, N, K_ = 1460, 4096, 1024
+    sites = K.Fp8Sites(DEV, 8)
+    sa, sb, sc = sites.new(1 if grad else 0), sites.new(0), sites.new(1 if grad else 0)
+    a = _rand((M, K_), torch.bfloat16, 540, 1e-2 if grad else 1.0).to(DEV)
+    b = _rand((N, K_), torch.bfloat16, 541, 0.05).to(DEV)
+    a8, b8 = sa.quantize(a), sb.quantize(b)
+    x = _rand((M, N), torch.bfloat16, 542).to(DEV)
+    if grad:
+        kw = dict(epilogue=3, aux=x)
+    else:
+        kw = dict(epilogue=1, aux_out=torch.empty(M, N, dtype=torch.bfloat16, device=DEV))
+    plain = K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), **kw)
+    sc.quantize(plain)                                   # primes the consumer's site from the tensor itself
+    scale = float(sc.row[1])
+    sites.update()
+    y8 = torch.empty(M, N, device=DEV, dtype=sc.torch_dtype)
+    out = K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), c8=(y8, sc), **kw)
+    assert torch.equal(out, plain)
+    # the copy is quantised from the f32 epilogue values (before their bf16 rounding): within one fp8 step of quantising `out`
+    want = (out.float() * scale).to(sc.torch_dtype).float()
+    got = y8.float()
+    step = torch.maximum(want.abs(), got.abs()) * (0.26 if grad else 0.13) + 2.0 ** (-16 if grad else -9)
+    assert bool(((got - want).abs() <= step).all())
+    assert float((got - want).abs().gt(0).float().mean()) < 0.2       # and mostly identical
+    amax = float(out.float().abs().max())
+    assert abs(float(sc.row[0]) - amax) <= 8e-3 * amax                 # max |C| of the f32 values, recorded for the next scale
