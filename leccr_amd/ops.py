@@ -72,7 +72,7 @@ def _fp8_ok(x2, w8):
 def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, **kw):
     """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free).
     fp8 (compute_dtype 'fp8', the encoder blocks' Linears): x2 is quantised to e4m3 under the Linear's activation site and
-    multiplied with the weight's e4m3 copy on the scaled-MFMA kernel; the saved-for-backward tensors stay bf16."""
+    multiplied with the weight's e4m3 copy on the scaled-MFMA kernel; the saved-for-backward tensors stay bf16.
     x8: x2's fp8 copy when the producer already wrote it (c8_site).  c8_site: the activation site of the Linear that CONSUMES this
     output: once that site has a scale, the epilogue also writes the output's fp8 copy under it (no separate quantise pass over
     it) and (y, y8) is returned; (y, None) otherwise."""
