@@ -69,13 +69,13 @@ def _fp8_ok(x2, w8):
             and x2.stride(0) % 16 == 0)
 
 
-def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, **kw):
+def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, **kw):
     """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free).
     fp8 (compute_dtype 'fp8', the encoder blocks' Linears): x2 is quantised to e4m3 under the Linear's activation site and
     multiplied with the weight's e4m3 copy on the scaled-MFMA kernel; the saved-for-backward tensors stay bf16.
     x8: x2's fp8 copy when the producer already wrote it (c8_site).  c8_site: the activation site of the Linear that CONSUMES this
     output: once that site has a scale, the epilogue also writes the output's fp8 copy under it (no separate quantise pass over
-    it) and (y, y8) is returned; (y, None) otherwise."""
+    it).  want8: return (y, y8 or None) instead of y."""
     if fp8 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8):
         if x8 is None:
             x8 = w._xsite.quantize(x2)
@@ -83,12 +83,12 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, **kw):
         if c8_site is not None and c8_site.primed:
             c8 = (torch.empty(x2.shape[0], w._q8.shape[0], device=x2.device, dtype=c8_site.torch_dtype), c8_site)
         y = K.gemm(x8, w._q8, bias=_bias(b), alpha_dev=(w._xsite.inv_scale, w._wsite.inv_scale), c8=c8, **kw)
-        return (y, c8[0] if c8 is not None else None) if c8_site is not None else y
+        return (y, c8[0] if c8 is not None else None) if want8 else y
     y = K.gemm(x2, w._lp, bias=_bias(b), **kw)
-    return (y, None) if c8_site is not None else y
+    return (y, None) if want8 else y
 
 
-def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, **kw):
+def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, **kw):
     """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N].
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
     if fp8 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t):
@@ -98,9 +98,9 @@ def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, **kw):
         if c8_site is not None and c8_site.primed:
             c8 = (torch.empty(dy2.shape[0], w._q8t.shape[0], device=dy2.device, dtype=c8_site.torch_dtype), c8_site)
         y = K.gemm(g8, w._q8t, alpha_dev=(w._gsite.inv_scale, w._wsite.inv_scale), c8=c8, **kw)
-        return (y, c8[0] if c8 is not None else None) if c8_site is not None else y
+        return (y, c8[0] if c8 is not None else None) if want8 else y
     y = K.gemm(dy2, w._lpt, **kw) if w._lpt is not None else K.gemm(dy2, w._lp, trans_b=True, **kw)
-    return (y, None) if c8_site is not None else y
+    return (y, None) if want8 else y
 
 
 # Weight-gradient launches (dW GEMM + bias column sums) run on a second HIP stream beside the dX chain of the backward pass:
@@ -360,7 +360,7 @@ class ViTBlockFn(torch.autograd.Function):
         pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
         # (fp8: the activation's e4m3 copy for c_proj comes out of c_fc's epilogue - no quantise pass over the 4d-wide tensor)
         act, act8 = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, epilogue=EPI_QUICKGELU, aux_out=pre,
-                            c8_site=_site(blk.mlp.c_proj.weight, '_xsite'))
+                            c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True)
         x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
         ctx.save_for_backward(x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act)
         ctx.blk = blk
@@ -374,7 +374,7 @@ class ViTBlockFn(torch.autograd.Function):
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
-        dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, epilogue=EPI_DQUICKGELU, aux=pre, c8_site=_site(blk.mlp.c_fc.weight, '_gsite'))
+        dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, epilogue=EPI_DQUICKGELU, aux=pre, c8_site=_site(blk.mlp.c_fc.weight, '_gsite'), want8=True)
         # bias gradients of c_proj / out_proj = column sums of dx2 / dx1.  They ride the weight-gradient stream as 40 us HBM-bound
         # passes beside the dX chain: folded into the LayerNorm backward launches (whose `dres` operands those tensors are) they
         # cost that kernel a fifth of its occupancy - 253 us against 201 us per launch on the main chain
@@ -485,7 +485,7 @@ class BertLayerFn(torch.autograd.Function):
             x1, mean1, rstd1, _ = K.layernorm_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps)
         pre = torch.empty(b * L, layer.intermediate.dense.weight.shape[0], device=x.device, dtype=x.dtype)
         h, h8 = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, epilogue=EPI_GELU,
-                        aux_out=pre, c8_site=_site(layer.output.dense.weight, '_xsite'))
+                        aux_out=pre, c8_site=_site(layer.output.dense.weight, '_xsite'), want8=True)
         out = layer.output
         if ph > 0:
             a2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8)
@@ -510,7 +510,7 @@ class BertLayerFn(torch.autograd.Function):
                               out.LayerNorm.bias._g)
         g2 = _rows(ds2)                                   # gradient of the sum: the residual path takes it as is
         gd2 = K.dropout(g2, ph, seeds[2]) if ph > 0 else g2   # the dense path takes it through the dropout mask
-        dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, epilogue=EPI_DGELU, aux=pre, c8_site=_site(layer.intermediate.dense.weight, '_gsite'))
+        dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, epilogue=EPI_DGELU, aux=pre, c8_site=_site(layer.intermediate.dense.weight, '_gsite'), want8=True)
         lin_dw(gd2, h, out.dense.weight, out.dense.bias)
         dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
         lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
