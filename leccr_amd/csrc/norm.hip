@@ -2,7 +2,6 @@
 // All HBM-bound: one wave64 per row (bf16: one or two rows with 16-byte accesses where the width allows), statistics in f32,
 // wave-shuffle reductions (no LDS for the row statistics).
 #include "common.h"
-#include <stdlib.h>
 
 namespace leccr {
 
@@ -258,102 +257,6 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
     }
 }
 
-// Backward with 16-byte accesses (round 2).  A wave owns a row; lane l holds chunk l of it (8 bf16) and, for rows wider than 512,
-// chunk 64 + l - so a lane keeps the SAME columns for every row and its dgamma / dbeta partials are 2 x 8 x 2 registers (the
-// forward kernel's two-rows-in-three-slots mapping gives a lane different columns per slot: three sets of partials, 150-216
-// registers, measured slower than the 8-byte kernel).  For d = 768 the second slot is half empty (lanes 32-63 idle in it):
-// that costs VALU slots, not bandwidth.  dy and x stay packed (bf16) between the two passes over the row and are converted
-// twice, gamma is re-read per row (L1): ~80 registers, 6 waves per SIMD in one round of workgroups.
-template <int NS>
-__global__ __launch_bounds__(256, NS == 1 ? 6 : 4) void layernorm_bwd16_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xin,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                                 const float* __restrict__ rstd, const bf16_t* __restrict__ dres,
-                                                                 bf16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                                                 float* __restrict__ dbeta, int64_t rows, int d) {
-    __shared__ float red[NS * 64 * 8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int C = d >> 3;
-    bool on[NS];
-    int col[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        on[s] = 64 * s + lane < C;
-        col[s] = (64 * s + lane) * 8;
-    }
-    float dg[NS][8], db[NS][8];
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dg[s][j] = db[s][j] = 0.f;
-    const float inv_d = 1.f / d;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        bf16x8 dyp[NS], xp[NS];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (on[s]) {
-                dyp[s] = *reinterpret_cast<const bf16x8*>(dy + row * d + col[s]);
-                xp[s] = *reinterpret_cast<const bf16x8*>(xin + row * d + col[s]);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (on[s]) {
-                const f32x4 g0 = load4(gamma + col[s]), g1 = load4(gamma + col[s] + 4);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float dyv = (float)dyp[s][j], xh = ((float)xp[s][j] - mu) * rs, gy = dyv * (j < 4 ? g0[j] : g1[j - 4]);
-                    dg[s][j] += dyv * xh;
-                    db[s][j] += dyv;
-                    s1 += gy;
-                    s2 += gy * xh;
-                }
-            }
-        }
-        s1 = wave_sum(s1) * inv_d;
-        s2 = wave_sum(s2) * inv_d;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (on[s]) {
-                const f32x4 g0 = load4(gamma + col[s]), g1 = load4(gamma + col[s] + 4);
-                float o[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = ((float)xp[s][j] - mu) * rs, gy = (float)dyp[s][j] * (j < 4 ? g0[j] : g1[j - 4]);
-                    o[j] = (gy - s1 - xh * s2) * rs;
-                }
-                if (dres) {
-                    float r[8];
-                    load8f(dres + row * d + col[s], r);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] += r[j];
-                }
-                store8f(dx + row * d + col[s], o);
-            }
-        }
-    }
-    // the 4 waves' partials through LDS (one wave at a time), then one f32 atomic per column
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int w = 0; w < 4; ++w) {
-            __syncthreads();
-            if (wave == w) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float val = pass == 0 ? dg[s][j] : db[s][j];
-                        float* slot = red + (64 * s + lane) * 8 + j;
-                        *slot = w == 0 ? val : *slot + val;
-                    }
-            }
-        }
-        __syncthreads();
-        float* out = pass == 0 ? dgamma : dbeta;
-        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(out + c, red[c]);
-    }
-}
-
 // (R, NS) of the 16-byte forward kernel for a row of d bf16, or false: the 4-element kernel takes the shape.  (A backward with
 // the same mapping needs 150-216 registers for its three sets of column partials and measured slower than the 4-element one.)
 static bool rows16_shape(int64_t d, int* R, int* NS) {
@@ -491,22 +394,6 @@ template <typename T>
 static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, const float* mean, const float* rstd,
                            const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of,
                            int64_t rows, int64_t d, hipStream_t st) {
-    if constexpr (sizeof(T) == 2) {
-        // bf16, no fused column sums, rows of <= 1024 elements in 8-element chunks: the 16-byte kernel (LECCR_LN_BWD16=0: the old one)
-        static const bool use16 = [] { const char* e = getenv("LECCR_LN_BWD16"); return !(e && e[0] == '0'); }();
-        if (use16 && !colsum_of && (d & 7) == 0 && d <= 1024 && ((((uintptr_t)dy | (uintptr_t)xin | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0)) {
-            int64_t nb16 = cdiv(rows, 4);
-            const int64_t round16 = d <= 512 ? 1536 : 1024;  // 6 / 4 workgroups per CU (registers): exactly one round
-            if (nb16 > round16) nb16 = round16;
-            if (d <= 512)
-                hipLaunchKernelGGL((layernorm_bwd16_kernel<1>), dim3((unsigned)nb16), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)xin, gamma,
-                                   mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows, (int)d);
-            else
-                hipLaunchKernelGGL((layernorm_bwd16_kernel<2>), dim3((unsigned)nb16), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)xin, gamma,
-                                   mean, rstd, (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows, (int)d);
-            return check_launch("layernorm_bwd16");
-        }
-    }
     int64_t nb = cdiv(rows, 4);
     const int64_t resident = colsum_of ? 1024 : 1280;      // 4 / 5 workgroups per CU fit (registers): exactly one round
     if (nb > resident) nb = resident;
