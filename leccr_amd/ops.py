@@ -600,6 +600,13 @@ class CrossAttnLayerFn(torch.autograd.Function):
 
 
 # --------------------------------------------------------------------------------------- losses
+# The loss kernels take their upstream gradient as a host float.  Reading it from the incoming 0-dim tensor (float(g)) would drain
+# the stream - once per loss term, eight times at the very start of every backward pass, with the GPU idling until the host has
+# enqueued work again - so the kernels run with 1.0 and the (tiny, [G, D]) results are scaled by g on the device.
+def _scaled(g, *ts):
+    return tuple(None if t is None else t * g.to(t.dtype) for t in ts)
+
+
 class SimInfoNCEFn(torch.autograd.Function):
     """get_contrastive_loss's compute (models/xvlm.py:273-292) on already gathered f32 features."""
 
@@ -620,11 +627,12 @@ class SimInfoNCEFn(torch.autograd.Function):
         a, b, ws = ctx.saved_tensors
         tval, idx, both_dirs, has_temp, rows = ctx.meta
         dtemp = torch.zeros(1, device=a.device, dtype=torch.float32) if has_temp else None
-        da, db = K.sim_infonce_bwd(a, b, idx, tval, ws, float(g), both_dirs, dtemp, rows)
+        da, db = K.sim_infonce_bwd(a, b, idx, tval, ws, 1.0, both_dirs, dtemp, rows)
         if has_temp and rows is not None and rows[1] != a.shape[0]:
             # temp sits after the gather: every rank must hold the FULL dL/dtemp (DDP then averages identical values).
             # The row shards' shares add up to it over the ranks, so W x share survives the mean.
             dtemp = dtemp * (a.shape[0] / rows[1])
+        da, db, dtemp = _scaled(g, da, db, dtemp)
         return da, db, (dtemp[0] if has_temp else None), None, None, None, None
 
 
@@ -644,7 +652,8 @@ class CapSimFn(torch.autograd.Function):
     def backward(ctx, g):
         c, t, am, ws = ctx.saved_tensors
         dtemp = torch.zeros(1, device=c.device, dtype=torch.float32)
-        dc, dt = K.capsim_bwd(c, t, ctx.tval, am, ws, float(g), dtemp)
+        dc, dt = K.capsim_bwd(c, t, ctx.tval, am, ws, 1.0, dtemp)
+        dc, dt, dtemp = _scaled(g, dc, dt, dtemp)
         return dc, dt, dtemp[0], None
 
 
@@ -662,7 +671,7 @@ class DstlFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         v, t, ws = ctx.saved_tensors
-        dv, dt = K.dstl_bwd(v, t, ws, float(g), ctx.rows)
+        dv, dt = _scaled(g, *K.dstl_bwd(v, t, ws, 1.0, ctx.rows))
         return dv, None, None, dt, None, None
 
 
@@ -694,4 +703,4 @@ class CapRegFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (c,) = ctx.saved_tensors
-        return K.capreg_bwd(c, float(g))
+        return _scaled(g, K.capreg_bwd(c, 1.0))[0]
