@@ -11,16 +11,14 @@ from leccr_amd.parallel import attach_grad_sync
 from leccr_amd.scheduler import create_scheduler
 from leccr_amd.synthetic import make_batch
 dev = torch.device('cuda', 0)
-model, cfg = bench.build_model(args, dev)
+model, cfg, batch, fwd, _ = bench.build_workload(args, dev, 0)
 opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model)).enable_backward_fusion()
 sched = create_scheduler(dict(cfg['schedular'], step_per_epoch=1000), opt)
-cpu = make_batch(args.batch)
-batch = {'image': cpu['image'].to(dev), 'text': [t.to(dev) for t in cpu['text']], 'captions': cpu['captions'].to(dev), 'idx': cpu['idx'].to(dev)}
 ts = []
 n = int(os.environ.get('STEPS', 48))
 for i in range(n):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    bench.train_step(model, batch, opt, sched)
+    bench.train_step(model, batch, fwd, opt, sched)
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
     if i % 8 == 7:
         print(f'step {i + 1:3d}: last 8 steps ' + ' '.join(f'{t:.1f}' for t in ts[-8:]) +
