@@ -56,7 +56,7 @@ def parse():
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--roofline-steps', type=int, default=3, help='extra single-stream steps after the timed region that time every launch on its own')
     ap.add_argument('--cpu-batch', type=int, default=32, help='cpu_baseline batch (BASELINE config A: 32)')
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=3, help='timed cpu_baseline steps after one warm-up (BASELINE.md section 3: median of 3)')
     ap.add_argument('--cpu-budget-s', type=float, default=150.0, help='cpu_baseline stops adding steps past this many seconds')
     args = ap.parse_args()
     if args.batch is None:
