@@ -39,7 +39,20 @@ struct FP {
     int64_t Lqp, nbh;    // bwd: padded query count and b*heads of the row-constant workspace
     float scale;
     DropCfg drop;
+    int xcd;             // 1: XCD-aware block order (xcd_block)
 };
+
+// Workgroups are dealt to the 8 XCDs round-robin (block id % 8), each XCD with its own 4 MiB L2.  The blocks of one (batch, head)
+// - 5 query blocks that each stream the head's whole K / V in the forward, 5 key blocks that each stream its Q / dO in dK/dV -
+// have consecutive ids, i.e. land on 5 DIFFERENT XCDs and fetch the same 148 KB five times from the fabric (2.3 GB per ViT
+// layer against 0.45 GB of unique operands).  With the remap XCD x walks a contiguous range of logical blocks, so a head's blocks
+// run on one XCD back to back and share its L2.
+__device__ __forceinline__ int64_t xcd_block(int xcd_aware) {
+    const int64_t bid = blockIdx.x, n = gridDim.x;
+    if (!xcd_aware) return bid;
+    const int64_t q = n >> 3, r = n & 7, x = bid & 7, j = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
 
 // Stage a [64 rows][64 bf16] tile (rows clamped to n_rows-1) from `base` (row stride ld elements) into LDS.
 // LDS image: row r at byte r*128, physical 16-byte chunk = logical chunk ^ (r & 7)  (swizzle on the SOURCE address).
@@ -226,8 +239,9 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h4 = lane >> 4;
     const int64_t nqb = (p.Lq + BQ - 1) / BQ;
-    const int64_t bh = blockIdx.x / nqb, b = bh / p.heads, head = bh % p.heads;
-    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BQ;
+    const int64_t lb = xcd_block(p.xcd);
+    const int64_t bh = lb / nqb, b = bh / p.heads, head = bh % p.heads;
+    const int64_t q0 = (int64_t)(lb % nqb) * BQ;
     const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
     const bf16_t* Vp = p.v + b * p.Lk * p.ldv + head * HD;
@@ -498,8 +512,9 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
     const int tid = threadIdx.x, lane = tid & 63, h4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t nkb = (p.Lk + BQ - 1) / BQ;
-    const int64_t bh = blockIdx.x / nkb, b = bh / p.heads, head = bh % p.heads;
-    const int64_t k0 = (int64_t)(blockIdx.x % nkb) * BQ + wave * (KG * 16);   // this wave's KG x 16 keys
+    const int64_t lb = xcd_block(p.xcd);
+    const int64_t bh = lb / nkb, b = bh / p.heads, head = bh % p.heads;
+    const int64_t k0 = (int64_t)(lb % nkb) * BQ + wave * (KG * 16);   // this wave's KG x 16 keys
     const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
     const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
@@ -733,8 +748,9 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
     const int tid = threadIdx.x, lane = tid & 63, h4 = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t nqb = (p.Lq + BQ - 1) / BQ;
-    const int64_t bh = blockIdx.x / nqb, b = bh / p.heads, head = bh % p.heads;
-    const int64_t q0 = (int64_t)(blockIdx.x % nqb) * BQ + wave * (KG * 16);
+    const int64_t lb = xcd_block(p.xcd);
+    const int64_t bh = lb / nqb, b = bh / p.heads, head = bh % p.heads;
+    const int64_t q0 = (int64_t)(lb % nqb) * BQ + wave * (KG * 16);
     const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
     const bf16_t* DO = p.dout + b * p.Lq * p.ldo + head * HD;
     const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
@@ -941,6 +957,10 @@ static void set_smem(KFn k, int bytes) {
 }
 
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static int attn_xcd_aware() {      // LECCR_ATTN_XCD=0: plain block order (A/B)
+    static const int v = [] { const char* e = getenv("LECCR_ATTN_XCD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
 
 }  // namespace
 
@@ -959,6 +979,7 @@ int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* l
     p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)o; p.lse = lse;
     p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk; p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv;
     p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
+    p.xcd = attn_xcd_aware();
     if (D.Lq > 64) {        // 8 waves = 128 query rows per block
         dim3 grid((unsigned)(cdiv(D.Lq, 128) * D.b * D.heads));
         if (D.dropout) hipLaunchKernelGGL((flash_fwd_kernel<true, 8>), grid, dim3(512), 2 * FWD_STAGE, st, p);
@@ -983,6 +1004,7 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
     p.lse = const_cast<float*>(lse); p.delta = delta; p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk;
     p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv; p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
     p.Lqp = cdiv(D.Lq, BT) * BT;
+    p.xcd = attn_xcd_aware();
     p.nbh = D.b * D.heads;
     // dQ first: it computes the row constants (-delta, -lse/scale) and leaves them in `delta` for the dK/dV kernel
 #define LAUNCH_BWD(DR, KG)                                                                                              \
