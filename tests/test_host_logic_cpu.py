@@ -146,6 +146,54 @@ def test_allgather_and_grad_sync_two_ranks_gloo():
     assert ret[0] and ret[1]
 
 
+def _gather_worker_w(rank, world, port, ret):
+    """World size > 2 (BASELINE configs C / D / E run at W = 4 and 8): packed gather layout, local-slice backward, arena mean."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from leccr_amd.models import xvlm
+    from leccr_amd.models.xvlm import gather_rows
+    from leccr_amd.parallel import attach_grad_sync
+    b = 3
+    xvlm.begin_step_gathers()
+    p = (torch.arange(b * 4, dtype=torch.float32).view(b, 4) + 1000 * rank).requires_grad_(True)
+    q = (torch.arange(b * 2 * 5, dtype=torch.float32).view(b, 2, 5) - 50 * rank).requires_grad_(True)       # a [b, n, D] block
+    ids = (torch.arange(b).view(b, 1) + b * rank + 2 ** 33)
+    xvlm.gather_rows_packed([p, q], ids)
+    gp, gq, gi = gather_rows(p), gather_rows(q), gather_rows(ids)
+    ok = gp.shape == (world * b, 4) and gq.shape == (world * b, 2, 5)
+    ok &= gi.view(-1).tolist() == [2 ** 33 + i for i in range(world * b)]
+    for r in range(world):                                   # rank-major row order, as torch.cat(all_gather(...)) gives
+        ok &= torch.equal(gp.detach()[r * b:(r + 1) * b], torch.arange(b * 4, dtype=torch.float32).view(b, 4) + 1000 * r)
+        ok &= torch.equal(gq.detach()[r * b:(r + 1) * b], torch.arange(b * 2 * 5, dtype=torch.float32).view(b, 2, 5) - 50 * r)
+    wp = torch.arange(world * b * 4, dtype=torch.float32).view(world * b, 4)
+    ((gp * wp).sum() + gq.sum() * 3).backward()
+    ok &= torch.equal(p.grad, wp[rank * b:(rank + 1) * b]) and torch.equal(q.grad, torch.full((b, 2, 5), 3.0))   # local slice only
+    xvlm.begin_step_gathers()
+
+    class FakeOpt:
+        class arena:
+            grad = torch.full((12,), float(rank + 1))
+            early_numel = 8
+            on_late_backward_start = on_vit_block_backward = None
+        grad_sync, grad_scale = None, 1.0
+    opt = attach_grad_sync(FakeOpt)
+    FakeOpt.arena.on_late_backward_start()
+    opt.grad_sync()
+    ok &= torch.allclose(FakeOpt.arena.grad * opt.grad_scale, torch.full((12,), (world + 1) / 2))     # mean of 1..W
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_packed_gather_and_grad_sync_at_larger_world_sizes_gloo(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gather_worker_w, args=(world, 29700 + world, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
+
+
 def test_launcher_and_script_cli_match_the_reference_flags():
     import run
     import image_Retrieval_caption as task
