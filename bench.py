@@ -259,6 +259,39 @@ def parity_probe(args, cfg, model, batch, fwd, rows=2):
                     f'full {args.clip}@384 + {args.text} geometry'}
 
 
+def retrieval_probe(args, model, batch):
+    """The R@K half of the metric on what this run has: the benchmarked weights (random init: recall is at chance level - there is
+    no dataset and no pretrained checkpoint on this pipeline), the batch's 256 image / target-text pairs as a
+    retrieval set.  What it checks is the integer ranking: itm_eval's 13 numbers from the on-device rank kernel equal the CPU
+    oracle's on the same score matrix (image_Retrieval_caption.py:261-317)."""
+    import numpy as np
+    import torch
+    from leccr_amd import kernels as K
+    from leccr_amd.evaluation import itm_eval
+    from oracle import leccr_oracle as O
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        v, _ = model.get_vision_embeds(batch['image'])
+        c = model.get_caption_embeds(batch['captions'].input_ids, batch['captions'].attention_mask)
+        a_img, _, _ = model.interaction_with_caption(image_embeds=v, caption_embeds=c,
+                                                     key_padding_mask=~batch['captions'].attention_mask.bool())
+        fv = model.get_features(a_img.transpose(0, 1).contiguous(), None)
+        ft = model.get_features(None, model.get_text_embeds(batch['text'][1].input_ids, batch['text'][1].attention_mask))
+        scores = K.gemm(fv.float().contiguous(), ft.float().contiguous())          # [images, texts] = fv ft^T
+    model.train(was_training)
+    n = scores.shape[0]
+    s_np = scores.cpu().numpy()
+    t2i, i2t = {t: t for t in range(n)}, {i: [i] for i in range(n)}
+    got = itm_eval(s_np, s_np.T.copy(), t2i, i2t, device=scores.device)
+    ref = O.itm_eval(s_np, s_np.T.copy(), t2i, i2t)
+    same = all(float(got[k]) == float(ref[k]) for k in ref)
+    return {'pairs': n, 'txt_r1': got['txt_r1'], 'img_r1': got['img_r1'], 'r_mean': round(float(got['r_mean']), 4),
+            'ranks_bit_exact_vs_oracle': bool(same),
+            'what': 'itm_eval on the 256 x 256 image / target-text score matrix of the benchmarked (random-init) weights: recall is at '
+                    'chance level by construction; the check is that the device ranking equals the oracle\'s integer ranks'}
+
+
 HBM_KINDS = ['layernorm_fwd', 'layernorm_bwd', 'colsum', 'bert_embed_fwd', 'adamw', 'dropout']
 
 
@@ -344,8 +377,11 @@ def _main(args, real_stdout):
     else:
         leg, leg_ms, leg_work, leg_n = args.steps, ms, work, n
     parity = None
+    retrieval = None
     if world == 1 and not args.no_parity:          # (the model's forward gathers across ranks: a one-rank probe would hang W > 1)
         parity = parity_probe(args, cfg, model, batch, fwd)
+        if args.model == 'image':
+            retrieval = retrieval_probe(args, model, batch)
     if rank == 0:
         G = args.batch * world
         value = G * args.steps / dt
@@ -408,6 +444,8 @@ def _main(args, real_stdout):
         }
         if parity is not None:
             out['parity'] = parity
+        if retrieval is not None:
+            out['retrieval'] = retrieval
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cfg, model)
         print(json.dumps(out), file=real_stdout, flush=True)
@@ -416,6 +454,8 @@ def _main(args, real_stdout):
         dist.destroy_process_group()
     if parity is not None and not parity['ok']:
         raise SystemExit(f'bench.py: parity probe outside its tolerance: {parity}')
+    if retrieval is not None and not retrieval['ranks_bit_exact_vs_oracle']:
+        raise SystemExit(f'bench.py: device ranking differs from the oracle: {retrieval}')
 
 
 if __name__ == '__main__':
