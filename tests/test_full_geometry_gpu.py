@@ -315,3 +315,41 @@ def test_fp8_operand_path_vs_oracle_noise_model():
     losses2 = _forward(model, batch)
     for a, b_ in zip([float(l) for l in losses2], got):
         assert abs(a - b_) <= 2e-2 * max(1.0, abs(b_)), (got, [float(l) for l in losses2])
+
+
+def test_persistent_gemm_paths_in_a_model_vs_oracle():
+    """The kernels the benchmark spends its time in, inside a model: ViT-B/16 @384 (one layer) with b = 8 gives 4616 token rows,
+    enough for the persistent 256x256 GEMM in BOTH forms - NT forward / dX (>= 192 tiles... the wide ones) and the split-K TN
+    weight-gradient product with the bias gradient summed on the matrix cores (`asum`, K = rows >= 4096) - which the b = 2..4
+    parity runs above never reach.  bf16, every parameter gradient (weights AND biases of the ViT block) under the noise-model rule."""
+    from leccr_amd import _lib, kernels as K
+    model, _ = full_geometry_model('bf16', vision_layers=1, text_config=MID_BERT)
+    model = model.to(DEV).eval()
+    from leccr_amd.synthetic import make_batch
+    m = make_batch(8, vocab=500)
+    batch = dict(image=m['image'], ids_s=m['text'][0].input_ids, mask_s=m['text'][0].attention_mask, ids_t=m['text'][1].input_ids,
+                 mask_t=m['text'][1].attention_mask, ids_c=m['captions'].input_ids, mask_c=m['captions'].attention_mask, idx=m['idx'])
+    torch.set_num_threads(16)
+    ref_losses, sd = oracle_step(model.state_dict(), batch, 2)
+    _, sd_noise = oracle_step(model.state_dict(), batch, 2, lowp=True)
+    losses = _forward(model, batch)
+    for a, r in zip([float(l) for l in losses], ref_losses):
+        assert abs(a - r) <= 3e-2 * max(1.0, abs(r)), ([float(l) for l in losses], ref_losses)
+    model.arena.zero_grad()
+    lib = _lib.lib()
+    lib.leccr_prof_enable(1)
+    sum(losses).backward()
+    torch.cuda.synchronize()
+    lib.leccr_prof_enable(0)
+    # the dW products of the ViT block really were the 256x256 TN kernel: a probe launch of the same shape reports kernel 2
+    blk = model.clip_encoder.visual.transformer.resblocks[0]
+    dy, x = torch.zeros(4616, 3072, device=DEV, dtype=torch.bfloat16), torch.zeros(4616, 768, device=DEV, dtype=torch.bfloat16)
+    K.gemm(dy, x, trans_a=True, trans_b=True, out=torch.zeros(3072, 768, device=DEV), accumulate=True, asum=torch.zeros(3072, device=DEV))
+    assert lib.leccr_last_gemm_kernel() == 2
+    rows = grad_rows(model, sd, sd_noise)
+    names = {r[0] for r in rows}
+    assert {'clip_encoder.visual.transformer.resblocks.0.mlp.c_fc.bias', 'clip_encoder.visual.transformer.resblocks.0.attn.in_proj_bias',
+            'clip_encoder.visual.transformer.resblocks.0.mlp.c_proj.bias', 'clip_encoder.visual.transformer.resblocks.0.attn.out_proj.bias'} <= names
+    bad = outside_noise_model(rows)
+    assert not bad, (len(bad), bad[:8])
+    assert blk.mlp.c_fc.bias.grad.abs().sum() > 0
