@@ -16,12 +16,12 @@ def show(title, rows, k=12):
     live = [r for r in rows if r[2] >= 1e-6 * gmax]
     print(f'== {title}: {len(live)} tensors')
     worst = sorted(live, key=lambda r: -(r[1] / r[2]))[:k]
-    for n, err, rn, cos, nz in worst:
+    for n, err, rn, cos, nz, *_ in worst:
         print(f'  rel {err / rn:9.3e}  noise {((nz or 0) / rn):9.3e}  ratio {(err / nz if nz else float("nan")):6.2f}  cos {cos:.5f}  |g|/gmax {rn / gmax:8.2e}  {n}')
     if live and live[0][4] is not None:
         worst = sorted(live, key=lambda r: -(r[1] / (3 * r[4] + 1e-3 * r[2])))[:k]
         print('  -- by err / (3 noise + 1e-3 |g|)')
-        for n, err, rn, cos, nz in worst:
+        for n, err, rn, cos, nz, *_ in worst:
             print(f'  score {err / (3 * nz + 1e-3 * rn):6.3f} rel {err / rn:9.3e}  noise {nz / rn:9.3e}  cos {cos:.5f}  {n}')
 
 
