@@ -30,7 +30,7 @@ if __name__ == '__main__':
         (got, ref, noise), rows = F.bf16_vs_noise_model(temp)
         print('temp', temp, 'losses hip', got, '\n   ref', ref, '\n   noise', noise)
         show(f'MID bf16 temp {temp}', rows)
-    for dtype in ('bf16',):
+    for dtype in (('bf16',) if 'full' in sys.argv else ()):
         model, _ = F.full_geometry_model(dtype)
         model = model.to('cuda').eval()
         batch = F.multi30k_batch(4)
