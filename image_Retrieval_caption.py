@@ -25,7 +25,7 @@ from leccr_amd.evaluation import evaluation_coarse, itm_eval          # noqa: F4
 from leccr_amd.models.model_retrieval_caption import RetrievalModel
 from leccr_amd.optim import create_optimizer
 from leccr_amd.parallel import attach_grad_sync
-from leccr_amd.pipeline import DeferredScalars, DevicePrefetcher
+from leccr_amd.pipeline import DeferredScalars, DevicePrefetcher, TokenizingCollate, tokenize_or_pass
 from leccr_amd.scheduler import create_scheduler
 from leccr_amd.synthetic import MULTI30K_CFG, make_batch
 
@@ -49,9 +49,9 @@ def train(model, data_loader, optimizer, tokenizer, epoch, device, scheduler, co
     deferred = DeferredScalars()          # loss scalars reach the logger one step late, without a host sync per step
     batches = DevicePrefetcher(data_loader, device)       # batch k+1 is pinned + copied on a side stream during step k
     for i, (image, text_ls, captions, idx, cap_idx) in enumerate(metric_logger.log_every(batches, 50, header)):
-        text_inputs = [tokenizer(text, padding='longest', max_length=config['max_tokens'], return_tensors='pt').to(device)
-                       for text in text_ls]
-        captions = tokenizer(captions, padding='longest', max_length=config['max_tokens'], return_tensors='pt').to(device)
+        # tokenised in the loader workers (--tokenize_in_workers: TokenizingCollate) or here, as the reference does
+        text_inputs = [tokenize_or_pass(tokenizer, text, config['max_tokens'], device) for text in text_ls]
+        captions = tokenize_or_pass(tokenizer, captions, config['max_tokens'], device)
         losses = model(image, text_inputs, captions=captions, idx=idx, epoch=epoch, cap_idx=cap_idx)
         loss = losses[0] + losses[1] + losses[2] + losses[3] + losses[4]
         optimizer.zero_grad()
@@ -106,8 +106,11 @@ def main(args, config):
         from dataset import create_dataset, create_sampler, create_loader, mbert_build_tokenizer   # reference package
         train_dataset, val_dataset_dict, test_dataset_dict = create_dataset('re_caption', config, args.evaluate)
         samplers = create_sampler([train_dataset], [True], world_size, utils.get_rank()) + [None]
+        tokenizer = mbert_build_tokenizer()
+        # --tokenize_in_workers: the three tokenizer calls of a step run in the loader's worker processes (pipeline.TokenizingCollate)
+        train_collate = TokenizingCollate(tokenizer, config['max_tokens']) if args.tokenize_in_workers else None
         train_loader = create_loader([train_dataset], samplers[:1], batch_size=[config['batch_size_train']],
-                                     num_workers=[4], is_trains=[True], collate_fns=[None])[0]
+                                     num_workers=[4], is_trains=[True], collate_fns=[train_collate])[0]
         test_loaders = {k: create_loader([v], [None], batch_size=[config['batch_size_test']], num_workers=[4],
                                          is_trains=[False], collate_fns=[None])[0] for k, v in test_dataset_dict.items()}
         tokenizer = mbert_build_tokenizer()
@@ -177,6 +180,7 @@ def build_parser():
     p.add_argument('--bs', default=-1, type=int, help='for each gpu, batch_size = bs // num_gpus')
     p.add_argument('--evaluate', action='store_true')
     p.add_argument('--synthetic', action='store_true')
+    p.add_argument('--tokenize_in_workers', action='store_true', help='tokenise in the DataLoader workers instead of in the train loop')
     p.add_argument('--synthetic_steps', default=4, type=int)
     return p
 

@@ -9,7 +9,11 @@ image_Retrieval_caption.py:48-56) and reads five loss scalars back with `.item()
   * DeferredScalars copies the step's loss scalars into pinned memory without synchronising and hands them out one step
     later (the logger's window of 1 then shows the previous step, the epoch averages are unchanged).
 
-Both degrade to plain pass-through on a machine without a GPU (the CPU tests run that way).
+  * TokenizingCollate moves the three tokenizer calls of every step (source text, target text, generated caption - slow-Python
+    `BertTokenizer`, image_Retrieval_caption.py:46-58) out of the train loop into the DataLoader WORKER processes: the loop then
+    receives ready `input_ids` / `attention_mask` tensors, which the prefetcher uploads with the images.
+
+All degrade to plain pass-through on a machine without a GPU (the CPU tests run that way).
 """
 import torch
 
@@ -111,3 +115,39 @@ class DeferredScalars:
     def flush(self):
         prev, self._pending = self._pending, None
         return self._finish(prev) if prev is not None else None
+
+
+class TokenizingCollate:
+    """collate_fn for the reference's train loaders (dataset/__init__.py:187-212 pass collate_fns through to DataLoader): the default
+    collation of (image, [source text, target text], generated caption, image index, cap_id) samples, followed - still inside the
+    worker process - by the tokenizer calls the reference makes in its train loop, with the same arguments
+    (`padding='longest', max_length=config['max_tokens'], return_tensors='pt'`).  `train()` recognises tokenised batches
+    (`tokenize_or_pass`) and skips its own calls."""
+
+    def __init__(self, tokenizer, max_tokens, base_collate=None, text_pos=1):
+        # text_pos: position of the [source, target] text lists in the collated batch (image loader: 1; video loader, whose own
+        # collate_fn - retrieval_dataset_video.py:21-37, passed as base_collate - yields (video, mask, texts, captions, ..): 2)
+        self.tokenizer, self.max_tokens, self.base, self.text_pos = tokenizer, max_tokens, base_collate, text_pos
+
+    def _tok(self, texts):
+        return self.tokenizer(list(texts), padding='longest', max_length=self.max_tokens, return_tensors='pt')
+
+    def __call__(self, samples):
+        if self.base is not None:
+            batch = self.base(samples)
+        else:
+            from torch.utils.data import default_collate
+            batch = default_collate(samples)
+        batch = list(batch)
+        p = self.text_pos
+        batch[p] = [self._tok(t) for t in batch[p]]
+        batch[p + 1] = self._tok(batch[p + 1])
+        return tuple(batch)
+
+
+def tokenize_or_pass(tokenizer, texts, max_tokens, device):
+    """What the train loop does with one text field of a batch: tokenise it (the reference's call) unless the loader's collate_fn
+    (TokenizingCollate) or the synthetic generator already did; either way the result lives on `device`."""
+    if hasattr(texts, 'input_ids'):
+        return texts if texts.input_ids.device.type == torch.device(device).type else texts.to(device)
+    return tokenizer(texts, padding='longest', max_length=max_tokens, return_tensors='pt').to(device)

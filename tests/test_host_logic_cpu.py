@@ -310,3 +310,53 @@ def test_caption_txt_store_reader_matches_the_reference_dataset_classes(tmp_path
             assert (gen2, idx2) == (gen, idx) and path.startswith(images + '/')
     # the mscoco image path goes through img_id/image_ids.txt
     assert TrainAnnotations(cfgs['coco'][0]).record(0)[0].endswith('COCO_val2014_000000391895.jpg')
+
+
+class _WsTok:
+    """Whitespace "tokenizer" with the HF call signature the train loop uses; counts its calls in THIS process."""
+    calls = 0
+
+    def __call__(self, texts, padding=None, max_length=None, return_tensors=None):
+        from leccr_amd.synthetic import Encoding
+        assert padding == 'longest' and max_length == 200 and return_tensors == 'pt' and isinstance(texts, list)
+        _WsTok.calls += 1
+        rows = [[101] + [len(w) for w in t.split()] + [102] for t in texts]
+        L = max(map(len, rows))
+        ids = torch.tensor([r + [0] * (L - len(r)) for r in rows])
+        return Encoding(ids, (ids != 0).long())
+
+
+class _TextDS(torch.utils.data.Dataset):
+    def __len__(self):
+        return 6
+
+    def __getitem__(self, i):
+        return torch.full((3, 4, 4), float(i)), [f'a b c {"d " * i}', f'ein zwei {"x " * i}'], f'caption number {i}', i, f'img{i}#enc#0'
+
+
+def test_tokenizing_collate_moves_the_tokenizer_calls_into_the_loader_workers():
+    """pipeline.TokenizingCollate: a DataLoader with worker processes yields batches whose three text fields
+    are already tokenised with the reference's arguments (image_Retrieval_caption.py:46-58); tokenize_or_pass then leaves them
+    alone, and tokenises plain string lists exactly like the loop did.  Image layout (texts at position 1) and the video layout
+    behind the reference's frame-padding collate_fn (position 2)."""
+    from torch.utils.data import DataLoader
+    from leccr_amd.pipeline import DevicePrefetcher, TokenizingCollate, tokenize_or_pass
+    _WsTok.calls = 0
+    loader = DataLoader(_TextDS(), batch_size=3, num_workers=2, collate_fn=TokenizingCollate(_WsTok(), 200), timeout=60)
+    batches = list(DevicePrefetcher(loader, 'cpu'))
+    assert len(batches) == 2 and _WsTok.calls == 0                               # every tokenizer call ran in a WORKER process
+    image, text_ls, cap, idx, cap_ids = batches[1]
+    assert image.shape == (3, 3, 4, 4) and idx.tolist() == [3, 4, 5] and cap_ids[0] == 'img3#enc#0'
+    assert text_ls[0].input_ids.shape == (3, 2 + 3 + 5) and text_ls[0].input_ids[0].tolist()[:6] == [101, 1, 1, 1, 1, 1]
+    assert text_ls[1].attention_mask.sum(1).tolist() == [2 + 2 + 3, 2 + 2 + 4, 2 + 2 + 5] and cap.input_ids[:, 1].tolist() == [7, 7, 7]
+    assert tokenize_or_pass(_WsTok(), text_ls[0], 200, 'cpu') is text_ls[0] and _WsTok.calls == 0
+    plain = tokenize_or_pass(_WsTok(), ['a bb', 'ccc'], 200, 'cpu')              # the reference's in-loop call, unchanged
+    assert _WsTok.calls == 1 and plain.input_ids.tolist() == [[101, 1, 2, 102], [101, 3, 102, 0]]
+
+    def video_collate(samples):                      # shape of retrieval_dataset_video.collate_fn's result
+        frames, en, zh, gen, ids, caps = zip(*samples)
+        return torch.stack(frames), torch.ones(len(frames), 2).bool(), [list(en), list(zh)], list(gen), torch.tensor(ids), list(caps)
+    vb = TokenizingCollate(_WsTok(), 200, base_collate=video_collate, text_pos=2)(
+        [(torch.zeros(2, 8), 'one two', 'yi er san', 'gen cap', 7, 'v7#enc#0'), (torch.ones(2, 8), 'three', 'si', 'gen', 9, 'v9#enc#0')])
+    assert vb[0].shape == (2, 2, 8) and vb[1].dtype == torch.bool and vb[4].tolist() == [7, 9]
+    assert vb[2][1].input_ids.tolist() == [[101, 2, 2, 3, 102], [101, 2, 102, 0, 0]] and vb[3].input_ids.shape == (2, 4)

@@ -24,7 +24,7 @@ from leccr_amd.evaluation import evaluation_coarse_video as evaluation_coarse, i
 from leccr_amd.models.video_model_retrieval_caption import RetrievalModel
 from leccr_amd.optim import create_optimizer
 from leccr_amd.parallel import attach_grad_sync
-from leccr_amd.pipeline import DeferredScalars, DevicePrefetcher
+from leccr_amd.pipeline import DeferredScalars, DevicePrefetcher, TokenizingCollate, tokenize_or_pass
 from leccr_amd.scheduler import create_scheduler
 from leccr_amd.synthetic import VATEX_CFG, make_video_batch
 
@@ -41,9 +41,9 @@ def train(model, data_loader, optimizer, tokenizer, epoch, device, scheduler, co
     deferred = DeferredScalars()
     batches = DevicePrefetcher(data_loader, device)
     for i, (video, video_mask, text_ls, captions, idx, cap_idx) in enumerate(metric_logger.log_every(batches, 50, header)):
-        text_inputs = [tokenizer(text, padding='longest', max_length=config['max_tokens'], return_tensors='pt').to(device)
-                       for text in text_ls]
-        captions = tokenizer(captions, padding='longest', max_length=config['max_tokens'], return_tensors='pt').to(device)
+        # tokenised in the loader workers (--tokenize_in_workers: TokenizingCollate) or here, as the reference does
+        text_inputs = [tokenize_or_pass(tokenizer, text, config['max_tokens'], device) for text in text_ls]
+        captions = tokenize_or_pass(tokenizer, captions, config['max_tokens'], device)
         losses = model(video, video_mask, text_inputs, captions=captions, idx=idx, epoch=epoch, cap_idx=cap_idx)
         loss = losses[0] + losses[1] + losses[2] + losses[3] + losses[4]
         optimizer.zero_grad()
@@ -97,8 +97,14 @@ def main(args, config):
         from dataset import create_dataset, create_sampler, create_loader, mbert_build_tokenizer   # reference package
         train_dataset, val_dataset_dict, test_dataset_dict = create_dataset('re_video_caption', config, args.evaluate)
         samplers = create_sampler([train_dataset], [True], world_size, utils.get_rank()) + [None]
+        # the reference pads the ragged frame lists in the loader's collate_fn (video_Retrieval_caption_double_sim.py:288-292);
+        # --tokenize_in_workers additionally runs the step's three tokenizer calls there (pipeline.TokenizingCollate)
+        from dataset.retrieval_dataset_video import collate_fn
+        tokenizer = mbert_build_tokenizer()
+        train_collate = TokenizingCollate(tokenizer, config['max_tokens'], base_collate=collate_fn, text_pos=2) \
+            if args.tokenize_in_workers else collate_fn
         train_loader = create_loader([train_dataset], samplers[:1], batch_size=[config['batch_size_train']],
-                                     num_workers=[4], is_trains=[True], collate_fns=[None])[0]
+                                     num_workers=[4], is_trains=[True], collate_fns=[train_collate])[0]
         test_loaders = {k: create_loader([v], [None], batch_size=[config['batch_size_test']], num_workers=[4],
                                          is_trains=[False], collate_fns=[None])[0] for k, v in test_dataset_dict.items()}
         tokenizer = mbert_build_tokenizer()
