@@ -15,6 +15,10 @@ OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(HERE, 'libleccr_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
          '-Wno-unused-result']
+# Per-source extras.  attention_mfma: the SLP vectoriser pairs the f32 multiplies of the softmax / dS stages into v_pk_mul_f32
+# and glues the bf16 packs together with v_pk_mov / v_alignbit / v_perm (50 extra VALU instructions per tile in kernels the VALU
+# bounds; packed f32 ops also issue at half rate beside MFMAs): backward -3..5 % without it.
+EXTRA_FLAGS = {'attention_mfma.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -46,7 +50,7 @@ def build(force=False, verbose=True):
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s[:-4] + '.o')
         objs.append(obj)
         if force or _stale(src, obj, headers):
-            jobs.append([hipcc] + FLAGS + ['-c', src, '-o', obj])
+            jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ['-c', src, '-o', obj])
 
     def run(cmd):
         if verbose:

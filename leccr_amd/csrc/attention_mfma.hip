@@ -225,6 +225,30 @@ struct StageSrc {
     }
 };
 
+// Diagnostic builds only (-DLECCR_ATTN_STAMPS, scripts/attn_stamps.py): per wave and tile, s_memtime at five points of the forward
+// tile loop (all at points where no LDS read is outstanding: an s_memtime result returns through lgkmcnt like the reads).
+#ifdef LECCR_ATTN_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;
+#define ASTAMP(i)                                              \
+    do {                                                       \
+        __builtin_amdgcn_sched_barrier(0);                     \
+        tsm[i] = __builtin_amdgcn_s_memtime();                 \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+#define ASTAMP_FLUSH(t)                                                                                         \
+    do {                                                                                                        \
+        if (g_attn_stamps && lb < 4096 && lane == 0 && (t) < 16) {                                              \
+            unsigned long long* d_ = g_attn_stamps + (((size_t)lb * NW + wave) * 16 + (t)) * 8;                 \
+            for (int i_ = 0; i_ < 5; ++i_) d_[i_] = tsm[i_];                                                    \
+            d_[5] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   /* HW_ID */                  \
+            d_[6] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   /* XCC_ID */                 \
+        }                                                                                                       \
+    } while (0)
+#else
+#define ASTAMP(i) do {} while (0)
+#define ASTAMP_FLUSH(t) do {} while (0)
+#endif
+
 // --------------------------------------------------------------------------------------------------- forward
 // LDS per stage: K tile | V tile
 constexpr int FWD_STAGE = 2 * TILE_BYTES;
@@ -296,11 +320,16 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
         // key mask bytes of this tile are fetched BEFORE the next tile's DMA is issued, so waiting for them does
         // not wait for the prefetch (vmcnt retires in order)
         const bool ragged = t >= nfull;
+#ifdef LECCR_ATTN_STAMPS
+        unsigned long long tsm[5];
+#endif
+        ASTAMP(0);
         const uint32_t dead = dead_keys(km, p.Lk, (int64_t)t * BT + 4 * h4, ragged);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntiles) stage(t + 1);
+        ASTAMP(1);
         if (!active) continue;
         bf16x8 kf[8];
         kf[0] = lds_b128<0>(kt + tl.row[0]);
@@ -312,12 +341,13 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
         kf[6] = lds_b128<6144>(kt + tl.row[0]);
         kf[7] = lds_b128<6144>(kt + tl.row[1]);
         LDS_WAIT8(0, kf);
+        ASTAMP(2);
         f32x4 s[4];
+        // k-step outer: the second MFMA of an accumulator is issued 4 MFMAs behind the first, not right behind it
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = MFMA16(kf[2 * j], qf[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
-            s[j] = MFMA16(kf[2 * j + 1], qf[1], s[j]);
-        }
+        for (int j = 0; j < 4; ++j) s[j] = MFMA16(kf[2 * j], qf[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = MFMA16(kf[2 * j + 1], qf[1], s[j]);
         // s[j][r] = <k[key = 16j + 4*h4 + r], q[query = lane&15]>
         bf16x8 vf[8];                               // vf[2nd + ks]
         vf[0] = lds_tr16_pair<0>(vt + tl.tr[0]);
@@ -375,15 +405,15 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
         const bf16x8 pf0 = pack2(s[0], s[1]), pf1 = pack2(s[2], s[3]);
         __builtin_amdgcn_sched_barrier(0);          // keep the softmax above the wait: it is what hides the V reads
         LDS_WAIT8(0, vf);
+        ASTAMP(3);
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd) {
-            o[nd] = MFMA16(vf[2 * nd], pf0, o[nd]);
-            o[nd] = MFMA16(vf[2 * nd + 1], pf1, o[nd]);
-        }
-        if constexpr (!DROP) {
-            lacc = MFMA16(ones, pf0, lacc);
-            lacc = MFMA16(ones, pf1, lacc);
-        }
+        for (int nd = 0; nd < 4; ++nd) o[nd] = MFMA16(vf[2 * nd], pf0, o[nd]);
+        if constexpr (!DROP) lacc = MFMA16(ones, pf0, lacc);
+#pragma unroll
+        for (int nd = 0; nd < 4; ++nd) o[nd] = MFMA16(vf[2 * nd + 1], pf1, o[nd]);
+        if constexpr (!DROP) lacc = MFMA16(ones, pf1, lacc);
+        ASTAMP(4);
+        ASTAMP_FLUSH(t);
     }
     if (short_tail) {
         const int t = ntiles - 1;
@@ -593,20 +623,22 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
 #pragma unroll
         for (int g = KG - 1; g >= 0; --g)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[g][j] = MFMA16(fa[2 * j], kf[g][0], s[0][j]);            // group 0 last: it overwrites the shared start value
-                s[g][j] = MFMA16(fa[2 * j + 1], kf[g][1], s[g][j]);
-            }
+            for (int j = 0; j < 4; ++j) s[g][j] = MFMA16(fa[2 * j], kf[g][0], s[0][j]);   // group 0 last: it overwrites the shared start value
+#pragma unroll
+        for (int g = KG - 1; g >= 0; --g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[g][j] = MFMA16(fa[2 * j + 1], kf[g][1], s[g][j]);
         __builtin_amdgcn_sched_barrier(0);
         READ_ROWS8(fa, dot);
         LDS_WAIT8(0, fa);
 #pragma unroll
         for (int g = 0; g < KG; ++g)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dp[g][j] = MFMA16(fa[2 * j], vf[g][0], DROP ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dl[j]);      // dl = -delta
-                dp[g][j] = MFMA16(fa[2 * j + 1], vf[g][1], dp[g][j]);
-            }
+            for (int j = 0; j < 4; ++j) dp[g][j] = MFMA16(fa[2 * j], vf[g][0], DROP ? (f32x4{0.f, 0.f, 0.f, 0.f}) : dl[j]);      // dl = -delta
+#pragma unroll
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dp[g][j] = MFMA16(fa[2 * j + 1], vf[g][1], dp[g][j]);
         __builtin_amdgcn_sched_barrier(0);
         READ_TR8(fa, dot);                          // dO^T, under the p computation
         bf16x8 pf[KG][2];
@@ -638,12 +670,11 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
         __builtin_amdgcn_sched_barrier(0);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int g = 0; g < KG; ++g)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-                dv[g][nd] = MFMA16(fa[2 * nd], pf[g][0], dv[g][nd]);
-                dv[g][nd] = MFMA16(fa[2 * nd + 1], pf[g][1], dv[g][nd]);
-            }
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) dv[g][nd] = MFMA16(fa[2 * nd + ks], pf[g][ks], dv[g][nd]);
         __builtin_amdgcn_sched_barrier(0);
         READ_TR8(fa, qt);                           // Q^T, under the dS computation
         bf16x8 df[KG][2];
@@ -661,12 +692,11 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
         __builtin_amdgcn_sched_barrier(0);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int g = 0; g < KG; ++g)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-                dk[g][nd] = MFMA16(fa[2 * nd], df[g][0], dk[g][nd]);
-                dk[g][nd] = MFMA16(fa[2 * nd + 1], df[g][1], dk[g][nd]);
-            }
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) dk[g][nd] = MFMA16(fa[2 * nd + ks], df[g][ks], dk[g][nd]);
     }
     if (short_tail) {
         const int t = ntiles - 1;
@@ -838,22 +868,20 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
             }
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int g = 0; g < KG; ++g)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[g][j] = MFMA16(fa[2 * j], qf[g][0], s[g][j]);
-                s[g][j] = MFMA16(fa[2 * j + 1], qf[g][1], s[g][j]);
-            }
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) s[g][j] = MFMA16(fa[2 * j + ks], qf[g][ks], s[g][j]);
         __builtin_amdgcn_sched_barrier(0);
         READ_ROWS8(fa, vt);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int g = 0; g < KG; ++g)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dp[g][j] = MFMA16(fa[2 * j], dof[g][0], dp[g][j]);
-                dp[g][j] = MFMA16(fa[2 * j + 1], dof[g][1], dp[g][j]);
-            }
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dp[g][j] = MFMA16(fa[2 * j + ks], dof[g][ks], dp[g][j]);
         __builtin_amdgcn_sched_barrier(0);
         READ_TR8(fa, kt);                           // K^T, under the p / dS computation
         bf16x8 df[KG][2];
@@ -890,12 +918,11 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
         __builtin_amdgcn_sched_barrier(0);
         LDS_WAIT8(0, fa);
 #pragma unroll
-        for (int g = 0; g < KG; ++g)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-                dq[g][nd] = MFMA16(fa[2 * nd], df[g][0], dq[g][nd]);
-                dq[g][nd] = MFMA16(fa[2 * nd + 1], df[g][1], dq[g][nd]);
-            }
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) dq[g][nd] = MFMA16(fa[2 * nd + ks], df[g][ks], dq[g][nd]);
     }
     if (short_tail) {
         const int t = ntiles - 1;
@@ -980,7 +1007,10 @@ int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* l
     p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk; p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv;
     p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
     p.xcd = attn_xcd_aware();
-    if (D.Lq > 64) {        // 8 waves = 128 query rows per block
+#ifndef LECCR_ATTN_FWD_SPLIT
+#define LECCR_ATTN_FWD_SPLIT 64
+#endif
+    if (D.Lq > LECCR_ATTN_FWD_SPLIT) {        // 8 waves = 128 query rows per block
         dim3 grid((unsigned)(cdiv(D.Lq, 128) * D.b * D.heads));
         if (D.dropout) hipLaunchKernelGGL((flash_fwd_kernel<true, 8>), grid, dim3(512), 2 * FWD_STAGE, st, p);
         else hipLaunchKernelGGL((flash_fwd_kernel<false, 8>), grid, dim3(512), 2 * FWD_STAGE, st, p);
@@ -1023,3 +1053,10 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
 }
 
 }  // namespace leccr
+
+#ifdef LECCR_ATTN_STAMPS
+extern "C" int leccr_debug_set_attn_stamps(void* p) {      // diagnostic builds only
+    unsigned long long* v = (unsigned long long*)p;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(leccr::g_attn_stamps), &v, sizeof(v));
+}
+#endif

@@ -162,7 +162,11 @@ def _ref_attn(q, k, v, heads, kmask):
                                                      (2, 8, 4, 70, 64, True), (2, 8, 150, 4, 64, False),
                                                      (2, 4, 33, 33, 8, True), (1, 12, 577, 577, 64, False),
                                                      (2, 8, 5, 5, 512, True), (2, 12, 200, 200, 64, True),
-                                                     (3, 8, 130, 70, 64, True), (2, 8, 4, 577, 64, False)])
+                                                     (3, 8, 130, 70, 64, True), (2, 8, 4, 577, 64, False),
+                                                     # 64 n + 1 rows (class token + patch grid): the odd key / query row runs
+                                                     # behind the tile loop on the VALU
+                                                     (2, 4, 129, 129, 64, True), (2, 4, 193, 70, 64, True),
+                                                     (2, 4, 70, 257, 64, True), (2, 2, 65, 65, 64, False)])
 def test_attention(K, dtype, b, heads, Lq, Lk, hd, masked):
     d = heads * hd
     # packed projection buffers: q|k|v side by side (strided views), as the model uses them
