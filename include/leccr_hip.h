@@ -135,6 +135,19 @@ int leccr_layernorm_fwd(const void* x, const void* add, const float* gamma, cons
 int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
                         const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of,
                         int64_t rows, int64_t d, int dtype, void* stream);
+/* The post-LN residual blocks of HF BERT (BertSelfOutput / BertOutput, called at xvlm.py:238) and of CrossAttentionLayer
+ * (attention.py:52-54) are  y = LN(dropout(dense(h)) + residual): the _drop forms take the dropout inside the LayerNorm pass
+ * instead of a separate leccr_dropout launch over the tensor on each side.
+ * fwd_drop: as leccr_layernorm_fwd with x replaced by dropout(x; p, seed) - the mask and rounding of leccr_dropout(x, .., p, seed)
+ *           (element i of the contiguous [rows, d] tensor; rows * d < 2^32), so the results equal the two-call sequence bit for bit.
+ * bwd_drop: as leccr_layernorm_bwd (colsum_of = 0) with a second output dx_drop = dropout(dx; p, seed), the gradient the dense
+ *           layer sees; dx itself (the residual branch's gradient) is written as before. */
+int leccr_layernorm_fwd_drop(const void* x, const void* add, const float* gamma, const float* beta, void* y,
+                             void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p,
+                             uint64_t seed, int dtype, void* stream);
+int leccr_layernorm_bwd_drop(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
+                             const void* dres, void* dx, float* dgamma, float* dbeta, void* dx_drop, float p, uint64_t seed,
+                             int64_t rows, int64_t d, int dtype, void* stream);
 
 /* ---- Attention --------------------------------------------------------------------------------------------
  * softmax(Q K^T / sqrt(hd) + key mask) V per (batch, head); no materialised score matrix.

@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             T* __restrict__ sum_out, float* __restrict__ mean,
-                                                            float* __restrict__ rstd, int64_t rows, int d, float eps) {
+                                                            float* __restrict__ rstd, int64_t rows, int d, float eps,
+                                                            DropCfg drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -23,6 +24,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         const int c = (lane + 64 * i) * 4;
         if (c < d) {
             v[i] = load4(xr + c);
+            if (drop.thr) {     // x = dropout(x): the mask leccr_dropout(x, seed) applies, rounded through T as its output would be
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[i][j] = to_f32(from_f32<T>(v[i][j] * drop_mul(drop, (uint32_t)(row * d + c + j))));
+            }
             if (add) v[i] += load4(add + row * d + c);
             if (sum_out) {
                 // normalise exactly what is stored (and later handed to the backward as x_in): round through T
@@ -71,7 +77,8 @@ __global__ __launch_bounds__(256, NCH <= 3 ? (CS ? 4 : 5) : 1) void layernorm_bw
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
                                                             T* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ colsum,
-                                                            int colsum_of, int64_t rows, int d) {
+                                                            int colsum_of, int64_t rows, int d, T* __restrict__ dx_drop,
+                                                            DropCfg drop) {
     __shared__ float red[NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[NCH], db[NCH], dc[CS ? NCH : 1];    // dc: column sums of dres (colsum_of = 1) or of the dx written (2)
@@ -119,6 +126,12 @@ __global__ __launch_bounds__(256, NCH <= 3 ? (CS ? 4 : 5) : 1) void layernorm_bw
                     if (colsum_of == 2) dc[i] += o;
                 }
                 store4(dx + row * d + c, o);
+                if (dx_drop) {      // second output: dropout(dx) with the forward's mask - what leccr_dropout(dx, seed) would write
+                    f32x4 od;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) od[j] = to_f32(from_f32<T>(o[j])) * drop_mul(drop, (uint32_t)(row * d + c + j));
+                    store4(dx_drop + row * d + c, od);
+                }
             }
         }
     }
@@ -179,7 +192,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               bf16_t* __restrict__ y, bf16_t* __restrict__ sum_out,
                                                               float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
-                                                              int d, float eps) {
+                                                              int d, float eps, DropCfg drop) {
     const int lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
@@ -196,6 +209,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
         if (row < rows) {
             const int64_t o = row * d + m.col[s];
             load8f(x + o, v[s]);
+            if (drop.thr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[s][j] = (float)(bf16_t)(v[s][j] * drop_mul(drop, (uint32_t)(o + j)));
+            }
             if (add) {
                 float a[8];
                 load8f(add + o, a);
@@ -365,14 +382,14 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const bf16_t* __restrict_
 template <typename T>
 static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                            void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
-                           hipStream_t st) {
+                           const DropCfg& drop, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         int R = 0, NS = 0;
         if (rows16_shape(d, &R, &NS)) {
             dim3 g16((unsigned)cdiv(cdiv(rows, R), 4));
 #define F16(NS_, R_)                                                                                                     \
     hipLaunchKernelGGL((layernorm_fwd16_kernel<NS_, R_>), g16, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)add, gamma,  \
-                       beta, (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)d, eps)
+                       beta, (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)d, eps, drop)
             if (R == 1 && NS == 1) F16(1, 1); else if (R == 1 && NS == 2) F16(2, 1); else if (R == 1 && NS == 3) F16(3, 1);
             else if (R == 1 && NS == 4) F16(4, 1); else if (R == 2 && NS == 1) F16(1, 2); else if (R == 2 && NS == 3) F16(3, 2);
             else if (R == 2 && NS == 5) F16(5, 2); else R = 0;
@@ -383,7 +400,7 @@ static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, c
     dim3 grid((unsigned)cdiv(rows, 4));
 #define L(N)                                                                                                      \
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, (const T*)add, gamma, beta, \
-                       (T*)y, (T*)sum_out, mean, rstd, rows, (int)d, eps)
+                       (T*)y, (T*)sum_out, mean, rstd, rows, (int)d, eps, drop)
     if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
     else if (d <= 2048) L(8); else L(16);
 #undef L
@@ -393,7 +410,7 @@ static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, c
 template <typename T>
 static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, const float* mean, const float* rstd,
                            const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of,
-                           int64_t rows, int64_t d, hipStream_t st) {
+                           int64_t rows, int64_t d, void* dx_drop, const DropCfg& drop, hipStream_t st) {
     int64_t nb = cdiv(rows, 4);
     const int64_t resident = colsum_of ? 1024 : 1280;      // 4 / 5 workgroups per CU fit (registers): exactly one round
     if (nb > resident) nb = resident;
@@ -402,10 +419,10 @@ static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, 
     do {                                                                                                         \
         if (colsum_of)                                                                                           \
             hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, true>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma,  \
-                               mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d);          \
+                               mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d, (T*)dx_drop, drop); \
         else                                                                                                     \
             hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, false>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma, \
-                               mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d);          \
+                               mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d, (T*)dx_drop, drop); \
     } while (0)
     if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
     else if (d <= 2048) L(8); else L(16);
@@ -425,32 +442,64 @@ using namespace leccr;
         return LECCR_EINVAL;                                             \
     } while (0)
 
+static int ln_fwd_entry(const void* x, const void* add, const float* gamma, const float* beta, void* y, void* sum_out,
+                        float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p, uint64_t seed, int dtype,
+                        void* stream) {
+    LECCR_REQUIRE(x && gamma && beta && y && mean && rstd, LECCR_EINVAL, "layernorm_fwd: null pointer");
+    LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_fwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
+    LECCR_REQUIRE(p >= 0.f && p < 1.f && rows * d < (1ll << 32), LECCR_EINVAL, "layernorm_fwd: dropout p in [0, 1), fewer than 2^32 elements");
+    if (rows == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    DropCfg drop = make_drop(p, seed);
+    if (p == 0.f) drop.thr = 0;
+    const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
+    ProfScope prof(PROF_LN_FWD, (double)rows * d * esz * (2 + (add ? 1 : 0) + (sum_out ? 1 : 0)) + 8.0 * rows, st);
+    DISPATCH_T(dtype, ln_fwd_dispatch<float>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, st),
+               ln_fwd_dispatch<bf16_t>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, st));
+}
+
 extern "C" int leccr_layernorm_fwd(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                                    void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
                                    int dtype, void* stream) {
-    LECCR_REQUIRE(x && gamma && beta && y && mean && rstd, LECCR_EINVAL, "layernorm_fwd: null pointer");
-    LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_fwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
+    return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, 0.f, 0, dtype, stream);
+}
+
+extern "C" int leccr_layernorm_fwd_drop(const void* x, const void* add, const float* gamma, const float* beta, void* y,
+                                        void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p,
+                                        uint64_t seed, int dtype, void* stream) {
+    return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, p, seed, dtype, stream);
+}
+
+static int ln_bwd_entry(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
+                        const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of, void* dx_drop,
+                        float p, uint64_t seed, int64_t rows, int64_t d, int dtype, void* stream) {
+    LECCR_REQUIRE(dy && x_in && gamma && mean && rstd && dx && dgamma && dbeta, LECCR_EINVAL, "layernorm_bwd: null pointer");
+    LECCR_REQUIRE(colsum_of == 0 || (colsum && (colsum_of == 2 || (colsum_of == 1 && dres))), LECCR_EINVAL,
+                  "layernorm_bwd: colsum_of=%d needs colsum (and dres for 1)", colsum_of);
+    LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_bwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
+    LECCR_REQUIRE(!dx_drop || (p >= 0.f && p < 1.f && rows * d < (1ll << 32)), LECCR_EINVAL,
+                  "layernorm_bwd: dropout p in [0, 1), fewer than 2^32 elements");
     if (rows == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
+    const DropCfg drop = make_drop(dx_drop ? p : 0.f, seed);
     const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
-    ProfScope prof(PROF_LN_FWD, (double)rows * d * esz * (2 + (add ? 1 : 0) + (sum_out ? 1 : 0)) + 8.0 * rows, st);
-    DISPATCH_T(dtype, ln_fwd_dispatch<float>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, st),
-               ln_fwd_dispatch<bf16_t>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, st));
+    ProfScope prof(PROF_LN_BWD, (double)rows * d * esz * (3 + (dres ? 1 : 0) + (dx_drop ? 1 : 0)) + 8.0 * rows, st);
+    DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, st),
+               ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, st));
 }
 
 extern "C" int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, const float* mean,
                                    const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
                                    float* colsum, int colsum_of, int64_t rows, int64_t d, int dtype, void* stream) {
-    LECCR_REQUIRE(dy && x_in && gamma && mean && rstd && dx && dgamma && dbeta, LECCR_EINVAL, "layernorm_bwd: null pointer");
-    LECCR_REQUIRE(colsum_of == 0 || (colsum && (colsum_of == 2 || (colsum_of == 1 && dres))), LECCR_EINVAL,
-                  "layernorm_bwd: colsum_of=%d needs colsum (and dres for 1)", colsum_of);
-    LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_bwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
-    if (rows == 0) return LECCR_OK;
-    hipStream_t st = as_stream(stream);
-    const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
-    ProfScope prof(PROF_LN_BWD, (double)rows * d * esz * (3 + (dres ? 1 : 0)) + 8.0 * rows, st);
-    DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, st),
-               ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, st));
+    return ln_bwd_entry(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, nullptr, 0.f, 0, rows, d, dtype, stream);
+}
+
+extern "C" int leccr_layernorm_bwd_drop(const void* dy, const void* x_in, const float* gamma, const float* mean,
+                                        const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                        void* dx_drop, float p, uint64_t seed, int64_t rows, int64_t d, int dtype,
+                                        void* stream) {
+    LECCR_REQUIRE(dx_drop, LECCR_EINVAL, "layernorm_bwd_drop: dx_drop is null");
+    return ln_bwd_entry(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, 0, dx_drop, p, seed, rows, d, dtype, stream);
 }
 
 template <typename T>

@@ -73,7 +73,8 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False):
+def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None):
+    """drop = (p, seed): normalise dropout(x) (+ add) - the mask leccr_dropout(x, p, seed) would apply, inside this pass."""
     x2, rows, d, ld = _rows2d(x)
     assert ld == d
     y = torch.empty_like(x2)
@@ -83,18 +84,31 @@ def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False):
     if add is not None:
         add = add.reshape(rows, d)
         assert add.is_contiguous() and add.dtype == x.dtype
-    check(lib().leccr_layernorm_fwd(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd),
-                                    rows, d, eps, dtype_code(x), stream()), 'leccr_layernorm_fwd')
+    if drop is not None and drop[0] > 0:
+        check(lib().leccr_layernorm_fwd_drop(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd),
+                                             rows, d, eps, float(drop[0]), int(drop[1]), dtype_code(x), stream()),
+              'leccr_layernorm_fwd_drop')
+    else:
+        check(lib().leccr_layernorm_fwd(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd),
+                                        rows, d, eps, dtype_code(x), stream()), 'leccr_layernorm_fwd')
     return y.view(x.shape), mean, rstd, (s.view(x.shape) if s is not None else None)
 
 
-def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None, colsum=None, colsum_of=0):
-    """colsum_of: 1 = colsum += column sums of dres, 2 = of the returned dx (fused bias gradient, see leccr_hip.h)."""
+def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None, colsum=None, colsum_of=0, drop=None):
+    """colsum_of: 1 = colsum += column sums of dres, 2 = of the returned dx (fused bias gradient, see leccr_hip.h).
+    drop = (p, seed): returns (dx, dropout(dx; p, seed)) from one pass."""
     dy2, rows, d, ld = _rows2d(dy)
     assert ld == d and x_in.is_contiguous()
     dx = torch.empty_like(dy2)
     if dres is not None:
         assert dres.is_contiguous() and dres.dtype == dy.dtype
+    if drop is not None:
+        assert not colsum_of
+        dxd = torch.empty_like(dy2)
+        check(lib().leccr_layernorm_bwd_drop(ptr(dy2), ptr(x_in), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                                             ptr(dgamma), ptr(dbeta), ptr(dxd), float(drop[0]), int(drop[1]), rows, d,
+                                             dtype_code(dy), stream()), 'leccr_layernorm_bwd_drop')
+        return dx.view(dy.shape), dxd.view(dy.shape)
     if colsum_of:
         assert colsum is not None and colsum.dtype == torch.float32 and colsum.numel() == d and colsum.is_contiguous()
     check(lib().leccr_layernorm_bwd(ptr(dy2), ptr(x_in), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),

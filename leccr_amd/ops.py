@@ -477,9 +477,8 @@ class BertLayerFn(torch.autograd.Function):
         ao = layer.attention.output
         if ph > 0:      # dense -> dropout -> + residual (inside the LayerNorm kernel)
             a1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8)
-            K.dropout(a1, ph, seeds[1], out=a1)
             x1, mean1, rstd1, s1 = K.layernorm_fwd(a1.view(b, L, d), ao.LayerNorm.weight.data, ao.LayerNorm.bias.data,
-                                                   layer.eps, add=x, want_sum=True)
+                                                   layer.eps, add=x, want_sum=True, drop=(ph, seeds[1]))
         else:
             s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8, residual=_rows(x)).view(b, L, d)
             x1, mean1, rstd1, _ = K.layernorm_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps)
@@ -489,9 +488,8 @@ class BertLayerFn(torch.autograd.Function):
         out = layer.output
         if ph > 0:
             a2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8)
-            K.dropout(a2, ph, seeds[2], out=a2)
             x2, mean2, rstd2, s2 = K.layernorm_fwd(a2.view(b, L, d), out.LayerNorm.weight.data, out.LayerNorm.bias.data,
-                                                   layer.eps, add=x1, want_sum=True)
+                                                   layer.eps, add=x1, want_sum=True, drop=(ph, seeds[2]))
         else:
             s2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8, residual=_rows(x1)).view(b, L, d)
             x2, mean2, rstd2, _ = K.layernorm_fwd(s2, out.LayerNorm.weight.data, out.LayerNorm.bias.data, layer.eps)
@@ -506,18 +504,18 @@ class BertLayerFn(torch.autograd.Function):
         ph, pa, seeds = ctx.drop
         ao, out = layer.attention.output, layer.output
         b, L, d = x.shape
+        # gradient of the sum: the residual path takes it as is (g2), the dense path through the dropout mask (gd2) - both
+        # written by the LayerNorm backward pass
         ds2 = K.layernorm_bwd(dx2.contiguous(), s2, out.LayerNorm.weight.data, mean2, rstd2, out.LayerNorm.weight._g,
-                              out.LayerNorm.bias._g)
-        g2 = _rows(ds2)                                   # gradient of the sum: the residual path takes it as is
-        gd2 = K.dropout(g2, ph, seeds[2]) if ph > 0 else g2   # the dense path takes it through the dropout mask
+                              out.LayerNorm.bias._g, drop=(ph, seeds[2]) if ph > 0 else None)
+        g2, gd2 = (_rows(ds2[0]), _rows(ds2[1])) if ph > 0 else (_rows(ds2), _rows(ds2))
         dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, epilogue=EPI_DGELU, aux=pre, c8_site=_site(layer.intermediate.dense.weight, '_gsite'), want8=True)
         lin_dw(gd2, h, out.dense.weight, out.dense.bias)
         dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
         lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
         ds1 = K.layernorm_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
-                              ao.LayerNorm.bias._g)
-        g1 = _rows(ds1)
-        gd1 = K.dropout(g1, ph, seeds[1]) if ph > 0 else g1
+                              ao.LayerNorm.bias._g, drop=(ph, seeds[1]) if ph > 0 else None)
+        g1, gd1 = (_rows(ds1[0]), _rows(ds1[1])) if ph > 0 else (_rows(ds1), _rows(ds1))
         do = lin_dx(gd1, ao.dense.weight, fp8=layer.fp8).view(b, L, d)
         lin_dw(gd1, _rows(o), ao.dense.weight, ao.dense.bias)
         dqkv = torch.empty_like(qkv)
@@ -554,9 +552,8 @@ class CrossAttnLayerFn(torch.autograd.Function):
         if pd > 0:
             K.dropout(h, pd, seeds[1], out=h)
             l2 = lin_fwd(h, layer.linear2.weight, layer.linear2.bias)
-            K.dropout(l2, pd, seeds[2], out=l2)
             y, mean, rstd, s = K.layernorm_fwd(l2.view(b, Lq, d), layer.norm2.weight.data, layer.norm2.bias.data, 1e-5,
-                                               add=tgt.contiguous(), want_sum=True)
+                                               add=tgt.contiguous(), want_sum=True, drop=(pd, seeds[2]))
         else:
             s = lin_fwd(h, layer.linear2.weight, layer.linear2.bias, residual=_rows(tgt)).view(b, Lq, d)
             y, mean, rstd, _ = K.layernorm_fwd(s, layer.norm2.weight.data, layer.norm2.bias.data, 1e-5)
@@ -575,11 +572,10 @@ class CrossAttnLayerFn(torch.autograd.Function):
         wq, wkv = _Slice(mha.in_proj_weight, 0, d), _Slice(mha.in_proj_weight, d, 3 * d)
         bq, bkv = _Slice(mha.in_proj_bias, 0, d), _Slice(mha.in_proj_bias, d, 3 * d)
         ds = K.layernorm_bwd(dy.contiguous(), s, layer.norm2.weight.data, mean, rstd, layer.norm2.weight._g,
-                             layer.norm2.bias._g)
+                             layer.norm2.bias._g, drop=(pd, seeds[2]) if pd > 0 else None)
         _mark(layer.norm2.weight)
         _mark(layer.norm2.bias)
-        gs = _rows(ds)
-        gd = K.dropout(gs, pd, seeds[2]) if pd > 0 else gs
+        gs, gd = (_rows(ds[0]), _rows(ds[1])) if pd > 0 else (_rows(ds), _rows(ds))
         dpre = lin_dx(gd, layer.linear2.weight, epilogue=EPI_DGELU, aux=pre)      # (g W2) * gelu'(pre) ...
         if pd > 0:
             K.dropout(dpre, pd, seeds[1], out=dpre)                               # ... * dropout mask (both elementwise)

@@ -144,6 +144,33 @@ def test_layernorm(K, dtype, rows, d, eps):
         assert e <= (1e-4 if which == 1 or dtype == torch.float32 else _tol(dtype)) * sc + 1e-4, ('colsum', which, e, sc)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,d', [(512, 768), (77, 1024), (33, 512), (9, 64)])     # 768 / 1024 / 512: 16-byte bf16 forward kernels
+def test_layernorm_with_fused_dropout_equals_the_two_call_sequence(K, dtype, rows, d):
+    """y = LN(dropout(x) + add) and (dx, dropout(dx)) from one LayerNorm pass each: bit-identical to leccr_dropout followed /
+    preceded by the plain LayerNorm calls (post-LN blocks of HF BERT, xvlm.py:238, and CrossAttentionLayer, attention.py:52-54)."""
+    p, seed = 0.1, 0x1234567890ABCDEF
+    x, add = _rand((rows, d), dtype, 26).to(DEV), _rand((rows, d), dtype, 27).to(DEV)
+    g, b = (1 + 0.1 * _rand((d,), torch.float32, 28)).to(DEV), _rand((d,), torch.float32, 29).to(DEV)
+    y, mean, rstd, s = K.layernorm_fwd(x, g, b, 1e-12, add=add, want_sum=True, drop=(p, seed))
+    xd = K.dropout(x, p, seed)
+    assert 0.05 < float((xd == 0).float().mean()) < 0.15
+    y0, mean0, rstd0, s0 = K.layernorm_fwd(xd, g, b, 1e-12, add=add, want_sum=True)
+    for got, want in ((y, y0), (mean, mean0), (rstd, rstd0), (s, s0)):
+        assert torch.equal(got, want)
+    dy, dres = _rand((rows, d), dtype, 30).to(DEV), _rand((rows, d), dtype, 31).to(DEV)
+    dg, db, dg0, db0 = (torch.zeros(d, device=DEV) for _ in range(4))
+    dx, dxd = K.layernorm_bwd(dy, s, g, mean, rstd, dg, db, dres=dres, drop=(p, seed))
+    dx0 = K.layernorm_bwd(dy, s, g, mean, rstd, dg0, db0, dres=dres)
+    assert torch.equal(dx, dx0)
+    assert torch.equal(dxd, K.dropout(dx0, p, seed))
+    live = (x != 0) & (dx0 != 0)
+    assert torch.equal((dxd == 0)[live], (xd == 0)[live])                                 # the forward's mask
+    for got, want in ((dg, dg0), (db, db0)):
+        e, sc = _err(got, want.cpu().double())          # f32 atomics: summation order differs between launches
+        assert e <= 1e-4 * sc + 1e-5
+
+
 def _ref_attn(q, k, v, heads, kmask):
     b, Lq, d = q.shape
     Lk, hd = k.shape[1], d // heads
