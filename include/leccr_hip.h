@@ -148,6 +148,17 @@ int leccr_layernorm_fwd_drop(const void* x, const void* add, const float* gamma,
 int leccr_layernorm_bwd_drop(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
                              const void* dres, void* dx, float* dgamma, float* dbeta, void* dx_drop, float p, uint64_t seed,
                              int64_t rows, int64_t d, int dtype, void* stream);
+/* _ex: the _drop forms (p = 0 / dx_drop = NULL: no dropout) plus an optional fp8 copy of the output for the scaled-MFMA product that
+ * consumes it (compute_dtype 'fp8', "fp8 GEMM operands" below): y8 / g8 [rows, d] bytes (8-byte aligned, d % 8 == 0), quantised under
+ * `site` = {amax, scale, 1/scale, fmt} exactly as leccr_fp8_quantize would quantise the tensor just written (fwd: y, e4m3 activations;
+ * bwd: dx_drop if given else dx, e5m2 gradients), |value| folded into the site's running amax - the separate quantise pass over the
+ * tensor is not needed.  NULL y8 / g8: off. */
+int leccr_layernorm_fwd_ex(const void* x, const void* add, const float* gamma, const float* beta, void* y,
+                           void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p,
+                           uint64_t seed, void* y8, float* y8_site, int y8_fmt, int dtype, void* stream);
+int leccr_layernorm_bwd_ex(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
+                           const void* dres, void* dx, float* dgamma, float* dbeta, void* dx_drop, float p, uint64_t seed,
+                           void* g8, float* g8_site, int g8_fmt, int64_t rows, int64_t d, int dtype, void* stream);
 
 /* ---- Attention --------------------------------------------------------------------------------------------
  * softmax(Q K^T / sqrt(hd) + key mask) V per (batch, head); no materialised score matrix.

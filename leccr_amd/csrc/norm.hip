@@ -5,6 +5,36 @@
 
 namespace leccr {
 
+// Optional second output of the LayerNorm passes: the fp8 copy of the tensor just written, for the scaled-MFMA product that consumes it
+// (compute_dtype 'fp8').  Same arithmetic as leccr_fp8_quantize on the stored tensor: the value is rounded through T first, scaled by
+// site[1], clamped and converted; |value| feeds the site's running amax (one conditional atomic per wave).
+struct Q8Out {
+    uint8_t* out;      // [rows, d] fp8, or nullptr: off
+    float* site;       // {amax, scale, 1/scale, fmt}
+    int fmt;           // 0 e4m3, 1 e5m2
+};
+__device__ __forceinline__ int q8_pack4(const Q8Out& q, float sc, float a, float b, float c, float d) {
+    const float fmax = q.fmt ? 57344.f : 448.f;
+    a = fminf(fmaxf(a * sc, -fmax), fmax);
+    b = fminf(fmaxf(b * sc, -fmax), fmax);
+    c = fminf(fmaxf(c * sc, -fmax), fmax);
+    d = fminf(fmaxf(d * sc, -fmax), fmax);
+    int w = 0;
+    if (q.fmt == 0) {
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    } else {
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, w, false);
+        w = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+    }
+    return w;
+}
+__device__ __forceinline__ void q8_amax(const Q8Out& q, float m) {
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(q.site))
+        atomicMax(reinterpret_cast<unsigned int*>(q.site), __float_as_uint(m));      // m >= 0: float order == unsigned order of the bits
+}
+
 // A wave owns one row; lane l handles the 4-element chunks c = l, l+64, ... (NCH chunks per lane, d <= NCH*256).
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ add,
@@ -12,7 +42,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             T* __restrict__ sum_out, float* __restrict__ mean,
                                                             float* __restrict__ rstd, int64_t rows, int d, float eps,
-                                                            DropCfg drop) {
+                                                            DropCfg drop, Q8Out q8) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -56,29 +86,43 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         mean[row] = mu;
         rstd[row] = rs;
     }
+    const float q8sc = q8.out ? q8.site[1] : 1.f;
+    float q8m = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < d) {
             const f32x4 g = load4(gamma + c), b = load4(beta + c);
-            store4(y + row * d + c, (v[i] - mu) * rs * g + b);
+            const f32x4 o = (v[i] - mu) * rs * g + b;
+            store4(y + row * d + c, o);
+            if (q8.out) {
+                float r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    r[j] = to_f32(from_f32<T>(o[j]));
+                    q8m = fmaxf(q8m, fabsf(r[j]));
+                }
+                *reinterpret_cast<int*>(q8.out + row * d + c) = q8_pack4(q8, q8sc, r[0], r[1], r[2], r[3]);
+            }
         }
     }
+    if (q8.out) q8_amax(q8, q8m);
 }
 
 // Backward.  Grid-stride over rows so each wave accumulates its dgamma/dbeta partials in registers; one LDS reduce
 // per block and one f32 atomic per (block, column).  gamma is re-read per row (L1-resident) and the colsum partials exist only
 // in the CS instantiation: the kernel is bound by how many rows are in flight, i.e. by waves per SIMD (94 registers: 5 waves;
 // 106 with the colsum partials: 4 waves - forcing 5 there spills and costs 75 %).
-template <typename T, int NCH, bool CS>
-__global__ __launch_bounds__(256, NCH <= 3 ? (CS ? 4 : 5) : 1) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xin,
+// EX: the instantiation with the optional second outputs (dropout(dx), fp8 copy); the plain one keeps its 94 registers / 5 waves.
+template <typename T, int NCH, bool CS, bool EX>
+__global__ __launch_bounds__(256, NCH <= 3 ? ((CS || EX) ? 4 : 5) : 1) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xin,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
                                                             T* __restrict__ dx, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ colsum,
                                                             int colsum_of, int64_t rows, int d, T* __restrict__ dx_drop,
-                                                            DropCfg drop) {
+                                                            DropCfg drop, Q8Out q8) {
     __shared__ float red[NCH * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[NCH], db[NCH], dc[CS ? NCH : 1];    // dc: column sums of dres (colsum_of = 1) or of the dx written (2)
@@ -88,6 +132,8 @@ __global__ __launch_bounds__(256, NCH <= 3 ? (CS ? 4 : 5) : 1) void layernorm_bw
         db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (CS) dc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    [[maybe_unused]] float q8sc = 1.f, q8m = 0.f;      // fp8 copy of the gradient the dense layer sees (dx_drop if given, else dx)
+    if constexpr (EX) q8sc = q8.out ? q8.site[1] : 1.f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[NCH], gy[NCH];
@@ -126,14 +172,28 @@ __global__ __launch_bounds__(256, NCH <= 3 ? (CS ? 4 : 5) : 1) void layernorm_bw
                     if (colsum_of == 2) dc[i] += o;
                 }
                 store4(dx + row * d + c, o);
-                if (dx_drop) {      // second output: dropout(dx) with the forward's mask - what leccr_dropout(dx, seed) would write
-                    f32x4 od;
+                if constexpr (EX) {
+                    f32x4 od = o;
+                    if (dx_drop) {      // second output: dropout(dx) with the forward's mask - what leccr_dropout(dx, seed) would write
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) od[j] = to_f32(from_f32<T>(o[j])) * drop_mul(drop, (uint32_t)(row * d + c + j));
-                    store4(dx_drop + row * d + c, od);
+                        for (int j = 0; j < 4; ++j) od[j] = to_f32(from_f32<T>(o[j])) * drop_mul(drop, (uint32_t)(row * d + c + j));
+                        store4(dx_drop + row * d + c, od);
+                    }
+                    if (q8.out) {
+                        float r[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            r[j] = to_f32(from_f32<T>(od[j]));
+                            q8m = fmaxf(q8m, fabsf(r[j]));
+                        }
+                        *reinterpret_cast<int*>(q8.out + row * d + c) = q8_pack4(q8, q8sc, r[0], r[1], r[2], r[3]);
+                    }
                 }
             }
         }
+    }
+    if constexpr (EX) {
+        if (q8.out) q8_amax(q8, q8m);
     }
     // reduce the 4 waves' partials through LDS (one wave at a time), then one f32 atomic per column
     for (int pass = 0; pass < (CS ? 3 : 2); ++pass) {
@@ -192,7 +252,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               bf16_t* __restrict__ y, bf16_t* __restrict__ sum_out,
                                                               float* __restrict__ mean, float* __restrict__ rstd, int64_t rows,
-                                                              int d, float eps, DropCfg drop) {
+                                                              int d, float eps, DropCfg drop, Q8Out q8) {
     const int lane = threadIdx.x & 63;
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (row0 >= rows) return;
@@ -257,6 +317,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
         mean[row0 + lane] = lane == 0 ? mu[0] : mu[R - 1];
         rstd[row0 + lane] = lane == 0 ? rs[0] : rs[R - 1];
     }
+    const float q8sc = q8.out ? q8.site[1] : 1.f;
+    float q8m = 0.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int64_t row = row0 + m.rsel[s];
@@ -271,7 +333,18 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
             o[4 + j] = (v[s][4 + j] - mm) * rr * g1[j] + b1[j];
         }
         store8f(y + row * d + m.col[s], o);
+        if (q8.out) {
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                r[j] = (float)(bf16_t)o[j];
+                q8m = fmaxf(q8m, fabsf(r[j]));
+            }
+            *reinterpret_cast<int2*>(q8.out + row * d + m.col[s]) =
+                int2{q8_pack4(q8, q8sc, r[0], r[1], r[2], r[3]), q8_pack4(q8, q8sc, r[4], r[5], r[6], r[7])};
+        }
     }
+    if (q8.out) q8_amax(q8, q8m);
 }
 
 // (R, NS) of the 16-byte forward kernel for a row of d bf16, or false: the 4-element kernel takes the shape.  (A backward with
@@ -382,14 +455,14 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const bf16_t* __restrict_
 template <typename T>
 static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                            void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
-                           const DropCfg& drop, hipStream_t st) {
+                           const DropCfg& drop, const Q8Out& q8, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         int R = 0, NS = 0;
         if (rows16_shape(d, &R, &NS)) {
             dim3 g16((unsigned)cdiv(cdiv(rows, R), 4));
 #define F16(NS_, R_)                                                                                                     \
     hipLaunchKernelGGL((layernorm_fwd16_kernel<NS_, R_>), g16, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)add, gamma,  \
-                       beta, (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)d, eps, drop)
+                       beta, (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)d, eps, drop, q8)
             if (R == 1 && NS == 1) F16(1, 1); else if (R == 1 && NS == 2) F16(2, 1); else if (R == 1 && NS == 3) F16(3, 1);
             else if (R == 1 && NS == 4) F16(4, 1); else if (R == 2 && NS == 1) F16(1, 2); else if (R == 2 && NS == 3) F16(3, 2);
             else if (R == 2 && NS == 5) F16(5, 2); else R = 0;
@@ -400,7 +473,7 @@ static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, c
     dim3 grid((unsigned)cdiv(rows, 4));
 #define L(N)                                                                                                      \
     hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, (const T*)add, gamma, beta, \
-                       (T*)y, (T*)sum_out, mean, rstd, rows, (int)d, eps, drop)
+                       (T*)y, (T*)sum_out, mean, rstd, rows, (int)d, eps, drop, q8)
     if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
     else if (d <= 2048) L(8); else L(16);
 #undef L
@@ -410,23 +483,25 @@ static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, c
 template <typename T>
 static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, const float* mean, const float* rstd,
                            const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of,
-                           int64_t rows, int64_t d, void* dx_drop, const DropCfg& drop, hipStream_t st) {
+                           int64_t rows, int64_t d, void* dx_drop, const DropCfg& drop, const Q8Out& q8, hipStream_t st) {
     int64_t nb = cdiv(rows, 4);
-    const int64_t resident = colsum_of ? 1024 : 1280;      // 4 / 5 workgroups per CU fit (registers): exactly one round
+    const bool ex = dx_drop != nullptr || q8.out != nullptr;
+    const int64_t resident = (colsum_of || ex) ? 1024 : 1280;      // 4 / 5 workgroups per CU fit (registers): exactly one round
     if (nb > resident) nb = resident;
     dim3 grid((unsigned)nb);
-#define L(N)                                                                                                     \
-    do {                                                                                                         \
-        if (colsum_of)                                                                                           \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, true>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma,  \
-                               mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d, (T*)dx_drop, drop); \
-        else                                                                                                     \
-            hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, false>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma, \
-                               mean, rstd, (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d, (T*)dx_drop, drop); \
+#define LB(N, CS_, EX_)                                                                                                         \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, CS_, EX_>), grid, dim3(256), 0, st, (const T*)dy, (const T*)xin, gamma, mean, rstd, \
+                       (const T*)dres, (T*)dx, dgamma, dbeta, colsum, colsum_of, rows, (int)d, (T*)dx_drop, drop, q8)
+#define L(N)                                     \
+    do {                                         \
+        if (colsum_of) LB(N, true, false);       \
+        else if (ex) LB(N, false, true);         \
+        else LB(N, false, false);                \
     } while (0)
     if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
     else if (d <= 2048) L(8); else L(16);
 #undef L
+#undef LB
     return check_launch("layernorm_bwd");
 }
 
@@ -442,9 +517,18 @@ using namespace leccr;
         return LECCR_EINVAL;                                             \
     } while (0)
 
+static int q8_check(const char* who, void* q8, float* site, int fmt, int64_t d) {
+    if (!q8) return LECCR_OK;
+    LECCR_REQUIRE(site && (fmt == 0 || fmt == 1), LECCR_EINVAL, "%s: the fp8 copy needs its site and fmt 0 (e4m3) / 1 (e5m2)", who);
+    LECCR_REQUIRE((d & 7) == 0 && ((uintptr_t)q8 & 7) == 0, LECCR_EALIGN, "%s: the fp8 copy needs d %% 8 == 0 and an 8-byte aligned buffer", who);
+    return LECCR_OK;
+}
+
 static int ln_fwd_entry(const void* x, const void* add, const float* gamma, const float* beta, void* y, void* sum_out,
-                        float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p, uint64_t seed, int dtype,
-                        void* stream) {
+                        float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p, uint64_t seed, void* y8,
+                        float* y8_site, int y8_fmt, int dtype, void* stream) {
+    if (int rc = q8_check("layernorm_fwd", y8, y8_site, y8_fmt, d)) return rc;
+    const Q8Out q8{(uint8_t*)y8, y8_site, y8_fmt};
     LECCR_REQUIRE(x && gamma && beta && y && mean && rstd, LECCR_EINVAL, "layernorm_fwd: null pointer");
     LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_fwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
     LECCR_REQUIRE(p >= 0.f && p < 1.f && rows * d < (1ll << 32), LECCR_EINVAL, "layernorm_fwd: dropout p in [0, 1), fewer than 2^32 elements");
@@ -454,25 +538,34 @@ static int ln_fwd_entry(const void* x, const void* add, const float* gamma, cons
     if (p == 0.f) drop.thr = 0;
     const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
     ProfScope prof(PROF_LN_FWD, (double)rows * d * esz * (2 + (add ? 1 : 0) + (sum_out ? 1 : 0)) + 8.0 * rows, st);
-    DISPATCH_T(dtype, ln_fwd_dispatch<float>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, st),
-               ln_fwd_dispatch<bf16_t>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, st));
+    DISPATCH_T(dtype, ln_fwd_dispatch<float>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, q8, st),
+               ln_fwd_dispatch<bf16_t>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, q8, st));
 }
 
 extern "C" int leccr_layernorm_fwd(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                                    void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
                                    int dtype, void* stream) {
-    return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, 0.f, 0, dtype, stream);
+    return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, 0.f, 0, nullptr, nullptr, 0, dtype, stream);
 }
 
 extern "C" int leccr_layernorm_fwd_drop(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                                         void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p,
                                         uint64_t seed, int dtype, void* stream) {
-    return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, p, seed, dtype, stream);
+    return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, p, seed, nullptr, nullptr, 0, dtype, stream);
+}
+
+extern "C" int leccr_layernorm_fwd_ex(const void* x, const void* add, const float* gamma, const float* beta, void* y,
+                                      void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p,
+                                      uint64_t seed, void* y8, float* y8_site, int y8_fmt, int dtype, void* stream) {
+    return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, p, seed, y8, y8_site, y8_fmt, dtype, stream);
 }
 
 static int ln_bwd_entry(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
                         const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of, void* dx_drop,
-                        float p, uint64_t seed, int64_t rows, int64_t d, int dtype, void* stream) {
+                        float p, uint64_t seed, void* g8, float* g8_site, int g8_fmt, int64_t rows, int64_t d, int dtype,
+                        void* stream) {
+    if (int rc = q8_check("layernorm_bwd", g8, g8_site, g8_fmt, d)) return rc;
+    const Q8Out q8{(uint8_t*)g8, g8_site, g8_fmt};
     LECCR_REQUIRE(dy && x_in && gamma && mean && rstd && dx && dgamma && dbeta, LECCR_EINVAL, "layernorm_bwd: null pointer");
     LECCR_REQUIRE(colsum_of == 0 || (colsum && (colsum_of == 2 || (colsum_of == 1 && dres))), LECCR_EINVAL,
                   "layernorm_bwd: colsum_of=%d needs colsum (and dres for 1)", colsum_of);
@@ -484,14 +577,14 @@ static int ln_bwd_entry(const void* dy, const void* x_in, const float* gamma, co
     const DropCfg drop = make_drop(dx_drop ? p : 0.f, seed);
     const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
     ProfScope prof(PROF_LN_BWD, (double)rows * d * esz * (3 + (dres ? 1 : 0) + (dx_drop ? 1 : 0)) + 8.0 * rows, st);
-    DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, st),
-               ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, st));
+    DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, q8, st),
+               ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, q8, st));
 }
 
 extern "C" int leccr_layernorm_bwd(const void* dy, const void* x_in, const float* gamma, const float* mean,
                                    const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
                                    float* colsum, int colsum_of, int64_t rows, int64_t d, int dtype, void* stream) {
-    return ln_bwd_entry(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, nullptr, 0.f, 0, rows, d, dtype, stream);
+    return ln_bwd_entry(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, nullptr, 0.f, 0, nullptr, nullptr, 0, rows, d, dtype, stream);
 }
 
 extern "C" int leccr_layernorm_bwd_drop(const void* dy, const void* x_in, const float* gamma, const float* mean,
@@ -499,7 +592,15 @@ extern "C" int leccr_layernorm_bwd_drop(const void* dy, const void* x_in, const 
                                         void* dx_drop, float p, uint64_t seed, int64_t rows, int64_t d, int dtype,
                                         void* stream) {
     LECCR_REQUIRE(dx_drop, LECCR_EINVAL, "layernorm_bwd_drop: dx_drop is null");
-    return ln_bwd_entry(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, 0, dx_drop, p, seed, rows, d, dtype, stream);
+    return ln_bwd_entry(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, 0, dx_drop, p, seed, nullptr, nullptr, 0, rows, d, dtype, stream);
+}
+
+extern "C" int leccr_layernorm_bwd_ex(const void* dy, const void* x_in, const float* gamma, const float* mean,
+                                      const float* rstd, const void* dres, void* dx, float* dgamma, float* dbeta,
+                                      void* dx_drop, float p, uint64_t seed, void* g8, float* g8_site, int g8_fmt,
+                                      int64_t rows, int64_t d, int dtype, void* stream) {
+    return ln_bwd_entry(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, nullptr, 0, dx_drop, p, seed, g8, g8_site, g8_fmt, rows, d,
+                        dtype, stream);
 }
 
 template <typename T>

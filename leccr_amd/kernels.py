@@ -73,8 +73,16 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     return out
 
 
-def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None):
-    """drop = (p, seed): normalise dropout(x) (+ add) - the mask leccr_dropout(x, p, seed) would apply, inside this pass."""
+def _q8_out(site, rows, d, device):
+    """(fp8 buffer, site row pointer, fmt) for a fused fp8 copy under `site`, or (None, None, 0) while the site has no scale yet."""
+    if site is None or not site.primed or d % 8:
+        return None, None, 0
+    return torch.empty(rows, d, device=device, dtype=site.torch_dtype), site.row, site.fmt
+
+
+def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None, q8_site=None):
+    """drop = (p, seed): normalise dropout(x) (+ add) - the mask leccr_dropout(x, p, seed) would apply, inside this pass.
+    q8_site (an Fp8Site): also return y's fp8 copy under that site as a 5th value (None until the site is primed)."""
     x2, rows, d, ld = _rows2d(x)
     assert ld == d
     y = torch.empty_like(x2)
@@ -84,6 +92,13 @@ def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None):
     if add is not None:
         add = add.reshape(rows, d)
         assert add.is_contiguous() and add.dtype == x.dtype
+    if q8_site is not None:
+        y8, site_row, fmt = _q8_out(q8_site, rows, d, x.device)
+        p_, seed_ = (float(drop[0]), int(drop[1])) if drop is not None else (0.0, 0)
+        check(lib().leccr_layernorm_fwd_ex(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd),
+                                           rows, d, eps, p_, seed_, ptr(y8), ptr(site_row), fmt, dtype_code(x), stream()),
+              'leccr_layernorm_fwd_ex')
+        return y.view(x.shape), mean, rstd, (s.view(x.shape) if s is not None else None), y8
     if drop is not None and drop[0] > 0:
         check(lib().leccr_layernorm_fwd_drop(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd),
                                              rows, d, eps, float(drop[0]), int(drop[1]), dtype_code(x), stream()),
@@ -94,14 +109,25 @@ def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None):
     return y.view(x.shape), mean, rstd, (s.view(x.shape) if s is not None else None)
 
 
-def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None, colsum=None, colsum_of=0, drop=None):
+def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None, colsum=None, colsum_of=0, drop=None, q8_site=None):
     """colsum_of: 1 = colsum += column sums of dres, 2 = of the returned dx (fused bias gradient, see leccr_hip.h).
-    drop = (p, seed): returns (dx, dropout(dx; p, seed)) from one pass."""
+    drop = (p, seed): returns (dx, dropout(dx; p, seed)) from one pass.
+    q8_site (an Fp8Site): returns (dx, dropout(dx) or None, g8): g8 = the fp8 copy of dropout(dx) (of dx without drop) under that
+    site, None until the site is primed."""
     dy2, rows, d, ld = _rows2d(dy)
     assert ld == d and x_in.is_contiguous()
     dx = torch.empty_like(dy2)
     if dres is not None:
         assert dres.is_contiguous() and dres.dtype == dy.dtype
+    if q8_site is not None:
+        assert not colsum_of
+        g8, site_row, fmt = _q8_out(q8_site, rows, d, dy.device)
+        dxd = torch.empty_like(dy2) if drop is not None else None
+        p_, seed_ = (float(drop[0]), int(drop[1])) if drop is not None else (0.0, 0)
+        check(lib().leccr_layernorm_bwd_ex(ptr(dy2), ptr(x_in), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                                           ptr(dgamma), ptr(dbeta), ptr(dxd), p_, seed_, ptr(g8), ptr(site_row), fmt, rows, d,
+                                           dtype_code(dy), stream()), 'leccr_layernorm_bwd_ex')
+        return dx.view(dy.shape), (dxd.view(dy.shape) if dxd is not None else None), g8
     if drop is not None:
         assert not colsum_of
         dxd = torch.empty_like(dy2)

@@ -261,6 +261,11 @@ class XVLMBase(nn.Module):
             h._q8 = torch.empty(h._lp.shape, device=dev, dtype=torch.float8_e4m3fn)
             h._q8t = torch.empty(h._lpt.shape, device=dev, dtype=torch.float8_e4m3fn)
 
+        if self.clip_encoder is not None:      # block i's backward output dx is consumed by block i-1's c_proj dX product (ops._g8_give)
+            blocks = list(self.clip_encoder.visual.transformer.resblocks)
+            for prev, blk in zip(blocks[:-1], blocks[1:]):
+                blk._dx_consumer = (prev.mlp.c_proj.weight,)        # a tuple: not registered as this block's parameter
+
         def requantise():
             for h in holders:
                 h._wsite.quantize(h._lp, out=h._q8)

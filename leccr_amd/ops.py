@@ -63,6 +63,55 @@ def _site(w, name):
     return getattr(w, name, None)
 
 
+fuse_fp8_copies = os.environ.get('LECCR_FP8_FUSE_LN', '1') != '0'      # 0: separate quantise passes over the LayerNorm outputs (A/B)
+
+
+def _q8_site(on, rows, w, which):
+    """The site under which a producer (LayerNorm pass) should write the fp8 copy of a tensor that Linear `w` consumes as its
+    activation (which = '_xsite', product against w._q8) or incoming gradient ('_gsite', against w._q8t) - None when that product
+    does not run on the fp8 kernel (same shape rules as _fp8_ok; the producers' outputs are contiguous)."""
+    w8 = getattr(w, '_q8' if which == '_xsite' else '_q8t', None) if (on and fuse_fp8_copies) else None
+    if w8 is None or not (rows >= 256 and w8.shape[0] >= 256 and w8.shape[0] % 32 == 0 and w8.shape[1] % 128 == 0):
+        return None
+    return getattr(w, which, None)
+
+
+def _ln_fwd(x, gamma, beta, eps, site=None, **kw):
+    """K.layernorm_fwd -> (y, mean, rstd, sum or None, y8 or None): with a site (fp8 mode) the pass also writes y's fp8 copy for the
+    product that consumes it - no quantise pass over y."""
+    if site is None:
+        return K.layernorm_fwd(x, gamma, beta, eps, **kw) + (None,)
+    return K.layernorm_fwd(x, gamma, beta, eps, q8_site=site, **kw)
+
+
+def _ln_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, site=None, drop=None, **kw):
+    """K.layernorm_bwd -> (dx, g, g8): g = dropout(dx) with drop = (p, seed), else dx - the gradient the dense layer in front of the
+    residual add sees; g8 = its fp8 copy under `site` (fp8 mode, once the site has a scale), else None."""
+    if site is None:
+        r = K.layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, drop=drop, **kw)
+        return (r[0], r[1], None) if drop is not None else (r, r, None)
+    dx, dxd, g8 = K.layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, drop=drop, q8_site=site, **kw)
+    return dx, (dxd if dxd is not None else dx), g8
+
+
+# fp8 mode, ViT backward: a block's LayerNorm-1 backward writes dx, the gradient the PREVIOUS block's c_proj dX product consumes; its
+# fp8 copy rides along in this one-slot hand-off, keyed by the tensor's address and shape (anything else falls back to a quantise pass)
+_g8_slot = None
+
+
+def _g8_give(t, t8):
+    global _g8_slot
+    _g8_slot = (t.data_ptr(), tuple(t.shape), t8) if t8 is not None else None
+
+
+def _g8_take(t):
+    global _g8_slot
+    slot, _g8_slot = _g8_slot, None
+    if slot is not None and slot[0] == t.data_ptr() and slot[1] == tuple(t.shape):
+        return slot[2]
+    return None
+
+
 def _fp8_ok(x2, w8):
     """The fp8 product exists for the large Linears only (leccr_gemm: M, N >= 256, whole 128-element K-tiles, N % 32 == 0)."""
     return (x2.shape[0] >= 256 and w8.shape[0] >= 256 and w8.shape[0] % 32 == 0 and w8.shape[1] % 128 == 0 and x2.stride(1) == 1
@@ -120,8 +169,9 @@ _wgrad_join_queued = False
 def begin_step():
     """Called at the start of every model forward: a backward pass that raised leaves its end-of-pass join unqueued-but-flagged;
     the next pass must queue its own."""
-    global _wgrad_join_queued
+    global _wgrad_join_queued, _g8_slot
     _wgrad_join_queued = False
+    _g8_slot = None
 
 
 def text_stream(device):
@@ -352,14 +402,17 @@ class ViTBlockFn(torch.autograd.Function):
     def forward(ctx, x, blk, *params):
         b, N, d = x.shape
         M = b * N
-        h1, mean1, rstd1, _ = K.layernorm_fwd(x, blk.ln_1.weight.data, blk.ln_1.bias.data, 1e-5)
-        qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8).view(b, N, 3 * d)
+        # (fp8: the LayerNorm passes also write the e4m3 copy their consumer multiplies - no quantise pass over h1 / h2)
+        h1, mean1, rstd1, _, h1_8 = _ln_fwd(x, blk.ln_1.weight.data, blk.ln_1.bias.data, 1e-5,
+                                            site=_q8_site(blk.fp8, M, blk.attn.in_proj_weight, '_xsite'))
+        qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8, x8=h1_8).view(b, N, 3 * d)
         o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
         x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, residual=_rows(x)).view(b, N, d)
-        h2, mean2, rstd2, _ = K.layernorm_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5)
+        h2, mean2, rstd2, _, h2_8 = _ln_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5,
+                                            site=_q8_site(blk.fp8, M, blk.mlp.c_fc.weight, '_xsite'))
         pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
         # (fp8: the activation's e4m3 copy for c_proj comes out of c_fc's epilogue - no quantise pass over the 4d-wide tensor)
-        act, act8 = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, epilogue=EPI_QUICKGELU, aux_out=pre,
+        act, act8 = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, x8=h2_8, epilogue=EPI_QUICKGELU, aux_out=pre,
                             c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True)
         x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
         ctx.save_for_backward(x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act)
@@ -374,7 +427,9 @@ class ViTBlockFn(torch.autograd.Function):
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
-        dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, epilogue=EPI_DQUICKGELU, aux=pre, c8_site=_site(blk.mlp.c_fc.weight, '_gsite'), want8=True)
+        g2_8 = _g8_take(g2) if blk.fp8 else None          # written by the next block's LayerNorm-1 backward (fp8 mode)
+        dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, g8=g2_8, epilogue=EPI_DQUICKGELU, aux=pre,
+                             c8_site=_site(blk.mlp.c_fc.weight, '_gsite'), want8=True)
         # bias gradients of c_proj / out_proj = column sums of dx2 / dx1.  They ride the weight-gradient stream as 40 us HBM-bound
         # passes beside the dX chain: folded into the LayerNorm backward launches (whose `dres` operands those tensors are) they
         # cost that kernel a fifth of its occupancy - 253 us against 201 us per launch on the main chain
@@ -383,18 +438,22 @@ class ViTBlockFn(torch.autograd.Function):
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
         lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
-        dx1 = K.layernorm_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g,
-                              blk.ln_2.bias._g, dres=dx2)
+        dx1, _, g1_8 = _ln_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g, blk.ln_2.bias._g,
+                               site=_q8_site(blk.fp8, b * N, blk.attn.out_proj.weight, '_gsite'), dres=dx2)
         g1 = _rows(dx1)
-        do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8).view(b, N, d)
+        do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8, g8=g1_8).view(b, N, d)
         lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
         dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8)
         lin_dw(_rows(dqkv), _rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias)
-        dx = K.layernorm_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g,
-                             blk.ln_1.bias._g, dres=dx1)
+        # (fp8: dx is the gradient the previous block's c_proj dX product consumes: its e5m2 copy goes with it)
+        prev = getattr(blk, '_dx_consumer', (None,))[0]
+        dx, _, dx_8 = _ln_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g, blk.ln_1.bias._g,
+                              site=_q8_site(blk.fp8 and prev is not None, b * N, prev, '_gsite'), dres=dx1)
+        if blk.fp8:
+            _g8_give(_rows(dx), dx_8)
         for p in (blk.ln_1.weight, blk.ln_1.bias, blk.ln_2.weight, blk.ln_2.bias):
             _mark(p)
         return (dx, None) + (None,) * 12
@@ -475,15 +534,16 @@ class BertLayerFn(torch.autograd.Function):
         qkv = lin_fwd(_rows(x), layer._qkv_w, layer._qkv_b, fp8=layer.fp8).view(b, L, 3 * d)
         o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask, pa, seeds[0])
         ao = layer.attention.output
+        x1_site = _q8_site(layer.fp8, b * L, layer.intermediate.dense.weight, '_xsite')      # fp8: x1's e4m3 copy out of its LayerNorm pass
         if ph > 0:      # dense -> dropout -> + residual (inside the LayerNorm kernel)
             a1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8)
-            x1, mean1, rstd1, s1 = K.layernorm_fwd(a1.view(b, L, d), ao.LayerNorm.weight.data, ao.LayerNorm.bias.data,
-                                                   layer.eps, add=x, want_sum=True, drop=(ph, seeds[1]))
+            x1, mean1, rstd1, s1, x1_8 = _ln_fwd(a1.view(b, L, d), ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps,
+                                                 site=x1_site, add=x, want_sum=True, drop=(ph, seeds[1]))
         else:
             s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8, residual=_rows(x)).view(b, L, d)
-            x1, mean1, rstd1, _ = K.layernorm_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps)
+            x1, mean1, rstd1, _, x1_8 = _ln_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps, site=x1_site)
         pre = torch.empty(b * L, layer.intermediate.dense.weight.shape[0], device=x.device, dtype=x.dtype)
-        h, h8 = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, epilogue=EPI_GELU,
+        h, h8 = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, x8=x1_8, epilogue=EPI_GELU,
                         aux_out=pre, c8_site=_site(layer.output.dense.weight, '_xsite'), want8=True)
         out = layer.output
         if ph > 0:
@@ -506,17 +566,21 @@ class BertLayerFn(torch.autograd.Function):
         b, L, d = x.shape
         # gradient of the sum: the residual path takes it as is (g2), the dense path through the dropout mask (gd2) - both
         # written by the LayerNorm backward pass
-        ds2 = K.layernorm_bwd(dx2.contiguous(), s2, out.LayerNorm.weight.data, mean2, rstd2, out.LayerNorm.weight._g,
-                              out.LayerNorm.bias._g, drop=(ph, seeds[2]) if ph > 0 else None)
-        g2, gd2 = (_rows(ds2[0]), _rows(ds2[1])) if ph > 0 else (_rows(ds2), _rows(ds2))
-        dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, epilogue=EPI_DGELU, aux=pre, c8_site=_site(layer.intermediate.dense.weight, '_gsite'), want8=True)
+        # written by the LayerNorm backward pass (fp8: with gd2's e5m2 copy)
+        g2, gd2, gd2_8 = _ln_bwd(dx2.contiguous(), s2, out.LayerNorm.weight.data, mean2, rstd2, out.LayerNorm.weight._g,
+                                 out.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, out.dense.weight, '_gsite'),
+                                 drop=(ph, seeds[2]) if ph > 0 else None)
+        g2, gd2 = _rows(g2), _rows(gd2)
+        dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, g8=gd2_8, epilogue=EPI_DGELU, aux=pre,
+                             c8_site=_site(layer.intermediate.dense.weight, '_gsite'), want8=True)
         lin_dw(gd2, h, out.dense.weight, out.dense.bias)
         dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
         lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
-        ds1 = K.layernorm_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
-                              ao.LayerNorm.bias._g, drop=(ph, seeds[1]) if ph > 0 else None)
-        g1, gd1 = (_rows(ds1[0]), _rows(ds1[1])) if ph > 0 else (_rows(ds1), _rows(ds1))
-        do = lin_dx(gd1, ao.dense.weight, fp8=layer.fp8).view(b, L, d)
+        g1, gd1, gd1_8 = _ln_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
+                                 ao.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, ao.dense.weight, '_gsite'),
+                                 drop=(ph, seeds[1]) if ph > 0 else None)
+        g1, gd1 = _rows(g1), _rows(gd1)
+        do = lin_dx(gd1, ao.dense.weight, fp8=layer.fp8, g8=gd1_8).view(b, L, d)
         lin_dw(gd1, _rows(o), ao.dense.weight, ao.dense.bias)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, layer.heads, kmask,

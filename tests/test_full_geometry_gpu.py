@@ -311,10 +311,20 @@ def test_fp8_operand_path_vs_oracle_noise_model():
     rows = grad_rows(model, sd, sd_noise)
     bad = outside_noise_model(rows)
     assert len(rows) > 150 and not bad, (len(bad), bad[:8])
-    # a second step re-uses the delayed scales (update at the start of forward) and stays finite and close
+    # a second step re-uses the delayed scales (update at the start of forward).  From this step on the producers write the fp8 copies
+    # of their outputs themselves - GEMM epilogues (activation / its gradient) and LayerNorm passes (activations forward, gradients
+    # backward, the ViT blocks' hand-off included) - instead of separate quantise passes: the steady state of training, held to the
+    # same rule.  (Gradients do NOT repeat step 1's: a producer quantises its f32 result, the quantise pass the bf16-rounded tensor,
+    # and at fp8 noise levels the lower blocks' gradients are that sensitive - which is what the noise model measures.)
     losses2 = _forward(model, batch)
-    for a, b_ in zip([float(l) for l in losses2], got):
-        assert abs(a - b_) <= 2e-2 * max(1.0, abs(b_)), (got, [float(l) for l in losses2])
+    got2 = [float(l) for l in losses2]
+    for a, r, nz in zip(got2, ref_losses, noise_losses):
+        assert abs(a - r) <= 3 * abs(nz - r) + 1e-2 * max(1.0, abs(r)), (got2, ref_losses, noise_losses)
+    model.arena.zero_grad()
+    sum(losses2).backward()
+    rows2 = grad_rows(model, sd, sd_noise)
+    bad2 = outside_noise_model(rows2)
+    assert len(rows2) > 150 and not bad2, (len(bad2), bad2[:8])
 
 
 def test_persistent_gemm_paths_in_a_model_vs_oracle():
