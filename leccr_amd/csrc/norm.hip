@@ -36,7 +36,8 @@ __device__ __forceinline__ void q8_amax(const Q8Out& q, float m) {
 }
 
 // A wave owns one row; lane l handles the 4-element chunks c = l, l+64, ... (NCH chunks per lane, d <= NCH*256).
-template <typename T, int NCH>
+// EX: the instantiation with the optional extras (dropout on x, fp8 copy of y); the plain one carries none of their code.
+template <typename T, int NCH, bool EX>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ add,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
@@ -54,10 +55,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         const int c = (lane + 64 * i) * 4;
         if (c < d) {
             v[i] = load4(xr + c);
-            if (drop.thr) {     // x = dropout(x): the mask leccr_dropout(x, seed) applies, rounded through T as its output would be
+            if constexpr (EX) {
+                if (drop.thr) {     // x = dropout(x): the mask leccr_dropout(x, seed) applies, rounded through T as its output would be
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    v[i][j] = to_f32(from_f32<T>(v[i][j] * drop_mul(drop, (uint32_t)(row * d + c + j))));
+                    for (int j = 0; j < 4; ++j)
+                        v[i][j] = to_f32(from_f32<T>(v[i][j] * drop_mul(drop, (uint32_t)(row * d + c + j))));
+                }
             }
             if (add) v[i] += load4(add + row * d + c);
             if (sum_out) {
@@ -86,8 +89,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         mean[row] = mu;
         rstd[row] = rs;
     }
-    const float q8sc = q8.out ? q8.site[1] : 1.f;
-    float q8m = 0.f;
+    [[maybe_unused]] float q8sc = 1.f, q8m = 0.f;
+    if constexpr (EX) q8sc = q8.out ? q8.site[1] : 1.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 4;
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
             const f32x4 g = load4(gamma + c), b = load4(beta + c);
             const f32x4 o = (v[i] - mu) * rs * g + b;
             store4(y + row * d + c, o);
-            if (q8.out) {
+            if (EX && q8.out) {
                 float r[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
             }
         }
     }
-    if (q8.out) q8_amax(q8, q8m);
+    if (EX && q8.out) q8_amax(q8, q8m);
 }
 
 // Backward.  Grid-stride over rows so each wave accumulates its dgamma/dbeta partials in registers; one LDS reduce
@@ -247,7 +250,7 @@ __device__ __forceinline__ void store8f(bf16_t* p, const float (&v)[8]) {
     *reinterpret_cast<bf16x8*>(p) = t;
 }
 
-template <int NS, int R>
+template <int NS, int R, bool EX>
 __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ add,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               bf16_t* __restrict__ y, bf16_t* __restrict__ sum_out,
@@ -269,7 +272,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
         if (row < rows) {
             const int64_t o = row * d + m.col[s];
             load8f(x + o, v[s]);
-            if (drop.thr) {
+            if (EX && drop.thr) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[s][j] = (float)(bf16_t)(v[s][j] * drop_mul(drop, (uint32_t)(o + j)));
             }
@@ -317,8 +320,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
         mean[row0 + lane] = lane == 0 ? mu[0] : mu[R - 1];
         rstd[row0 + lane] = lane == 0 ? rs[0] : rs[R - 1];
     }
-    const float q8sc = q8.out ? q8.site[1] : 1.f;
-    float q8m = 0.f;
+    [[maybe_unused]] float q8sc = 1.f, q8m = 0.f;
+    if constexpr (EX) q8sc = q8.out ? q8.site[1] : 1.f;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         const int64_t row = row0 + m.rsel[s];
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
             o[4 + j] = (v[s][4 + j] - mm) * rr * g1[j] + b1[j];
         }
         store8f(y + row * d + m.col[s], o);
-        if (q8.out) {
+        if (EX && q8.out) {
             float r[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
                 int2{q8_pack4(q8, q8sc, r[0], r[1], r[2], r[3]), q8_pack4(q8, q8sc, r[4], r[5], r[6], r[7])};
         }
     }
-    if (q8.out) q8_amax(q8, q8m);
+    if (EX && q8.out) q8_amax(q8, q8m);
 }
 
 // (R, NS) of the 16-byte forward kernel for a row of d bf16, or false: the 4-element kernel takes the shape.  (A backward with
@@ -456,27 +459,40 @@ template <typename T>
 static int ln_fwd_dispatch(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                            void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps,
                            const DropCfg& drop, const Q8Out& q8, hipStream_t st) {
+    const bool ex = drop.thr != 0 || q8.out != nullptr;
     if constexpr (sizeof(T) == 2) {
         int R = 0, NS = 0;
         if (rows16_shape(d, &R, &NS)) {
             dim3 g16((unsigned)cdiv(cdiv(rows, R), 4));
-#define F16(NS_, R_)                                                                                                     \
-    hipLaunchKernelGGL((layernorm_fwd16_kernel<NS_, R_>), g16, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)add, gamma,  \
+#define F16E(NS_, R_, EX_)                                                                                                    \
+    hipLaunchKernelGGL((layernorm_fwd16_kernel<NS_, R_, EX_>), g16, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)add, gamma,  \
                        beta, (bf16_t*)y, (bf16_t*)sum_out, mean, rstd, rows, (int)d, eps, drop, q8)
+#define F16(NS_, R_)                 \
+    do {                             \
+        if (ex) F16E(NS_, R_, true); \
+        else F16E(NS_, R_, false);   \
+    } while (0)
             if (R == 1 && NS == 1) F16(1, 1); else if (R == 1 && NS == 2) F16(2, 1); else if (R == 1 && NS == 3) F16(3, 1);
             else if (R == 1 && NS == 4) F16(4, 1); else if (R == 2 && NS == 1) F16(1, 2); else if (R == 2 && NS == 3) F16(3, 2);
             else if (R == 2 && NS == 5) F16(5, 2); else R = 0;
 #undef F16
+#undef F16E
             if (R) return check_launch("layernorm_fwd");
         }
     }
     dim3 grid((unsigned)cdiv(rows, 4));
-#define L(N)                                                                                                      \
-    hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, dim3(256), 0, st, (const T*)x, (const T*)add, gamma, beta, \
+#define LE(N, EX_)                                                                                                      \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, N, EX_>), grid, dim3(256), 0, st, (const T*)x, (const T*)add, gamma, beta, \
                        (T*)y, (T*)sum_out, mean, rstd, rows, (int)d, eps, drop, q8)
+#define L(N)                  \
+    do {                      \
+        if (ex) LE(N, true);  \
+        else LE(N, false);    \
+    } while (0)
     if (d <= 256) L(1); else if (d <= 512) L(2); else if (d <= 768) L(3); else if (d <= 1024) L(4);
     else if (d <= 2048) L(8); else L(16);
 #undef L
+#undef LE
     return check_launch("layernorm_fwd");
 }
 

@@ -9,6 +9,8 @@ Extensions (all optional, defaults reproduce the reference's hard-coded choices)
                            the ViT blocks and BERT layers; LayerNorm, softmax, residuals, weight gradients, heads and losses as in bf16)
   config['clip_text_tower'] keep the unused CLIP text tower's parameters for state_dict compatibility (default True)
 """
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -251,7 +253,7 @@ class XVLMBase(nn.Module):
             for blk in self.clip_encoder.visual.transformer.resblocks:
                 blk.fp8 = True
                 holders += [blk.attn.in_proj_weight, blk.attn.out_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight]
-        for layer in self.text_encoder.encoder.layer:
+        for layer in (self.text_encoder.encoder.layer if os.environ.get('LECCR_FP8_TEXT', '1') != '0' else []):
             layer.fp8 = True
             holders += [layer._qkv_w, layer.attention.output.dense.weight, layer.intermediate.dense.weight, layer.output.dense.weight]
         self.fp8_sites = sites = Fp8Sites(dev, 3 * len(holders) + 8)

@@ -275,15 +275,17 @@ def test_config_e_geometry_vit_l14_xlmr_large_vs_oracle(dtype):
     assert not bad, (len(bad), bad[:8])
 
 
-def test_fp8_operand_path_vs_oracle_noise_model():
+@pytest.mark.parametrize('fuse_ln', [False, True])
+def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, monkeypatch):
     """compute_dtype 'fp8' (BASELINE configs[4]: "fp8 MFMA"): the ViT-L/14 + XLM-R-large shaped model (two layers each, b = 8 so
     that every encoder Linear has >= 256 rows and takes the fp8 kernel) with e4m3 activations / weights in the forward products and
     e5m2 gradients in the dX products.  Held against the fp32 oracle through the oracle's OWN fp8 operand model (oracle.lowp(fp8=
     True): the same per-tensor power-of-two scaling and formats at the same Linears): losses within 3x what that model moves them,
     every parameter gradient within 3x its noise."""
-    from leccr_amd import _lib
+    from leccr_amd import _lib, ops
     from leccr_amd.models import RetrievalModel
     from leccr_amd.synthetic import MULTI30K_CFG, make_batch
+    monkeypatch.setattr(ops, 'fuse_fp8_copies', fuse_ln)      # LECCR_FP8_FUSE_LN: fp8 copies out of the LayerNorm passes (step 2 on)
     torch.manual_seed(17)
     model = RetrievalModel(dict(MULTI30K_CFG, clip_geometry=L14_GEOMETRY, text_config=dict(XLMR_LARGE_2L, vocab_size=30000),
                                 compute_dtype='fp8', clip_text_tower=False))
