@@ -12,8 +12,9 @@ A step = RetrievalModel.forward (ViT-B/16 @384 + mBERT + caption interaction + 5
 all-reduce + fused AdamW + LR schedule on one synthetic Multi30K-shaped batch that is already resident in HBM
 (BASELINE.json configs[1]: bf16, batch 256 per GPU, 1xMI355X; weak scaling: the per-GPU batch is fixed, the contrastive
 batch is all-gathered across ranks).  Prints ONE JSON line on rank 0 with the metric, a `roofline` object for the
-dominant kernel family (bf16 MFMA GEMMs, timed with hipEvents on the launch stream), an `hbm_kernels` list (achieved TB/s of
-the bandwidth-bound launches), a `parity` object (the same weights on a 2-row slice against the CPU oracle) and a
+dominant kernel family (bf16 MFMA GEMMs, timed with hipEvents on the launch stream in legs run AFTER the timed region - the timed
+region itself runs with the event profiler off), an `hbm_kernels` list (achieved TB/s of the bandwidth-bound launches), a `parity`
+object (the same weights on a 16-row slice against the CPU oracle: features, logits, losses, ground-truth ranks) and a
 `cpu_baseline` object (the CPU oracle timed on this host: BASELINE config A, bounded sample).
 
 Other workloads (not the headline line): --model video (the reference's MSR-VTT geometry: 4096-wide frame features, F = 8)
@@ -233,37 +234,92 @@ def cpu_baseline(args, cfg, model):
             's_per_step': round(t, 3), 'step_times_s': [round(x, 2) for x in times]}
 
 
-def parity_probe(args, cfg, model, batch, fwd, rows=2):
-    """After the timed region: the HIP model (the benchmarked weights, eval mode = dropout off) on rows [0, rows) of the
-    batch against the CPU oracle (fp32) on the same weights and inputs - the five losses."""
+def _sub_batch(batch, rows):
     import torch
-    was_training = model.training
-    model.eval()
     sub = {k: (v[:rows] if torch.is_tensor(v) else v) for k, v in batch.items()}
     sub['text'] = [type(t)(t.input_ids[:rows], t.attention_mask[:rows]) for t in batch['text']]
     sub['captions'] = type(batch['captions'])(batch['captions'].input_ids[:rows], batch['captions'].attention_mask[:rows])
+    return sub
+
+
+def parity_probe(args, cfg, model, batch, fwd, rows=16, with_losses=True):
+    """After the timed region: the HIP model (the benchmarked weights, eval mode = dropout off) on rows [0, rows) of the batch against
+    the CPU oracle (fp32) on the same weights and inputs.  What north_star bounds is the LOGITS, so that is what is compared: the
+    three L2-normalised feature matrices (image after the caption interaction, source text, target text: models/xvlm.py:241-256) and
+    the three rows x rows logits matrices feat_a feat_b^T / temp of get_contrastive_loss (models/xvlm.py:273-276), max-abs error each;
+    the five losses beside them (at a handful of rows and random-init towers the contrastive terms sit near ln(rows) whatever the
+    encoders do - they are the weak part of the probe, the features are the strong one).  with_losses=False (W > 1): the model's
+    forward gathers across ranks, so only the collective-free encoder / feature / logits part runs, on this rank's rows.
+    Also the R@K half on the same rows: the integer rank of every ground-truth pair from the HIP encoders' score matrix against the
+    ranks from the ORACLE encoders' score matrix (image_Retrieval_caption.py:151-152, 261-317)."""
+    import numpy as np
+    import torch
+    from oracle import leccr_oracle as O
+    was_training = model.training
+    model.eval()
+    rows = min(rows, batch['idx'].shape[0])
+    sub = _sub_batch(batch, rows)
+    feats = None
     with torch.no_grad():
-        got = [float(l) for l in fwd(model, sub)]
+        if args.model == 'image':
+            cap_ids, cap_m = sub['captions'].input_ids, sub['captions'].attention_mask
+            v, _ = model.get_vision_embeds(sub['image'])
+            c = model.get_caption_embeds(cap_ids, cap_m)
+            a_img, _, _ = model.interaction_with_caption(image_embeds=v, caption_embeds=c, key_padding_mask=~cap_m.bool())
+            feats = [model.get_features(a_img.transpose(0, 1).contiguous(), None)]
+            feats += [model.get_features(None, model.get_text_embeds(t.input_ids, t.attention_mask)) for t in sub['text']]
+            feats = [f.float().cpu().double() for f in feats]
+        got = [float(l) for l in fwd(model, sub)] if with_losses else None
     model.train(was_training)
     cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in sub.items()}
     cpu['text'] = [t.to('cpu') for t in sub['text']]
     cpu['captions'] = sub['captions'].to('cpu')
     torch.set_num_threads(host_cores()[0])
+    sd = _oracle_state(model)
+    heads = 16 if args.text == 'xlmr-large' else 12
+    out = {'rows': rows}
+    ok = True
     with torch.no_grad():
-        ref = [float(l) for l in _oracle_losses(args, cfg, _oracle_state(model), cpu, rows)]
-    err = max(abs(a - r) for a, r in zip(got, ref))
-    tol = {'fp32': 1e-3, 'bf16': 3e-2, 'fp8': 1e-1}[args.dtype]
-    return {'rows': rows, 'max_abs_loss_err': round(err, 6), 'tolerance': tol, 'ok': bool(err <= tol),
-            'losses_hip': [round(x, 5) for x in got], 'losses_oracle_fp32': [round(x, 5) for x in ref],
-            'what': f'{args.dtype} HIP path (eval mode) vs CPU oracle fp32, same weights (after the timed steps) and inputs, '
-                    f'full {args.clip}@384 + {args.text} geometry'}
+        if feats is not None:
+            vis = O.encode_image(sd, 'clip_encoder.visual.', cpu['image'])
+            cap = O.bert_forward(sd, 'text_encoder.', cpu['captions'].input_ids, cpu['captions'].attention_mask, heads)
+            a_img, _, _ = O.interaction_with_caption(sd, vis, cap, ~cpu['captions'].attention_mask.bool())
+            ref = [O.get_features(sd, image_embeds=a_img)]
+            ref += [O.get_features(sd, text_embeds=O.bert_forward(sd, 'text_encoder.', t.input_ids, t.attention_mask, heads)) for t in cpu['text']]
+            ref = [f.double() for f in ref]
+            temp = float(sd['temp'])
+            ferr = [float((a - r).abs().max()) for a, r in zip(feats, ref)]
+            pairs = ((0, 1), (0, 2), (1, 2))                 # v-s, v-t, s-t: the three get_contrastive_loss calls of a step
+            lerr = [float(((feats[i] @ feats[j].t()) / temp - (ref[i] @ ref[j].t()) / temp).abs().max()) for i, j in pairs]
+            ftol, ltol = {'fp32': (1e-4, 1e-3), 'bf16': (2e-2, 0.3), 'fp8': (6e-2, 1.0)}[args.dtype]
+            out.update(max_abs_feature_err={'image': round(ferr[0], 7), 'text_src': round(ferr[1], 7), 'text_tgt': round(ferr[2], 7)},
+                       max_abs_logits_err={'v_s': round(lerr[0], 6), 'v_t': round(lerr[1], 6), 's_t': round(lerr[2], 6)},
+                       feature_tolerance=ftol, logits_tolerance=ltol, temp=round(temp, 6))
+            ok = ok and max(ferr) <= ftol and max(lerr) <= ltol
+            # retrieval on these rows: rank of the ground-truth pair, HIP encoders vs oracle encoders (count of strictly larger scores)
+            s_hip, s_ref = (feats[0] @ feats[2].t()).numpy(), (ref[0] @ ref[2].t()).numpy()
+            rk = lambda s_: np.array([int((s_[i] > s_[i, i]).sum()) for i in range(rows)])
+            same = int((rk(s_hip) == rk(s_ref)).sum() + (rk(s_hip.T) == rk(s_ref.T)).sum())
+            out['gt_ranks_equal_to_oracle_encoders'] = f'{same}/{2 * rows}'
+        if with_losses:
+            ref_l = [float(l) for l in _oracle_losses(args, cfg, sd, cpu, rows)]
+            err = max(abs(a - r) for a, r in zip(got, ref_l))
+            tol = {'fp32': 1e-3, 'bf16': 3e-2, 'fp8': 1e-1}[args.dtype]
+            out.update(max_abs_loss_err=round(err, 6), tolerance=tol, losses_hip=[round(x, 5) for x in got],
+                       losses_oracle_fp32=[round(x, 5) for x in ref_l])
+            ok = ok and err <= tol
+    out['ok'] = bool(ok)
+    out['what'] = (f'{args.dtype} HIP path (eval mode) vs CPU oracle fp32, same weights (after the timed steps) and inputs, full '
+                   f'{args.clip}@384 + {args.text} geometry; north_star bound: logits within 1e-3 in fp32')
+    return out
 
 
 def retrieval_probe(args, model, batch):
     """The R@K half of the metric on what this run has: the benchmarked weights (random init: recall is at chance level - there is
     no dataset and no pretrained checkpoint on this pipeline), the batch's 256 image / target-text pairs as a
     retrieval set.  What it checks is the integer ranking: itm_eval's 13 numbers from the on-device rank kernel equal the CPU
-    oracle's on the same score matrix (image_Retrieval_caption.py:261-317)."""
+    oracle's on the same score matrix (image_Retrieval_caption.py:261-317).  (Encoder-level ranking parity - HIP encoders' scores
+    against the oracle encoders' scores - is in the parity probe above on 16 rows, and at 64 x 320 in tests/test_eval_gpu.py.)"""
     import numpy as np
     import torch
     from leccr_amd import kernels as K
@@ -339,25 +395,43 @@ def _main(args, real_stdout):
     for _ in range(args.warmup):
         train_step(model, batch, fwd, opt, sched)
     lib = _lib.lib()
+    # The timed region runs with the in-library event profiler OFF (round 2 timed it with two hipEvents around each of ~700 launches
+    # per step); K + 1 stream events mark the step boundaries for the median (no host sync inside the region).
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     barrier()
-    lib.leccr_prof_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         losses = train_step(model, batch, fwd, opt, sched)
+        marks[i + 1].record()
     barrier()
     dt = time.perf_counter() - t0
-    lib.leccr_prof_enable(0)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if world > 1:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     NK = 11
     ms, work, n = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
-    lib.leccr_prof_read_n(NK, ms, work, n)
-    # GEMM busy time = union of the launch intervals (HIP events on the launch streams): the weight-gradient GEMMs run on a
-    # second stream beside the dX chain, so summing per-launch durations would count the overlapped stretches twice
     busy, gwork, gn = C.c_double(), C.c_double(), C.c_int64()
-    lib.leccr_prof_read_union(0b11, C.byref(busy), C.byref(gwork), C.byref(gn))
+    prof_steps = args.roofline_steps if args.roofline_steps > 0 else 0
+    prof_ms_per_step, dropped = None, 0
+    if prof_steps:
+        # Profiled leg, SAME schedule as the timed region (side streams, fused update), event profiler ON: the union of the GEMM launch
+        # intervals over all streams (weight-gradient GEMMs run beside the dX chain: summing durations would count the overlapped
+        # stretches twice) and the cost of the profiler itself, as the A/B against the unprofiled timed region.
+        barrier()
+        lib.leccr_prof_enable(1)
+        tp = time.perf_counter()
+        for _ in range(prof_steps):
+            train_step(model, batch, fwd, opt, sched)
+        barrier()
+        prof_ms_per_step = (time.perf_counter() - tp) * 1e3 / prof_steps
+        lib.leccr_prof_enable(0)
+        dropped += int(lib.leccr_prof_dropped())
+        lib.leccr_prof_read_n(NK, ms, work, n)
+        lib.leccr_prof_read_union(0b11, C.byref(busy), C.byref(gwork), C.byref(gn))
     # Roofline leg: the same steps with every launch on ONE stream, so that a launch's event interval is the kernel running
     # alone (in the timed region above a dW GEMM shares the chip with the dX chain, and its own interval is stretched by that).
     ms1, work1, n1 = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
@@ -370,17 +444,20 @@ def _main(args, real_stdout):
             train_step(model, batch, fwd, opt, sched)
         barrier()
         lib.leccr_prof_enable(0)
+        dropped += int(lib.leccr_prof_dropped())
         lib.leccr_prof_read_n(NK, ms1, work1, n1)
         ops.wgrad_overlap, ops.text_overlap = overlap
         opt.backward_fusion = fusion
         leg, leg_ms, leg_work, leg_n = args.roofline_steps, ms1, work1, n1
     else:
-        leg, leg_ms, leg_work, leg_n = args.steps, ms, work, n
+        leg, leg_ms, leg_work, leg_n = 1, ms1, work1, n1              # (no profiled leg at all: the roofline object reports zeros)
     parity = None
     retrieval = None
-    if world == 1 and not args.no_parity:          # (the model's forward gathers across ranks: a one-rank probe would hang W > 1)
-        parity = parity_probe(args, cfg, model, batch, fwd)
-        if args.model == 'image':
+    if not args.no_parity and (world == 1 or (rank == 0 and args.model == 'image')):
+        # W > 1: the model's forward gathers across ranks, so rank 0 runs only the collective-free part on its own rows (encoders ->
+        # features -> logits against the oracle); the five losses are compared on one rank only
+        parity = parity_probe(args, cfg, model, batch, fwd, with_losses=world == 1)
+        if args.model == 'image' and world == 1:
             retrieval = retrieval_probe(args, model, batch)
     if rank == 0:
         G = args.batch * world
@@ -399,7 +476,7 @@ def _main(args, real_stdout):
             traffic, traffic_src = round(tr['hbm_bytes_per_launch']), 'profiles/' + os.path.basename(tj)
         hbm = []
         for k, name in enumerate(HBM_KINDS, start=5):
-            if leg_n[k]:
+            if leg_n[k] and leg_ms[k] > 0:
                 tbs = leg_work[k] / (leg_ms[k] * 1e-3) / 1e12
                 hbm.append({'kernel': name, 'launches_per_step': leg_n[k] // leg, 'ms_per_step': round(leg_ms[k] / leg, 3),
                             'algorithmic_gb_per_step': round(leg_work[k] / leg / 1e9, 3), 'achieved_tb_s': round(tbs, 3),
@@ -413,6 +490,7 @@ def _main(args, real_stdout):
             'metric': 'image-text pairs/sec (train step)' if args.model == 'image' else 'video-text pairs/sec (train step)',
             'value': round(value, 2), 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3),
+            'ms_per_step_median': round(median_ms, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f'{what}, {args.dtype}, batch {args.batch}/GPU (global {G}), L_t=32, L_c=64, train mode '
                                    f'(dropout 0.1 on), full step (fwd+bwd+all-gather+all-reduce+AdamW)',
@@ -433,8 +511,11 @@ def _main(args, real_stdout):
                                     'after the timed region (same process, same tensors): each interval is the kernel alone. In the timed '
                                     'region the dW launches and the text towers share the chip with the image tower / dX chain on side streams')
                                    if args.roofline_steps > 0 else 'HIP events around every GEMM launch of the timed region',
-                         'timed_region_gemm_tflops_union': round(union_fl / (union_ms * 1e-3) / 1e12, 1) if union_ms > 0 else None,
-                         'timed_region_gemm_busy_share': round(union_ms / (dt * 1e3), 3),
+                         'overlapped_gemm_tflops_union': round(union_fl / (union_ms * 1e-3) / 1e12, 1) if union_ms > 0 else None,
+                         'overlapped_gemm_busy_share': round(union_ms / (prof_ms_per_step * prof_steps), 3) if prof_steps else None,
+                         'profiler': {'timed_region': 'off', 'ms_per_step_profiler_off': round(dt / args.steps * 1e3, 3),
+                                      'ms_per_step_profiler_on': round(prof_ms_per_step, 3) if prof_steps else None,
+                                      'records_dropped': dropped},
                          'gemm_ms_per_step': round(gemm_ms / leg, 3),
                          'attn_fwd_ms_per_step': round(leg_ms[3] / leg, 3), 'attn_bwd_ms_per_step': round(leg_ms[4] / leg, 3),
                          'attn_fwd_tflops': round(leg_work[3] / (leg_ms[3] * 1e-3) / 1e12, 1) if leg_ms[3] > 0 else None,

@@ -56,6 +56,8 @@ int leccr_prof_read_n(int n, double* ms, double* work, int64_t* launches);
 /* The launches of the kinds in kind_mask (bit k = index k above) as one busy time: the union of their [start, stop]
  * intervals (launches that overlap on two streams are not counted twice), their total work and count. */
 int leccr_prof_read_union(int kind_mask, double* busy_ms, double* work, int64_t* launches);
+int64_t leccr_prof_dropped(void);              /* launches since leccr_prof_enable(1) that found the record buffer (131 072
+                                                * entries) full and were not timed: the read-outs undercount when > 0 */
 
 /* ---- GEMM -------------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )      (+ C if accumulate)
@@ -236,16 +238,19 @@ int leccr_l2norm_bwd(const void* dy, const void* y, const float* inv_norm, void*
  *   sim_infonce_rows (one direction, no temperature).
  * capreg: caption_regularization (model_retrieval_caption.py:65-73): mean(c_hat c_hat^T - I), c [b,n,d].
  */
+/* temp_dev (the four temperature-taking calls): NULL = use the host value `temp`; else a DEVICE pointer to the temperature
+ * (the learnable scalar XVLMBase.temp, models/xvlm.py:177), read by the kernels at run time - `temp` is then ignored and the
+ * training step needs no host read of a device scalar (the reference's `/ self.temp` is a device op too). */
 int leccr_sim_infonce_fwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
-                          int both_dirs, float* loss, float* ws, void* stream);
+                          int both_dirs, float* loss, float* ws, const float* temp_dev, void* stream);
 int leccr_sim_infonce_bwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
                           int both_dirs, const float* ws, float gscale, float* da, float* db, float* dtemp,
-                          int64_t row0, int64_t nrows, void* stream);
+                          int64_t row0, int64_t nrows, const float* temp_dev, void* stream);
 int leccr_capsim_fwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D, float* loss,
-                     int32_t* argmax, float* ws, void* stream);
+                     int32_t* argmax, float* ws, const float* temp_dev, void* stream);
 int leccr_capsim_bwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D,
                      const int32_t* argmax, const float* ws, float gscale, float* dc, float* dt, float* dtemp,
-                     void* stream);
+                     const float* temp_dev, void* stream);
 int leccr_dstl_fwd(const float* v, const float* c, const float* s, const float* t, float alpha, int64_t G,
                    int64_t n, int64_t D, float* loss, float* ws, void* stream);
 int leccr_dstl_bwd(const float* v, const float* t, int64_t G, int64_t D, const float* ws, float gscale, float* dv,

@@ -38,6 +38,7 @@ _SIGS = {
     'leccr_prof_read': ([C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
     'leccr_prof_read_n': ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
     'leccr_prof_read_union': ([C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)], C.c_int),
+    'leccr_prof_dropped': ([], C.c_int64),
     'leccr_gemm': ([C.POINTER(GemmParams), vp], C.c_int),
     'leccr_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, vp], C.c_int),
     'leccr_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, i64, C.c_int, vp], C.c_int),
@@ -59,10 +60,10 @@ _SIGS = {
     'leccr_fp8_quantize': ([vp, vp, i64, i64, i64, i64, C.c_int, C.c_int, vp, vp], C.c_int),
     'leccr_l2norm_fwd': ([vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),
     'leccr_l2norm_bwd': ([vp, vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),
-    'leccr_sim_infonce_fwd': ([vp, vp, vp, f32, i64, i64, C.c_int, vp, vp, vp], C.c_int),
-    'leccr_sim_infonce_bwd': ([vp, vp, vp, f32, i64, i64, C.c_int, vp, f32, vp, vp, vp, i64, i64, vp], C.c_int),
-    'leccr_capsim_fwd': ([vp, vp, f32, i64, i64, i64, vp, vp, vp, vp], C.c_int),
-    'leccr_capsim_bwd': ([vp, vp, f32, i64, i64, i64, vp, vp, f32, vp, vp, vp, vp], C.c_int),
+    'leccr_sim_infonce_fwd': ([vp, vp, vp, f32, i64, i64, C.c_int, vp, vp, vp, vp], C.c_int),
+    'leccr_sim_infonce_bwd': ([vp, vp, vp, f32, i64, i64, C.c_int, vp, f32, vp, vp, vp, i64, i64, vp, vp], C.c_int),
+    'leccr_capsim_fwd': ([vp, vp, f32, i64, i64, i64, vp, vp, vp, vp, vp], C.c_int),
+    'leccr_capsim_bwd': ([vp, vp, f32, i64, i64, i64, vp, vp, f32, vp, vp, vp, vp, vp], C.c_int),
     'leccr_dstl_fwd': ([vp, vp, vp, vp, f32, i64, i64, i64, vp, vp, vp], C.c_int),
     'leccr_dstl_bwd': ([vp, vp, i64, i64, vp, f32, vp, vp, i64, i64, vp], C.c_int),
     'leccr_cvpool_fwd': ([vp, vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),

@@ -52,7 +52,8 @@ __global__ void fp8_update_kernel(float* __restrict__ sites, int64_t n) {
     if (amax > 0.f && isfinite(amax)) {
         const float fmax = s[3] != 0.f ? 57344.f : 448.f;
         // a power of two: scaling is then exact in bf16 / f32, and the headroom (< 2x) absorbs next step's growth
-        const float sc = exp2f(floorf(log2f(fmax / amax)));
+        // exponent clamped so that sc and 1 / sc stay finite and normal for a (nearly) all-zero tensor (amax ~ 1e-38: fmax / amax = inf)
+        const float sc = exp2f(fminf(floorf(log2f(fmax) - log2f(amax)), 100.f));
         s[1] = sc;
         s[2] = 1.f / sc;
     }

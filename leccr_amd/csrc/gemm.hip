@@ -426,7 +426,17 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     const leccr_gemm_params& p = *pp;
     LECCR_REQUIRE(p.A && p.B && p.C, LECCR_EINVAL, "gemm: null operand");
     LECCR_REQUIRE(p.M >= 0 && p.N >= 0 && p.K >= 0, LECCR_EINVAL, "gemm: negative size");
-    if (p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A) {
+    // checks every operand format shares (they used to sit below the fp8 branch, which returned before reaching them)
+    LECCR_REQUIRE(p.lda >= (p.trans_a ? p.M : p.K) && p.ldb >= (p.trans_b ? p.N : p.K) && p.ldc >= p.N, LECCR_EINVAL,
+                  "gemm: leading dimension smaller than the row length");
+    LECCR_REQUIRE(!(p.aux && p.ldaux < p.N) && !(p.residual && p.ldr < p.N), LECCR_EINVAL,
+                  "gemm: ldaux / ldr smaller than the row length");
+    if ((p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU))
+        LECCR_REQUIRE(p.aux != nullptr, LECCR_EINVAL, "gemm: derivative epilogue needs aux");
+    const bool fp8_ab = p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A;
+    LECCR_REQUIRE(fp8_ab || (p.alpha_dev[0] == nullptr && p.alpha_dev[1] == nullptr), LECCR_EINVAL,
+                  "gemm: alpha_dev (device-side operand scales) exists for fp8 operands only");
+    if (fp8_ab) {
         // fp8 MFMA GEMM inputs: only the 4-wave 256x256 kernel has them (no generic / small-shape fp8 path: callers keep those in bf16)
         LECCR_REQUIRE(gemm256w4_fp8_legal(p), LECCR_EINVAL, "gemm: fp8 operands need trans_a = trans_b = 0, a bf16 C, M, N >= 256, K %% 128 == 0, "
                       "16-byte aligned rows and a compiled epilogue");
@@ -442,10 +452,6 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     LECCR_REQUIRE(p.c8 == nullptr, LECCR_EINVAL, "gemm: c8 (fused fp8 copy of C) exists for fp8 operands only");
     LECCR_REQUIRE(p.c_dtype == LECCR_F32 || p.c_dtype == LECCR_BF16, LECCR_EINVAL, "gemm: bad c_dtype");
     LECCR_REQUIRE(!(p.accumulate && p.c_dtype != LECCR_F32), LECCR_EINVAL, "gemm: accumulate needs an f32 C");
-    LECCR_REQUIRE(p.lda >= (p.trans_a ? p.M : p.K) && p.ldb >= (p.trans_b ? p.N : p.K) && p.ldc >= p.N, LECCR_EINVAL,
-                  "gemm: leading dimension smaller than the row length");
-    if ((p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU))
-        LECCR_REQUIRE(p.aux != nullptr, LECCR_EINVAL, "gemm: derivative epilogue needs aux");
     if (p.M == 0 || p.N == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     LECCR_REQUIRE(!(p.colsum && p.accumulate), LECCR_EINVAL, "gemm: colsum with accumulate is not defined");

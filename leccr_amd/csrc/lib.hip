@@ -28,13 +28,15 @@ int check_launch(const char* what) {
 
 // ---- profiling: event pairs around selected launches, summed per kind on read ---------------------------------
 static bool g_prof_on = false;
-static constexpr int kProfCap = 1 << 15;
+static constexpr int kProfCap = 1 << 17;       // 131 072 launches per window (~50 steps of the config-E model)
+static int64_t g_prof_dropped = 0;              // launches of the current window that found the buffer full
 struct ProfRec { hipEvent_t a, b; int kind; double work; };
 static ProfRec* g_prof = nullptr;
 static int g_prof_n = 0;
 
 ProfScope::ProfScope(int kind, double work, hipStream_t stream) : slot(-1), st(stream) {
-    if (!g_prof_on || g_prof_n >= kProfCap) return;
+    if (!g_prof_on) return;
+    if (g_prof_n >= kProfCap) { ++g_prof_dropped; return; }
     slot = g_prof_n++;
     ProfRec& r = g_prof[slot];
     if (!r.a) {
@@ -54,9 +56,12 @@ extern "C" int leccr_prof_enable(int on) {
     using namespace leccr;
     if (on && !g_prof) g_prof = static_cast<ProfRec*>(calloc(kProfCap, sizeof(ProfRec)));
     g_prof_on = on != 0;
-    if (on) g_prof_n = 0;
+    if (on) { g_prof_n = 0; g_prof_dropped = 0; }
     return LECCR_OK;
 }
+
+// Launches of the current window that were NOT recorded because the buffer was full (0 = the read-outs are complete).
+extern "C" int64_t leccr_prof_dropped(void) { return leccr::g_prof_dropped; }
 
 // ms[k], work[k] (FLOPs), launches[k] for k < 5 (gemm_nt, gemm_tn, gemm_generic, attn_fwd, attn_bwd). Synchronises.
 extern "C" int leccr_prof_read(double* ms, double* work, int64_t* launches) {

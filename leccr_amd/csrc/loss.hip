@@ -61,8 +61,14 @@ constexpr int kScoreKC = 256;
 template <int MODE>
 __global__ __launch_bounds__(256) void f32_nt_tile_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                           int64_t ldb, float* __restrict__ C, int64_t ldc, int M, int N,
-                                                          int K, float alpha, int32_t* __restrict__ arg, int q) {
+                                                          int K, float alpha, const float* __restrict__ inv_alpha_dev,
+                                                          int last, int32_t* __restrict__ arg, int q) {
+    // alpha: the scale of the stored result; inv_alpha_dev (optional) = DEVICE scalar whose reciprocal replaces it (the learnable
+    // temperature, read at run time: no host read of a device scalar in the training step).  MODE 1 / 2 take the running maximum of
+    // the RAW products over the launches q = 0, 1, .. and scale only in the launch flagged `last` - max first, then / temp, as
+    // model_retrieval_caption.py:148 orders it (right for either sign of temp).
     extern __shared__ float sm[];
+    if (inv_alpha_dev) alpha = 1.f / inv_alpha_dev[0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
@@ -99,21 +105,26 @@ __global__ __launch_bounds__(256) void f32_nt_tile_kernel(const float* __restric
         const int m = m0 + wr * 32 + 8 * (i >> 2) + 4 * (lane >> 5) + (i & 3);
         if (m < M) {
             float* cp = C + (int64_t)m * ldc + n;
-            const float v = alpha * acc[i];
             if constexpr (MODE == 2) {               // running max over launches q = 0, 1, ..: the first maximum wins (torch.max)
-                if (q == 0 || v > *cp) {
-                    *cp = v;
+                float cur = q == 0 ? acc[i] : *cp;
+                if (q == 0 || acc[i] > cur) {
+                    cur = acc[i];
                     arg[(int64_t)m * ldc + n] = q;
                 }
+                *cp = last ? cur * alpha : cur;
+            } else if constexpr (MODE == 1) {
+                const float cur = fmaxf(*cp, acc[i]);
+                *cp = last ? cur * alpha : cur;
             } else {
-                *cp = MODE == 1 ? fmaxf(*cp, v) : v;
+                *cp = alpha * acc[i];
             }
         }
     }
 }
 
 static int launch_f32_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int64_t N,
-                         int64_t K, float alpha, bool take_max, hipStream_t st, int32_t* arg = nullptr, int q = 0) {
+                         int64_t K, float alpha, bool take_max, hipStream_t st, int32_t* arg = nullptr, int q = 0, int last = 1,
+                         const float* inv_alpha_dev = nullptr) {
     const size_t lds = (size_t)2 * 64 * (kScoreKC + 4) * sizeof(float);
     static bool attr = false;
     if (!attr) {
@@ -123,9 +134,9 @@ static int launch_f32_nt(const float* A, int64_t lda, const float* B, int64_t ld
         attr = true;
     }
     const dim3 grid((unsigned)cdiv(N, 64), (unsigned)cdiv(M, 64));
-    if (arg) hipLaunchKernelGGL(f32_nt_tile_kernel<2>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, arg, q);
-    else if (take_max) hipLaunchKernelGGL(f32_nt_tile_kernel<1>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, arg, q);
-    else hipLaunchKernelGGL(f32_nt_tile_kernel<0>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, arg, q);
+    if (arg) hipLaunchKernelGGL(f32_nt_tile_kernel<2>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, inv_alpha_dev, last, arg, q);
+    else if (take_max) hipLaunchKernelGGL(f32_nt_tile_kernel<1>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, inv_alpha_dev, last, arg, q);
+    else hipLaunchKernelGGL(f32_nt_tile_kernel<0>, grid, dim3(256), lds, st, A, lda, B, ldb, C, ldc, (int)M, (int)N, (int)K, alpha, inv_alpha_dev, last, arg, q);
     return check_launch("f32_nt_tile");
 }
 
@@ -169,8 +180,9 @@ __global__ __launch_bounds__(256) void sim_rowstat_kernel(const float* __restric
 // matching logits, match count).  sim_merge_kernel combines a row's (column's) partials over the tiles into lse and the loss.
 // Workspace: 2 G (lse) + 2 * G * ceil(G / 64) * 4 floats (2 MB at G = 2048, against 16.8 MB of logits written and read twice).
 __global__ __launch_bounds__(256) void sim_tile_stats_kernel(const float* __restrict__ A, const float* __restrict__ B,
-                                                             const int64_t* __restrict__ idx, int G, int D, float inv_temp,
+                                                             const int64_t* __restrict__ idx, int G, int D, float inv_temp, const float* __restrict__ temp_dev,
                                                              f32x4* __restrict__ part, int both_dirs) {
+    if (temp_dev) inv_temp = 1.f / temp_dev[0];          // the learnable temperature, read on the device
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -284,9 +296,10 @@ __global__ __launch_bounds__(256) void sim_merge_kernel(const f32x4* __restrict_
 // dir 0: rows of a vs all b ; dir 1: rows of b vs all a.   For row i: lse_i, pos_i = sum_j lab_ij logit_ij.
 // loss += scale * (lse_i - pos_i).   ws: [lse dir0 (G) | lse dir1 (G)]
 __global__ __launch_bounds__(256) void sim_rowlse_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                         const int64_t* __restrict__ idx, float inv_temp, int G, int D,
+                                                         const int64_t* __restrict__ idx, float inv_temp, const float* __restrict__ temp_dev, int G, int D,
                                                          float* __restrict__ loss, float* __restrict__ ws,
                                                          float scale) {
+    if (temp_dev) inv_temp = 1.f / temp_dev[0];          // the learnable temperature, read on the device
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int dir = blockIdx.y;
@@ -332,10 +345,11 @@ __global__ __launch_bounds__(256) void sim_rowlse_kernel(const float* __restrict
 //  g_ij = gs * [ w_r (softmax_row(i,j) - lab_ij) + w_c (softmax_col(i,j) - lab_ij) ],   w_r = w_c = 1/(2G) (both
 //  dirs) or w_r = 1/G, w_c = 0 (single direction).  dtemp += -sum_ij g_ij logit_ij / temp   (side 0 only).
 __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                      const int64_t* __restrict__ idx, float inv_temp, int G, int D,
+                                                      const int64_t* __restrict__ idx, float inv_temp, const float* __restrict__ temp_dev, int G, int D,
                                                       const float* __restrict__ ws, float w_r, float w_c,
                                                       float* __restrict__ da, float* __restrict__ db,
                                                       float* __restrict__ dtemp, int row0, int row_end, int slice) {
+    if (temp_dev) inv_temp = 1.f / temp_dev[0];          // the learnable temperature, read on the device
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int side = blockIdx.y;
@@ -413,10 +427,11 @@ __global__ __launch_bounds__(256) void sim_bwd_kernel(const float* __restrict__ 
 // (<= 512 rows: 8 per lane) stay in registers - then the wave walks the slice once per 1024-column chunk in 4-row load batches
 // with the coefficient broadcast from its lane.  Always adds into zeroed output rows.
 __global__ __launch_bounds__(256) void sim_bwd_wide_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                           const int64_t* __restrict__ idx, float inv_temp, int G, int D,
+                                                           const int64_t* __restrict__ idx, float inv_temp, const float* __restrict__ temp_dev, int G, int D,
                                                            const float* __restrict__ ws, float w_r, float w_c,
                                                            float* __restrict__ da, float* __restrict__ db,
                                                            float* __restrict__ dtemp, int row0, int row_end, int slice) {
+    if (temp_dev) inv_temp = 1.f / temp_dev[0];          // the learnable temperature, read on the device
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int side = blockIdx.y;
@@ -496,8 +511,9 @@ __global__ __launch_bounds__(256) void sim_bwd_wide_kernel(const float* __restri
 // ----------------------------------------------------------------------------------------------- capsim
 // logits[i,j] = max_n <c[i,n,:], t[j,:]> / temp  (b x b, local batch).  ws: [logits b*b | lse_row b | lse_col b]
 __global__ __launch_bounds__(256) void capsim_logits_kernel(const float* __restrict__ c, const float* __restrict__ t,
-                                                            float inv_temp, int b, int n, int D,
+                                                            float inv_temp, const float* __restrict__ temp_dev, int b, int n, int D,
                                                             float* __restrict__ logits, int32_t* __restrict__ argmax) {
+    if (temp_dev) inv_temp = 1.f / temp_dev[0];          // the learnable temperature, read on the device
     extern __shared__ float sm[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wave;
@@ -551,10 +567,11 @@ __device__ __forceinline__ float capsim_g(const float* logits, const float* lse_
 // blockIdx.z: a slice of the other index; per 64 of them the lanes compute the coefficients g (and fetch the arg-max query) in
 // parallel, then the wave walks the 64 operand rows with g broadcast from its lane; slices add into the zeroed outputs.
 __global__ __launch_bounds__(256) void capsim_bwd_kernel(const float* __restrict__ c, const float* __restrict__ t,
-                                                         float inv_temp, int b, int n, int D,
+                                                         float inv_temp, const float* __restrict__ temp_dev, int b, int n, int D,
                                                          const int32_t* __restrict__ argmax,
                                                          const float* __restrict__ ws, float w, float* __restrict__ dc,
                                                          float* __restrict__ dt, float* __restrict__ dtemp, int slice) {
+    if (temp_dev) inv_temp = 1.f / temp_dev[0];          // the learnable temperature, read on the device
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int side = blockIdx.y;
     const int r = blockIdx.x * 4 + wave;
@@ -970,8 +987,9 @@ __global__ __launch_bounds__(256) void capreg_kernel(const T* __restrict__ c, fl
 using namespace leccr;
 
 extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
-                                     int both_dirs, float* loss, float* ws, void* stream) {
-    LECCR_REQUIRE(a && b && loss && ws && G > 0 && D > 0 && D <= 4096 && temp != 0.f, LECCR_EINVAL, "sim_infonce_fwd: bad argument");
+                                     int both_dirs, float* loss, float* ws, const float* temp_dev, void* stream) {
+    LECCR_REQUIRE(a && b && loss && ws && G > 0 && D > 0 && D <= 4096 && (temp_dev || temp != 0.f), LECCR_EINVAL, "sim_infonce_fwd: bad argument");
+    if (temp_dev) temp = 1.f;               // (the kernels take 1 / *temp_dev)
     LECCR_REQUIRE((D & 3) == 0, LECCR_EALIGN, "sim_infonce_fwd: D must be a multiple of 4");
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("sim_infonce memset");
@@ -988,7 +1006,7 @@ extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64
         }
         const size_t lds = (size_t)2 * 64 * (kScoreKC + 4) * sizeof(float);
         hipLaunchKernelGGL(sim_tile_stats_kernel, dim3((unsigned)T, (unsigned)T), dim3(256), lds, st, a, b, idx, (int)G, (int)D,
-                           1.f / temp, part, both_dirs);
+                           1.f / temp, temp_dev, part, both_dirs);
         hipLaunchKernelGGL(sim_merge_kernel, dim3((unsigned)cdiv(G, 4), both_dirs ? 2 : 1), dim3(256), 0, st, part, (int)G, T, ws,
                            loss, scale);
         return check_launch("sim_infonce_fwd");
@@ -996,14 +1014,15 @@ extern "C" int leccr_sim_infonce_fwd(const float* a, const float* b, const int64
     const size_t lds_f = (size_t)(4 * D + 64 * (D + 4)) * sizeof(float);      // 4 own rows + the staged 64-row tile
     (void)hipFuncSetAttribute((const void*)sim_rowlse_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipLaunchKernelGGL(sim_rowlse_kernel, dim3((unsigned)cdiv(G, 4), both_dirs ? 2 : 1), dim3(256), lds_f, st,
-                       a, b, idx, 1.f / temp, (int)G, (int)D, loss, ws, scale);
+                       a, b, idx, 1.f / temp, temp_dev, (int)G, (int)D, loss, ws, scale);
     return check_launch("sim_infonce_fwd");
 }
 
 extern "C" int leccr_sim_infonce_bwd(const float* a, const float* b, const int64_t* idx, float temp, int64_t G, int64_t D,
                                      int both_dirs, const float* ws, float gscale, float* da, float* db, float* dtemp,
-                                     int64_t row0, int64_t nrows, void* stream) {
-    LECCR_REQUIRE(a && b && ws && da && db && G > 0 && D > 0 && D <= 8192 && (D & 3) == 0, LECCR_EINVAL, "sim_infonce_bwd: bad argument (D <= 8192)");
+                                     int64_t row0, int64_t nrows, const float* temp_dev, void* stream) {
+    LECCR_REQUIRE(a && b && ws && da && db && G > 0 && D > 0 && D <= 8192 && (D & 3) == 0 && (temp_dev || temp != 0.f), LECCR_EINVAL, "sim_infonce_bwd: bad argument (D <= 8192)");
+    if (temp_dev) temp = 1.f;
     LECCR_REQUIRE(row0 >= 0 && nrows > 0 && row0 + nrows <= G, LECCR_EINVAL, "sim_infonce_bwd: row range outside [0, G)");
     hipStream_t st = as_stream(stream);
     const float w_r = gscale * (both_dirs ? 0.5f / G : 1.f / G), w_c = both_dirs ? w_r : 0.f;
@@ -1022,31 +1041,33 @@ extern "C" int leccr_sim_infonce_bwd(const float* a, const float* b, const int64
         const int wslice = slice > 512 ? 512 : slice;                  // the wide kernel keeps a slice's coefficients in 8 registers
         (void)hipFuncSetAttribute((const void*)sim_bwd_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(sim_bwd_wide_kernel, dim3((unsigned)cdiv(nrows, 4), 2, (unsigned)cdiv(G, wslice)), dim3(256),
-                           (size_t)4 * D * sizeof(float), st, a, b, idx, 1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp,
+                           (size_t)4 * D * sizeof(float), st, a, b, idx, 1.f / temp, temp_dev, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp,
                            (int)row0, (int)(row0 + nrows), wslice);
         return check_launch("sim_infonce_bwd");
     }
     hipLaunchKernelGGL(sim_bwd_kernel, dim3((unsigned)cdiv(nrows, 4), 2, (unsigned)nslice), dim3(256), lds_b, st, a, b, idx,
-                       1.f / temp, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp, (int)row0, (int)(row0 + nrows), slice);
+                       1.f / temp, temp_dev, (int)G, (int)D, ws, w_r, w_c, da, db, dtemp, (int)row0, (int)(row0 + nrows), slice);
     return check_launch("sim_infonce_bwd");
 }
 
 extern "C" int leccr_capsim_fwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D, float* loss,
-                                int32_t* argmax, float* ws, void* stream) {
-    LECCR_REQUIRE(c && t && loss && argmax && ws && b > 0 && n > 0 && n <= 8 && D > 0 && (D & 3) == 0 && n * D <= 3072, LECCR_EINVAL, "capsim_fwd: bad argument");
+                                int32_t* argmax, float* ws, const float* temp_dev, void* stream) {
+    LECCR_REQUIRE(c && t && loss && argmax && ws && b > 0 && n > 0 && n <= 8 && D > 0 && (D & 3) == 0 && n * D <= 3072 && (temp_dev || temp != 0.f),
+                  LECCR_EINVAL, "capsim_fwd: bad argument");
+    if (temp_dev) temp = 1.f;
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(loss, 0, sizeof(float), st) != hipSuccess) return check_launch("capsim memset");
     float* logits = ws;
     float* lse_r = ws + b * b;
     float* lse_c = lse_r + b;
-    if ((D & 7) == 0 && temp > 0.f) {      // max_n <c_n, t> as n matrix-core tile passes keeping the running maximum and its n
+    if ((D & 7) == 0) {      // max_n <c_n, t> as n matrix-core tile passes keeping the running maximum (of the raw products) and its n
         for (int q = 0; q < n; ++q) {
-            const int rc = launch_f32_nt(c + q * D, n * D, t, D, logits, b, b, b, D, 1.f / temp, true, st, argmax, q);
+            const int rc = launch_f32_nt(c + q * D, n * D, t, D, logits, b, b, b, D, 1.f / temp, true, st, argmax, q, q == n - 1, temp_dev);
             if (rc != LECCR_OK) return rc;
         }
     } else {
         hipLaunchKernelGGL(capsim_logits_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 4 * n * D * sizeof(float), st, c, t,
-                           1.f / temp, (int)b, (int)n, (int)D, logits, argmax);
+                           1.f / temp, temp_dev, (int)b, (int)n, (int)D, logits, argmax);
     }
     hipLaunchKernelGGL(lse_ce_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, logits, (int)b, (int)b, (int64_t)b, (int64_t)1, lse_r, loss, 0.5f / b);
     hipLaunchKernelGGL(lse_ce_kernel, dim3((unsigned)cdiv(b, 4)), dim3(256), 0, st, logits, (int)b, (int)b, (int64_t)1, (int64_t)b, lse_c, loss, 0.5f / b);
@@ -1055,8 +1076,10 @@ extern "C" int leccr_capsim_fwd(const float* c, const float* t, float temp, int6
 
 extern "C" int leccr_capsim_bwd(const float* c, const float* t, float temp, int64_t b, int64_t n, int64_t D,
                                 const int32_t* argmax, const float* ws, float gscale, float* dc, float* dt, float* dtemp,
-                                void* stream) {
-    LECCR_REQUIRE(c && t && argmax && ws && dc && dt && b > 0 && n > 0 && n <= 8 && D > 0 && D <= 512, LECCR_EINVAL, "capsim_bwd: bad argument");
+                                const float* temp_dev, void* stream) {
+    LECCR_REQUIRE(c && t && argmax && ws && dc && dt && b > 0 && n > 0 && n <= 8 && D > 0 && D <= 512 && (temp_dev || temp != 0.f), LECCR_EINVAL,
+                  "capsim_bwd: bad argument");
+    if (temp_dev) temp = 1.f;
     hipStream_t st = as_stream(stream);
     int nslice = (int)cdiv(1024, 2 * cdiv(b, 4));
     if (nslice > cdiv(b, 64)) nslice = (int)cdiv(b, 64);
@@ -1065,8 +1088,8 @@ extern "C" int leccr_capsim_bwd(const float* c, const float* t, float temp, int6
     nslice = (int)cdiv(b, slice);
     if (hipMemsetAsync(dc, 0, sizeof(float) * b * n * D, st) != hipSuccess || hipMemsetAsync(dt, 0, sizeof(float) * b * D, st) != hipSuccess)
         return check_launch("capsim_bwd memset");
-    hipLaunchKernelGGL(capsim_bwd_kernel, dim3((unsigned)cdiv(b, 4), 2, (unsigned)nslice), dim3(256), 0, st, c, t, 1.f / temp, (int)b,
-                       (int)n, (int)D, argmax, ws, gscale * 0.5f / b, dc, dt, dtemp, slice);
+    hipLaunchKernelGGL(capsim_bwd_kernel, dim3((unsigned)cdiv(b, 4), 2, (unsigned)nslice), dim3(256), 0, st, c, t, 1.f / temp, temp_dev,
+                       (int)b, (int)n, (int)D, argmax, ws, gscale * 0.5f / b, dc, dt, dtemp, slice);
     return check_launch("capsim_bwd");
 }
 

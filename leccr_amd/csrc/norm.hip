@@ -547,7 +547,8 @@ static int ln_fwd_entry(const void* x, const void* add, const float* gamma, cons
     const Q8Out q8{(uint8_t*)y8, y8_site, y8_fmt};
     LECCR_REQUIRE(x && gamma && beta && y && mean && rstd, LECCR_EINVAL, "layernorm_fwd: null pointer");
     LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_fwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
-    LECCR_REQUIRE(p >= 0.f && p < 1.f && rows * d < (1ll << 32), LECCR_EINVAL, "layernorm_fwd: dropout p in [0, 1), fewer than 2^32 elements");
+    LECCR_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || rows * d < (1ll << 32)), LECCR_EINVAL,
+                  "layernorm_fwd: dropout p in [0, 1); with dropout fewer than 2^32 elements (32-bit element counter of the mask)");
     if (rows == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     DropCfg drop = make_drop(p, seed);

@@ -258,14 +258,24 @@ def _f32c(t):
     return t
 
 
+def _temp_args(temp):
+    """(host value, device pointer) of a temperature argument: a float, or a 1-element f32 DEVICE tensor the kernels read at run time
+    (the learnable XVLMBase.temp: no host read of a device scalar in the training step)."""
+    if torch.is_tensor(temp):
+        assert temp.is_cuda and temp.dtype == torch.float32 and temp.numel() == 1, (temp.device, temp.dtype, temp.shape)
+        return 1.0, ptr(temp)
+    return float(temp), None
+
+
 def sim_infonce_fwd(a, b, idx, temp, both_dirs=True):
     G, D = _f32c(a).shape
     _f32c(b)
     loss = torch.empty(1, device=a.device, dtype=torch.float32)
     # row / column log-sum-exps (what the backward reads) | per-tile online-softmax partials of the forward: 2 x G x ceil(G/64) x 4
     ws = torch.empty(2 * G + 4 + 8 * G * ((G + 63) // 64), device=a.device, dtype=torch.float32)
-    check(lib().leccr_sim_infonce_fwd(ptr(a), ptr(b), ptr(idx), float(temp), G, D, int(both_dirs), ptr(loss),
-                                      ptr(ws), stream()), 'leccr_sim_infonce_fwd')
+    tv, tdev = _temp_args(temp)
+    check(lib().leccr_sim_infonce_fwd(ptr(a), ptr(b), ptr(idx), tv, G, D, int(both_dirs), ptr(loss),
+                                      ptr(ws), tdev, stream()), 'leccr_sim_infonce_fwd')
     return loss, ws
 
 
@@ -274,8 +284,9 @@ def sim_infonce_bwd(a, b, idx, temp, ws, gscale, both_dirs=True, dtemp=None, row
     G, D = a.shape
     r0, nr = rows if rows is not None else (0, G)
     da, db = (torch.empty_like(a), torch.empty_like(b)) if nr == G else (torch.zeros_like(a), torch.zeros_like(b))
-    check(lib().leccr_sim_infonce_bwd(ptr(a), ptr(b), ptr(idx), float(temp), G, D, int(both_dirs), ptr(ws),
-                                      float(gscale), ptr(da), ptr(db), ptr(dtemp), int(r0), int(nr), stream()),
+    tv, tdev = _temp_args(temp)
+    check(lib().leccr_sim_infonce_bwd(ptr(a), ptr(b), ptr(idx), tv, G, D, int(both_dirs), ptr(ws),
+                                      float(gscale), ptr(da), ptr(db), ptr(dtemp), int(r0), int(nr), tdev, stream()),
           'leccr_sim_infonce_bwd')
     return da, db
 
@@ -286,7 +297,8 @@ def capsim_fwd(c, t, temp):
     loss = torch.empty(1, device=c.device, dtype=torch.float32)
     am = torch.empty(b, b, device=c.device, dtype=torch.int32)
     ws = torch.empty(b * b + 2 * b, device=c.device, dtype=torch.float32)
-    check(lib().leccr_capsim_fwd(ptr(c), ptr(t), float(temp), b, n, D, ptr(loss), ptr(am), ptr(ws), stream()),
+    tv, tdev = _temp_args(temp)
+    check(lib().leccr_capsim_fwd(ptr(c), ptr(t), tv, b, n, D, ptr(loss), ptr(am), ptr(ws), tdev, stream()),
           'leccr_capsim_fwd')
     return loss, am, ws
 
@@ -294,8 +306,9 @@ def capsim_fwd(c, t, temp):
 def capsim_bwd(c, t, temp, am, ws, gscale, dtemp=None):
     b, n, D = c.shape
     dc, dt = torch.empty_like(c), torch.empty_like(t)
-    check(lib().leccr_capsim_bwd(ptr(c), ptr(t), float(temp), b, n, D, ptr(am), ptr(ws), float(gscale), ptr(dc),
-                                 ptr(dt), ptr(dtemp), stream()), 'leccr_capsim_bwd')
+    tv, tdev = _temp_args(temp)
+    check(lib().leccr_capsim_bwd(ptr(c), ptr(t), tv, b, n, D, ptr(am), ptr(ws), float(gscale), ptr(dc),
+                                 ptr(dt), ptr(dtemp), tdev, stream()), 'leccr_capsim_bwd')
     return dc, dt
 
 
@@ -450,3 +463,15 @@ class Fp8Site:
         check(lib().leccr_fp8_quantize(ptr(x), ptr(y), rows, cols, x.stride(0), y.stride(0), dtype_code(x), self.fmt, ptr(self.row),
                                        stream()), 'leccr_fp8_quantize')
         return y
+
+    def quantize_current(self, x, outs):
+        """CURRENT scaling (weights): the scale is derived from x itself right now - amax pass, update of this one site, then the
+        quantise passes of x's layouts `outs` = [(tensor, fp8 out), ..] - so the fp8 copies and the 1/scale the GEMMs read at kernel
+        time always belong together.  (Delayed scaling is wrong for a tensor that is quantised ONCE and consumed across a later
+        update(): the copy would carry the old scale and the product the new one - off by 2x whenever amax crosses a power of two.)"""
+        rows, cols = x.shape
+        check(lib().leccr_fp8_amax(ptr(x), rows, cols, x.stride(0), dtype_code(x), ptr(self.row), stream()), 'leccr_fp8_amax')
+        check(lib().leccr_fp8_update(ptr(self.row), 1, stream()), 'leccr_fp8_update')
+        self.primed = True
+        for t, y in outs:
+            self.quantize(t, out=y)

@@ -5,7 +5,7 @@ import torch.nn as nn
 from .. import ops
 from .attention import CrossAttention
 from .layers import Linear
-from .xvlm import XVLMBase, _dist_info, begin_step_gathers, gather_rows, gather_rows_packed, local_rows
+from .xvlm import XVLMBase, _dist_info, local_rows
 
 
 class RetrievalModel(XVLMBase):
@@ -73,6 +73,7 @@ class RetrievalModel(XVLMBase):
                 ops.CvPoolFn.apply(self.vproj(ori_image, wgrad_scale=float(world))))
 
     def _cv_loss_pooled(self, pc, pv, idx):
+        gather_rows = self.gathers.rows
         idx_all = gather_rows(idx.view(-1, 1)).view(-1).contiguous()
         return ops.SimInfoNCEFn.apply(gather_rows(pc), gather_rows(pv), None, idx_all, False, 1.0, local_rows(pc.size(0)))
 
@@ -89,6 +90,7 @@ class RetrievalModel(XVLMBase):
 
     def dstl_loss(self, image_embeds, caption_embeds, text_embeds_s, text_embeds_t, idx, alpha=0.8):
         """model_retrieval_caption.py:94-116; caption_embeds [n, b, D] (LND)."""
+        gather_rows = self.gathers.rows
         v = gather_rows(image_embeds.float())
         c = gather_rows(caption_embeds.transpose(0, 1).float().contiguous())
         s, t = gather_rows(text_embeds_s.float()), gather_rows(text_embeds_t.float())
@@ -106,7 +108,8 @@ class RetrievalModel(XVLMBase):
         """model_retrieval_caption.py:154-199 -> (loss_itc_vs + loss_cv, loss_itc_vt', loss_itc_st, w_c loss_itc_c,
         w_r loss_reg_c).  Same five scalars; internally batch-major, src+tgt text in one BERT pass."""
         self._ensure_runtime()
-        begin_step_gathers()
+        self.gathers.begin()
+        gather_rows = self.gathers.rows
         ops.begin_step()
         if self.fp8_sites is not None:         # scales of this step = what the previous step's tensors asked for (delayed scaling)
             self.fp8_sites.update()
@@ -114,7 +117,7 @@ class RetrievalModel(XVLMBase):
             self._step_count = getattr(self, '_step_count', 0) + 1
             rank, _ = _dist_info()
             ops.set_dropout_seed((int(self.config.get('seed', 42)) + rank) * 1000003 + self._step_count)
-        tval = float(self.temp.detach())          # the step's only host read of a device scalar
+        tval = None           # the loss kernels read self.temp on the device (round 2: float(self.temp) here drained the stream)
         ids_s, atts_s = text_ls[0].input_ids, text_ls[0].attention_mask
         ids_t, atts_t = text_ls[1].input_ids, text_ls[1].attention_mask
         b = ids_s.shape[0]
@@ -161,7 +164,7 @@ class RetrievalModel(XVLMBase):
         text_feat_s, text_feat_t = feats[:b], feats[b:]
         cq = self.caption_proj1(after_caption, out_f32=True).contiguous()   # [b, n, D] f32
         # every block the loss terms gather (W > 1), in one collective instead of sixteen
-        gather_rows_packed([image_feat, text_feat_s, text_feat_t, cq, pc, pv], None if idx is None else idx.view(-1, 1))
+        self.gathers.packed([image_feat, text_feat_s, text_feat_t, cq, pc, pv], None if idx is None else idx.view(-1, 1))
         loss_cv = self._cv_loss_pooled(pc, pv, idx) * self.weight_cv_loss
 
         loss_itc_vs = self.get_contrastive_loss(image_feat, text_feat_s, idx=idx, tval=tval)

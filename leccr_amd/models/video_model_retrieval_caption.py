@@ -10,7 +10,7 @@ import torch
 from .. import ops
 from .attention import SelfAttention
 from .model_retrieval_caption import RetrievalModel as _ImageRetrievalModel
-from .xvlm import _dist_info, begin_step_gathers, gather_rows, local_rows
+from .xvlm import _dist_info, local_rows
 
 
 class RetrievalModel(_ImageRetrievalModel):
@@ -64,7 +64,8 @@ class RetrievalModel(_ImageRetrievalModel):
     def forward(self, video, video_mask, text_ls, captions=None, idx=None, epoch=None, cap_idx=None):
         """video_model_retrieval_caption.py:180-227 -> the same five scalars as the image model."""
         self._ensure_runtime()
-        begin_step_gathers()
+        self.gathers.begin()
+        gather_rows = self.gathers.rows
         ops.begin_step()
         if self.fp8_sites is not None:         # scales of this step = what the previous step's tensors asked for (delayed scaling)
             self.fp8_sites.update()
@@ -72,7 +73,7 @@ class RetrievalModel(_ImageRetrievalModel):
             self._step_count = getattr(self, '_step_count', 0) + 1
             rank, _ = _dist_info()
             ops.set_dropout_seed((int(self.config.get('seed', 42)) + rank) * 1000003 + self._step_count)
-        tval = float(self.temp.detach())
+        tval = None           # the loss kernels read self.temp on the device
         ori_video, video_kpm = self.get_vision_embeds(video, video_mask)
         with torch.no_grad():
             cap_ids, cap_atts = captions.input_ids, captions.attention_mask

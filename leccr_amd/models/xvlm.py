@@ -76,53 +76,72 @@ class AllGatherPacked(torch.autograd.Function):
         return (None, None) + tuple(None if g is None else g[b * r: b * (r + 1)] for g, b in zip(grads, ctx.rows))
 
 
-# One training step gathers the same feature blocks for several loss terms (image_feat for three of them, idx for four):
-# the gathered copy is kept per source tensor for the duration of the step (begin_step_gathers() clears it), and
-# gather_rows_packed() fills it for the whole set with a single collective.
-_gathered = {}
+class StepGathers:
+    """One training step gathers the same feature blocks for several loss terms (image_feat for three of them, idx for four): the
+    gathered copy is kept per source tensor for the duration of the step (begin() clears it), and packed() fills it for the whole
+    set with a single collective.  One instance per MODEL (XVLMBase.gathers): two models stepping in one process (a teacher beside
+    a student, a test's oracle twin) never see each other's blocks - the cache key is an address, and addresses are only unique
+    among the tensors one instance keeps alive."""
+
+    def __init__(self):
+        self.hit = {}
+
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+
+    def begin(self):
+        self.hit.clear()
+
+    def rows(self, t):
+        rank, world = _dist_info()
+        if world == 1:
+            return t
+        hit = self.hit.get(self._key(t))
+        if hit is not None:
+            return hit[1]
+        out = allgather(t, rank, world)
+        self.hit[self._key(t)] = (t, out)          # the source stays referenced: its address cannot be reused within the step
+        return out
+
+    def packed(self, tensors, idx=None):
+        """All-gather the f32 blocks `tensors` (and the int64 column `idx`, bit-cast to two f32 words per row) in one collective
+        and remember the results for rows()."""
+        rank, world = _dist_info()
+        if world == 1:
+            return
+        srcs = [t for t in tensors if self._key(t) not in self.hit]
+        assert all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs)
+        packed = list(srcs)
+        if idx is not None and self._key(idx) not in self.hit:
+            assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 2 and idx.shape[1] == 1
+            packed.append(idx.view(torch.float32))                     # [b, 2] words, copied bit for bit
+        else:
+            idx = None
+        if not packed:
+            return
+        outs = AllGatherPacked.apply(rank, world, *packed)
+        for t, o in zip(srcs, outs):
+            self.hit[self._key(t)] = (t, o)
+        if idx is not None:
+            self.hit[self._key(idx)] = (idx, outs[-1].detach().contiguous().view(torch.int64))
 
 
-def _gkey(t):
-    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), t.dtype)
+# module-level instance + functions: the free-standing API (tests, scripts without a model)
+_default_gathers = StepGathers()
+_gathered = _default_gathers.hit
 
 
 def begin_step_gathers():
-    _gathered.clear()
+    _default_gathers.begin()
 
 
 def gather_rows(t):
-    rank, world = _dist_info()
-    if world == 1:
-        return t
-    hit = _gathered.get(_gkey(t))
-    if hit is not None:
-        return hit[1]
-    out = allgather(t, rank, world)
-    _gathered[_gkey(t)] = (t, out)          # the source stays referenced: its address cannot be reused within the step
-    return out
+    return _default_gathers.rows(t)
 
 
 def gather_rows_packed(tensors, idx=None):
-    """All-gather the f32 blocks `tensors` (and the int64 column `idx`, bit-cast to two f32 words per row) in one collective
-    and remember the results for gather_rows()."""
-    rank, world = _dist_info()
-    if world == 1:
-        return
-    srcs = [t for t in tensors if _gkey(t) not in _gathered]
-    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs)
-    packed = list(srcs)
-    if idx is not None and _gkey(idx) not in _gathered:
-        assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 2 and idx.shape[1] == 1
-        packed.append(idx.view(torch.float32))                     # [b, 2] words, copied bit for bit
-    else:
-        idx = None
-    if not packed:
-        return
-    outs = AllGatherPacked.apply(rank, world, *packed)
-    for t, o in zip(srcs, outs):
-        _gathered[_gkey(t)] = (t, o)
-    if idx is not None:
-        _gathered[_gkey(idx)] = (idx, outs[-1].detach().contiguous().view(torch.int64))
+    _default_gathers.packed(tensors, idx)
 
 
 def local_rows(b):
@@ -200,6 +219,7 @@ class XVLMBase(nn.Module):
         self.fp8 = dt == 'fp8'
         self.fp8_sites = None
         self.arena = None
+        self.gathers = StepGathers()        # this model's per-step cache of all-gathered blocks
 
     # ------------------------------------------------------------------ runtime (arena + compute copies)
     def _ensure_runtime(self):
@@ -256,10 +276,14 @@ class XVLMBase(nn.Module):
         for layer in (self.text_encoder.encoder.layer if os.environ.get('LECCR_FP8_TEXT', '1') != '0' else []):
             layer.fp8 = True
             holders += [layer._qkv_w, layer.attention.output.dense.weight, layer.intermediate.dense.weight, layer.output.dense.weight]
-        self.fp8_sites = sites = Fp8Sites(dev, 3 * len(holders) + 8)
+        # activation / gradient sites: delayed scaling, all updated together at the start of a step (fp8_sites.update()).  Weight
+        # sites live in a block of their own that the per-step update never touches: a weight is quantised once per optimizer step and
+        # its copy is consumed until the next one, so its scale is taken from the weight itself at that moment (quantize_current)
+        self.fp8_sites = sites = Fp8Sites(dev, 2 * len(holders) + 8)
+        self.fp8_weight_sites = wsites = Fp8Sites(dev, len(holders) + 8)
         for h in holders:
             assert h._lpt is not None and h._lp.dim() == 2
-            h._wsite, h._xsite, h._gsite = sites.new(Fp8Sites.E4M3), sites.new(Fp8Sites.E4M3), sites.new(Fp8Sites.E5M2)
+            h._wsite, h._xsite, h._gsite = wsites.new(Fp8Sites.E4M3), sites.new(Fp8Sites.E4M3), sites.new(Fp8Sites.E5M2)
             h._q8 = torch.empty(h._lp.shape, device=dev, dtype=torch.float8_e4m3fn)
             h._q8t = torch.empty(h._lpt.shape, device=dev, dtype=torch.float8_e4m3fn)
 
@@ -270,8 +294,7 @@ class XVLMBase(nn.Module):
 
         def requantise():
             for h in holders:
-                h._wsite.quantize(h._lp, out=h._q8)
-                h._wsite.quantize(h._lpt, out=h._q8t)
+                h._wsite.quantize_current(h._lp, [(h._lp, h._q8), (h._lpt, h._q8t)])
         a.post_refresh.append(requantise)
 
     def refresh_weights(self):
@@ -315,6 +338,7 @@ class XVLMBase(nn.Module):
         """xvlm.py:260-292: all-gather both feature sets (+ idx), all-pairs logits / temp, soft-label InfoNCE both
         directions.  The G x G logits are never materialised (leccr_sim_infonce_*)."""
         assert image_feat.size(-1) == self.embed_dim and text_feat.size(-1) == self.embed_dim
+        gather_rows = self.gathers.rows
         a, b = gather_rows(image_feat.float()), gather_rows(text_feat.float())
         idx_all = None
         if idx is not None:

@@ -680,8 +680,8 @@ class SimInfoNCEFn(torch.autograd.Function):
         """local_rows = (row0, nrows): a and b are all-gathered and only those rows are this rank's (AllGather keeps the
         local slice of the gradient, xvlm.py:62-67): the backward computes just them - 1/W of its work."""
         a, b = a.contiguous(), b.contiguous()
-        if tval is None:
-            tval = float(temp) if temp is not None else 1.0
+        if tval is None:       # the learnable temperature is read by the kernels ON THE DEVICE (no float(temp): that drains the stream)
+            tval = temp.data.view(1) if temp is not None else 1.0
         loss, ws = K.sim_infonce_fwd(a, b, idx, tval, both_dirs)
         ctx.save_for_backward(a, b, ws)
         ctx.meta = (tval, idx, both_dirs, temp is not None, local_rows)
@@ -707,7 +707,7 @@ class CapSimFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, c, t, temp, tval=None):
         c, t = c.contiguous(), t.contiguous()
-        tval = float(temp) if tval is None else tval
+        tval = temp.data.view(1) if tval is None else tval          # device scalar, read by the kernels
         loss, am, ws = K.capsim_fwd(c, t, tval)
         ctx.save_for_backward(c, t, am, ws)
         ctx.tval = tval

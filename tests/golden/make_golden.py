@@ -406,22 +406,31 @@ FULL_CFG = {'embed_dim': 256, 'temp': 0.07, 'use_one_cl_proj_only': False, 'capt
             'num_queries': 4, 'caption_ca_layer': 3, 'caption_interaction_layer': 2, 'weight_reg_loss': 0.01,
             'weight_caption_loss': 0.01, 'weight_dstl_loss': 0.5, 'weight_cv_loss': 0.01}      # = leccr_amd.synthetic.MULTI30K_CFG
 
-def fixture_vit_b16_1layer(clip_model):
+# The geometry the reference's build_clip_encoder hard-codes (models/xvlm.py:83-88: clip.load('ViT-B/32'); clip/model.py:211-228
+# gives (384 // 32)^2 + 1 = 145 tokens and 3 * 32 * 32 = 3072-wide patch rows) - what run_multi30k.sh really instantiates.
+B32_VIT_1L = dict(B16_VIT_1L, vision_patch_size=32)
+B32_VIT = dict(B32_VIT_1L, vision_layers=12)
+FULL_GEOMETRY = {'b16': (B16_VIT_1L, B16_VIT, 51, 61, [0, 1, 288, 575, 576]),
+                 'b32': (B32_VIT_1L, B32_VIT, 151, 161, [0, 1, 72, 143, 144])}
+
+
+def fixture_vit_b16_1layer(clip_model, tag='b16'):
     """The reference's CLIP ViT at the REAL B/16 geometry (577 tokens, width 768, 12 heads, patch 16, res 384;
     clip/model.py:408-445), one layer, b = 2: checks the 577-token tiling of the production kernels.  Weights and inputs
-    come from tests.helpers.seeded_fill_ / a seeded generator (rebuilt by the tests), outputs are stored as slices."""
+    come from tests.helpers.seeded_fill_ / a seeded generator (rebuilt by the tests), outputs are stored as slices.
+    tag 'b32': the same at the reference's hard-coded default geometry (145 tokens, patch 32)."""
     from tests.golden_slices import B16_GRAD_SLICES
     from tests.helpers import seeded_fill_
+    geo, _, seed, _, rows = FULL_GEOMETRY[tag]
     torch.manual_seed(0)
-    clip = clip_model.CLIP(**B16_VIT_1L).float().eval()
-    sums = seeded_fill_(clip.visual.named_parameters(), 51)
-    g = torch.Generator().manual_seed(52)
+    clip = clip_model.CLIP(**geo).float().eval()
+    sums = seeded_fill_(clip.visual.named_parameters(), seed)
+    g = torch.Generator().manual_seed(seed + 1)
     image = torch.randn(2, 3, 384, 384, generator=g)
     cls, hidden = clip.encode_image(image, return_hidden=True)
     trunk = clip.visual(image)
     probe = torch.randn(hidden.shape, generator=g)
     (hidden * probe).sum().backward()
-    rows = [0, 1, 288, 575, 576]
     out = {'hidden_rows': hidden[:, rows, :].detach().numpy(), 'rows': np.array(rows), 'hidden_cols16': hidden[:, :, ::16].detach().numpy(),
            'trunk_cols16': trunk[:, :, ::16].detach().numpy(), 'hidden_sq_sum': np.array(float((hidden.double() ** 2).sum())),
            'wsum_names': np.array(sorted(sums)), 'wsum': np.array([sums[k] for k in sorted(sums)])}
@@ -430,19 +439,22 @@ def fixture_vit_b16_1layer(clip_model):
         gk = named[k].grad
         out['g/' + k] = (gk if sl is None else gk[sl]).detach().numpy()
         out['gn/' + k] = np.array(float(gk.double().norm()))
-    np.savez_compressed(os.path.join(OUT, 'vit_b16_1layer.npz'), **out)
-    print('vit_b16_1layer', hidden.shape, float(hidden.abs().mean()), os.path.getsize(os.path.join(OUT, 'vit_b16_1layer.npz')))
+    np.savez_compressed(os.path.join(OUT, f'vit_{tag}_1layer.npz'), **out)
+    print(f'vit_{tag}_1layer', hidden.shape, float(hidden.abs().mean()), os.path.getsize(os.path.join(OUT, f'vit_{tag}_1layer.npz')))
 
 
-def fixture_full_step_b16(clip_model, xvlm):
-    """SURVEY 8(c) `full_step_b16`: the reference RetrievalModel at the REAL ViT-B/16@384 + mBERT geometry (12 + 12 layers,
+def fixture_full_step_b16(clip_model, xvlm, tag='b16'):
+    """tag 'b32': the reference's hard-coded default tower (145 tokens, patch 32) -> full_step_b32.npz.
+    SURVEY 8(c) `full_step_b16`: the reference RetrievalModel at the REAL ViT-B/16@384 + mBERT geometry (12 + 12 layers,
     vocab 119 547, 4 queries, 3 + 2 + 2 interaction layers), b = 4, L_t = L_c = 12, seeded weights (tests.helpers.seeded_fill_):
     its five losses, the three feature matrices and norms / slices of a few gradients.  No weight payload: the GPU test
     rebuilds the same weights from the seed and must reproduce these numbers with the HIP model directly."""
     from tests.helpers import full_step_batch, seeded_fill_
 
+    _, geo, _, seed, _ = FULL_GEOMETRY[tag]
+
     def _clip(config=None):
-        return clip_model.CLIP(**B16_VIT).float(), B16_VIT['embed_dim']
+        return clip_model.CLIP(**geo).float(), geo['embed_dim']
 
     def _bert(config=None):
         from transformers import BertConfig, BertModel
@@ -451,12 +463,12 @@ def fixture_full_step_b16(clip_model, xvlm):
     xvlm.build_clip_encoder = _clip
     xvlm.build_text_encoder = _bert
     from models.model_retrieval_caption import RetrievalModel
-    torch.manual_seed(61)
+    torch.manual_seed(seed)
     model = RetrievalModel(dict(FULL_CFG))
     model.init_caption_encoder()
-    sums = seeded_fill_(model.named_parameters(), 61)
+    sums = seeded_fill_(model.named_parameters(), seed)
     model.eval()
-    batch = full_step_batch()
+    batch = full_step_batch(seed0=seed + 1)
     with torch.no_grad():
         v, _ = model.get_vision_embeds(batch['image'])
         c = model.get_caption_embeds(batch['ids_c'], batch['mask_c'])
@@ -477,8 +489,8 @@ def fixture_full_step_b16(clip_model, xvlm):
         gk = named[k].grad
         out['g/' + k] = np.asarray((gk if sl is None else gk[sl]).detach().numpy())
         out['gn/' + k] = np.array(float(gk.double().norm()))
-    np.savez_compressed(os.path.join(OUT, 'full_step_b16.npz'), **out)
-    print('full_step_b16 losses', out['losses'], os.path.getsize(os.path.join(OUT, 'full_step_b16.npz')))
+    np.savez_compressed(os.path.join(OUT, f'full_step_{tag}.npz'), **out)
+    print(f'full_step_{tag} losses', out['losses'], os.path.getsize(os.path.join(OUT, f'full_step_{tag}.npz')))
 
 
 def fixture_pos_embed(clip_model):
@@ -584,15 +596,23 @@ def main():
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29610')
         dist.init_process_group('gloo', rank=0, world_size=1)
     if only:            # python tests/golden/make_golden.py full  -> only the full-geometry fixtures (minutes of CPU)
-        assert only <= {'full', 'captions'}, only
+        assert only <= {'full', 'captions', 'b32'}, only
         if only == {'captions'}:
             fixture_caption_store()
+            dist.destroy_process_group()
+            return
+        if only == {'b32'}:
+            torch.set_num_threads(8)
+            fixture_vit_b16_1layer(clip_model, 'b32')
+            fixture_full_step_b16(clip_model, xvlm, 'b32')
             dist.destroy_process_group()
             return
         torch.set_num_threads(8)
         fixture_pos_embed(clip_model)
         fixture_vit_b16_1layer(clip_model)
         fixture_full_step_b16(clip_model, xvlm)
+        fixture_vit_b16_1layer(clip_model, 'b32')
+        fixture_full_step_b16(clip_model, xvlm, 'b32')
         dist.destroy_process_group()
         return
     fixture_vit(clip_model)
@@ -604,6 +624,8 @@ def main():
     fixture_pos_embed(clip_model)
     fixture_vit_b16_1layer(clip_model)
     fixture_full_step_b16(clip_model, xvlm)
+    fixture_vit_b16_1layer(clip_model, 'b32')
+    fixture_full_step_b16(clip_model, xvlm, 'b32')
     fixture_caption_store()
     dist.destroy_process_group()
     fixture_model_w2()

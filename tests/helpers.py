@@ -84,17 +84,19 @@ def seeded_tokens(seed, b, L, vocab, min_len=3):
 MBERT_VOCAB = 119547
 B16_GEOMETRY = dict(embed_dim=512, image_resolution=384, vision_layers=12, vision_width=768, vision_patch_size=16,
                     context_length=8, vocab_size=32, transformer_width=64, transformer_heads=1, transformer_layers=1)
+B32_GEOMETRY = dict(B16_GEOMETRY, vision_patch_size=32)        # the reference's hard-coded tower (models/xvlm.py:83-88): 145 tokens
 MBERT_CONFIG = dict(vocab_size=MBERT_VOCAB, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
                     intermediate_size=3072, max_position_embeddings=512)
 
 
-def full_step_batch(b=4, L_t=12, L_c=12):
-    """Inputs of the `full_step_b16` fixture (tests/golden/make_golden.py feeds exactly these to the reference)."""
-    g = torch.Generator().manual_seed(62)
+def full_step_batch(b=4, L_t=12, L_c=12, seed0=62):
+    """Inputs of the `full_step_b16` (seed0 62) / `full_step_b32` (162) fixtures (tests/golden/make_golden.py feeds exactly these
+    to the reference)."""
+    g = torch.Generator().manual_seed(seed0)
     image = torch.randn(b, 3, 384, 384, generator=g)
-    ids_s, m_s = seeded_tokens(63, b, L_t, MBERT_VOCAB)
-    ids_t, m_t = seeded_tokens(64, b, L_t, MBERT_VOCAB)
-    ids_c, m_c = seeded_tokens(65, b, L_c, MBERT_VOCAB)
+    ids_s, m_s = seeded_tokens(seed0 + 1, b, L_t, MBERT_VOCAB)
+    ids_t, m_t = seeded_tokens(seed0 + 2, b, L_t, MBERT_VOCAB)
+    ids_c, m_c = seeded_tokens(seed0 + 3, b, L_c, MBERT_VOCAB)
     idx = torch.arange(b) + 7
     idx[b - 1] = idx[1]
     return dict(image=image, ids_s=ids_s, mask_s=m_s, ids_t=ids_t, mask_t=m_t, ids_c=ids_c, mask_c=m_c, idx=idx)
@@ -108,12 +110,12 @@ def check_weight_sums(sums, z):
         assert abs(sums[n] - float(want)) <= 1e-6 * (1.0 + abs(float(want))), ('seeded weights differ from the fixture', n)
 
 
-def full_geometry_model(compute_dtype='fp32', vision_layers=12, seed=61, text_config=None):
+def full_geometry_model(compute_dtype='fp32', vision_layers=12, seed=61, text_config=None, geometry=None):
     """This project's RetrievalModel at the real ViT-B/16@384 + mBERT geometry with the `full_step_b16` seeded weights (CPU;
     the caller moves it to the GPU).  -> (model, checksum dict)."""
     from leccr_amd.models import RetrievalModel
     from leccr_amd.synthetic import MULTI30K_CFG
-    cfg = dict(MULTI30K_CFG, clip_geometry=dict(B16_GEOMETRY, vision_layers=vision_layers), text_config=dict(text_config or MBERT_CONFIG),
+    cfg = dict(MULTI30K_CFG, clip_geometry=dict(geometry or B16_GEOMETRY, vision_layers=vision_layers), text_config=dict(text_config or MBERT_CONFIG),
                compute_dtype=compute_dtype)
     model = RetrievalModel(cfg)
     model.init_caption_encoder()

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import (T, check_weight_sums, full_geometry_model, full_step_batch, grad_close, grad_rows, load_npz, max_err,
+from tests.helpers import (B32_GEOMETRY, T, check_weight_sums, full_geometry_model, full_step_batch, grad_close, grad_rows, load_npz, max_err,
                            outside_noise_model, seeded_fill_)
 
 pytestmark = pytest.mark.gpu
@@ -31,20 +31,29 @@ def _forward(model, b):
 
 
 # ----------------------------------------------------------------------------------------- 1. reference-captured, real geometry
+GEOMETRIES = {'b16': dict(geometry=None, vit_seed=51, seed=61, seed0=62, tokens=577),
+              # what run_multi30k.sh really instantiates: models/xvlm.py:83-88 hard-codes clip.load('ViT-B/32') -> 145 tokens
+              # (= 2*64 + 17), 3072-wide patch rows (clip/model.py:211-228); also this package's default clip_name
+              'b32': dict(geometry=B32_GEOMETRY, vit_seed=151, seed=161, seed0=162, tokens=145)}
+
+
+@pytest.mark.parametrize('tag', ['b16', 'b32'])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_vit_b16_one_layer_real_geometry_vs_reference(dtype):
+def test_vit_b16_one_layer_real_geometry_vs_reference(dtype, tag):
     """577 tokens x 768 wide x 12 heads of 64, patch 16 at 384, one layer, b = 2: the production ViT kernels (patchify, MFMA /
-    generic GEMMs, flash attention with the 577 = 9*64+1 tail, LayerNorm) against the reference's CLIP class."""
+    generic GEMMs, flash attention with the 577 = 9*64+1 tail, LayerNorm) against the reference's CLIP class.  'b32': the
+    reference's hard-coded default tower - 145 tokens (two 64-key tiles + a 17-key tail), patch 32 (K = 3072 patch rows)."""
     from tests.golden_slices import B16_GRAD_SLICES
-    z = load_npz('vit_b16_1layer.npz')
-    model, _ = full_geometry_model(dtype, vision_layers=1, text_config=MID_BERT)       # (the text tower is not used here)
+    G = GEOMETRIES[tag]
+    z = load_npz(f'vit_{tag}_1layer.npz')
+    model, _ = full_geometry_model(dtype, vision_layers=1, text_config=MID_BERT, geometry=G['geometry'])       # (the text tower is not used here)
     vis = model.clip_encoder.visual
-    check_weight_sums(seeded_fill_(vis.named_parameters(), 51), z)
+    check_weight_sums(seeded_fill_(vis.named_parameters(), G['vit_seed']), z)
     model = model.to(DEV).eval()
-    g = torch.Generator().manual_seed(52)
+    g = torch.Generator().manual_seed(G['vit_seed'] + 1)
     image = torch.randn(2, 3, 384, 384, generator=g)
     hidden, _ = model.get_vision_embeds(image.to(DEV))
-    assert hidden.shape == (2, 577, 512)
+    assert hidden.shape == (2, G['tokens'], 512)
     tol = 1e-3 if dtype == 'fp32' else 6e-2            # bf16: |hidden| ~ 0.7 +- 8-bit mantissas through 8 roundings
     rows = [int(r) for r in z['rows']]
     assert max_err(hidden[:, rows, :].float(), z['hidden_rows']) < tol
@@ -68,16 +77,19 @@ def test_vit_b16_one_layer_real_geometry_vs_reference(dtype):
             assert rel <= 5e-2, (k, rel)
 
 
+@pytest.mark.parametrize('tag', ['b16', 'b32'])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_full_step_b16_mbert_vs_reference(dtype):
+def test_full_step_b16_mbert_vs_reference(dtype, tag):
     """SURVEY 8(c) `full_step_b16`: the full 12 + 12-layer model, b = 4, against the five losses, three feature matrices and
-    gradient slices the REFERENCE produced with the same seeded weights."""
+    gradient slices the REFERENCE produced with the same seeded weights.  'b32' = `full_step_b32`: the same with the tower the
+    reference's build_clip_encoder hard-codes (ViT-B/32 @384: what "drops into run_multi30k.sh unchanged" runs)."""
     from tests.golden_slices import FULL_STEP_GRAD_SLICES
-    z = load_npz('full_step_b16.npz')
-    model, sums = full_geometry_model(dtype)
+    G = GEOMETRIES[tag]
+    z = load_npz(f'full_step_{tag}.npz')
+    model, sums = full_geometry_model(dtype, seed=G['seed'], geometry=G['geometry'])
     check_weight_sums(sums, z)
     model = model.to(DEV).eval()
-    b = full_step_batch()
+    b = full_step_batch(seed0=G['seed0'])
     with torch.no_grad():
         v, _ = model.get_vision_embeds(b['image'].to(DEV))
         c = model.get_caption_embeds(b['ids_c'].to(DEV), b['mask_c'].to(DEV))
@@ -302,7 +314,7 @@ def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, monkeypatch):
     # the fp8 kernel really ran: every encoder Linear's activation site was used, and the last product of the text tower was fp8
     blk = model.clip_encoder.visual.transformer.resblocks[0]
     lay = model.text_encoder.encoder.layer[1]
-    assert model.fp8_sites.n == 3 * (2 * 4 + 2 * 4)
+    assert model.fp8_sites.n == 2 * (2 * 4 + 2 * 4) and model.fp8_weight_sites.n == 2 * 4 + 2 * 4
     assert all(h._xsite.primed for h in (blk.attn.in_proj_weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight, lay._qkv_w, lay.output.dense.weight))
     got = [float(l) for l in losses]
     for a, r, nz in zip(got, ref_losses, noise_losses):
@@ -365,3 +377,41 @@ def test_persistent_gemm_paths_in_a_model_vs_oracle():
     bad = outside_noise_model(rows)
     assert not bad, (len(bad), bad[:8])
     assert blk.mlp.c_fc.bias.grad.abs().sum() > 0
+
+
+def test_fp8_weight_copies_and_their_scale_stay_together_when_a_weight_grows():
+    """A weight's fp8 copies are written once per optimizer step and read by every product until the next one, while the 1/scale of
+    the product is read at kernel time: both must come from the SAME scale.  Round 2 requantised under the site's previous scale and
+    let the per-step Fp8Sites.update() replace it afterwards - silently 2x / 0.5x off for one step whenever a weight's amax crossed a
+    power of two.  Here two Linears' weights are multiplied by 4 and by 1/4 between two steps (what many optimizer steps do slowly);
+    the fp8 tower must stay as close to the bf16 tower with the same weights as it was before."""
+    from leccr_amd.models import RetrievalModel
+    from leccr_amd.synthetic import MULTI30K_CFG, make_batch
+
+    def tower(dtype):
+        torch.manual_seed(17)
+        m = RetrievalModel(dict(MULTI30K_CFG, clip_geometry=L14_GEOMETRY, text_config=dict(XLMR_LARGE_2L, vocab_size=30000),
+                                compute_dtype=dtype, clip_text_tower=False))
+        m.init_caption_encoder()
+        seeded_fill_(m.named_parameters(), 93)
+        return m.to(DEV).eval()
+    m8, m16 = tower('fp8'), tower('bf16')
+    mb = make_batch(8, vocab=30000)
+    batch = dict(image=mb['image'], ids_s=mb['text'][0].input_ids, mask_s=mb['text'][0].attention_mask, ids_t=mb['text'][1].input_ids,
+                 mask_t=mb['text'][1].attention_mask, ids_c=mb['captions'].input_ids, mask_c=mb['captions'].attention_mask, idx=mb['idx'])
+    image = batch['image'].to(DEV)
+
+    def rel(a, b):
+        return float((a.float() - b.float()).norm() / b.float().norm())
+    with torch.no_grad():
+        _forward(m8, batch)                                   # step 1: primes the activation sites
+        before = rel(m8.get_vision_embeds(image)[0], m16.get_vision_embeds(image)[0])
+        for m in (m8, m16):
+            blk = m.clip_encoder.visual.transformer.resblocks[0]
+            blk.mlp.c_fc.weight.mul_(4.0)
+            blk.attn.out_proj.weight.mul_(0.25)
+            m.refresh_weights()                               # what optimizer.step() calls: compute copies + fp8 requantisation
+        _forward(m8, batch)                                   # step 2: Fp8Sites.update() runs first - it must not move a weight's scale
+        after = rel(m8.get_vision_embeds(image)[0], m16.get_vision_embeds(image)[0])
+    assert before < 0.1, before
+    assert after < max(0.1, 2.0 * before), (before, after)

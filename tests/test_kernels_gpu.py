@@ -195,7 +195,13 @@ def _ref_attn(q, k, v, heads, kmask):
                                                      # 64 n + 1 rows (class token + patch grid): the odd key / query row runs
                                                      # behind the tile loop on the VALU
                                                      (2, 4, 129, 129, 64, True), (2, 4, 193, 70, 64, True),
-                                                     (2, 4, 70, 257, 64, True), (2, 2, 65, 65, 64, False)])
+                                                     (2, 4, 70, 257, 64, True), (2, 2, 65, 65, 64, False),
+                                                     # the reference's default tower (ViT-B/32 @384: 145 tokens = 2*64 + 17) and
+                                                     # ViT-L/14 (730 = 11*64 + 26)
+                                                     (2, 12, 145, 145, 64, False), (1, 16, 730, 730, 64, False),
+                                                     # CrossAttention heads at vision_width 768 (config E: 8 heads of 96) and 1024
+                                                     (2, 8, 4, 64, 96, True), (2, 8, 145, 4, 96, False), (2, 8, 4, 730, 96, False),
+                                                     (2, 8, 4, 64, 128, True), (2, 8, 200, 4, 128, False), (2, 8, 4, 577, 128, False)])
 def test_attention(K, dtype, b, heads, Lq, Lk, hd, masked):
     d = heads * hd
     # packed projection buffers: q|k|v side by side (strided views), as the model uses them

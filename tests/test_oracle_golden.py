@@ -183,18 +183,21 @@ def _fill_oracle_state(module_named_params, seed):
     return {n: p.detach().clone() for n, p in named}, sums
 
 
-def test_vit_b16_one_layer_real_geometry_vs_reference():
+@pytest.mark.parametrize('tag', ['b16', 'b32'])
+def test_vit_b16_one_layer_real_geometry_vs_reference(tag):
     """The oracle's ViT at the REAL B/16 geometry (577 tokens, 768 wide, 12 heads of 64, patch 16 at 384) against the
-    reference's CLIP class on the same seeded weights / image (tests/golden/vit_b16_1layer.npz): trunk, hidden, gradients."""
+    reference's CLIP class on the same seeded weights / image (tests/golden/vit_b16_1layer.npz): trunk, hidden, gradients.
+    'b32': the tower the reference hard-codes (models/xvlm.py:83-88; 145 tokens, 3072-wide patch rows)."""
     from leccr_amd.models.clip_vit import CLIP
-    from tests.helpers import B16_GEOMETRY, check_weight_sums
-    z = load_npz('vit_b16_1layer.npz')
-    clip = CLIP(text_tower=False, **dict(B16_GEOMETRY, vision_layers=1))
-    sd, sums = _fill_oracle_state(clip.visual.named_parameters(), 51)
+    from tests.helpers import B16_GEOMETRY, B32_GEOMETRY, check_weight_sums
+    z = load_npz(f'vit_{tag}_1layer.npz')
+    geo, seed = {'b16': (B16_GEOMETRY, 51), 'b32': (B32_GEOMETRY, 151)}[tag]
+    clip = CLIP(text_tower=False, **dict(geo, vision_layers=1))
+    sd, sums = _fill_oracle_state(clip.visual.named_parameters(), seed)
     check_weight_sums(sums, z)
     for v in sd.values():
         v.requires_grad_(True)
-    g = torch.Generator().manual_seed(52)
+    g = torch.Generator().manual_seed(seed + 1)
     image = torch.randn(2, 3, 384, 384, generator=g)
     trunk = O.vit_trunk(sd, '', image)
     assert max_err(trunk[:, :, ::16], z['trunk_cols16']) < 5e-5
@@ -214,17 +217,18 @@ def test_vit_b16_one_layer_real_geometry_vs_reference():
     assert n == 10
 
 
-def test_full_step_b16_mbert_forward_vs_reference():
-    """SURVEY 8(c) `full_step_b16`: the oracle at the real ViT-B/16@384 + mBERT geometry (12 + 12 layers, vocab 119 547) on the
+@pytest.mark.parametrize('tag', ['b16', 'b32'])
+def test_full_step_b16_mbert_forward_vs_reference(tag):
+    """'b32' = the reference's default tower.  SURVEY 8(c) `full_step_b16`: the oracle at the real ViT-B/16@384 + mBERT geometry (12 + 12 layers, vocab 119 547) on the
     seeded weights reproduces the REFERENCE's features and five losses (forward only here: ~20 s of CPU; the gradients of this
     fixture are checked against the HIP model on the GPU)."""
-    from tests.helpers import check_weight_sums, full_geometry_model, full_step_batch
-    z = load_npz('full_step_b16.npz')
-    model, sums = full_geometry_model()
+    from tests.helpers import B32_GEOMETRY, check_weight_sums, full_geometry_model, full_step_batch
+    z = load_npz(f'full_step_{tag}.npz')
+    model, sums = full_geometry_model() if tag == 'b16' else full_geometry_model(seed=161, geometry=B32_GEOMETRY)
     check_weight_sums(sums, z)
     sd = {k: v.detach() for k, v in model.state_dict().items() if not k.startswith('caption_encoder.')}
     del model
-    b = full_step_batch()
+    b = full_step_batch(seed0=62 if tag == 'b16' else 162)
     torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
     with torch.no_grad():
         vis = O.encode_image(sd, 'clip_encoder.visual.', b['image'])

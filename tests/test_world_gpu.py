@@ -1,0 +1,245 @@
+"""The world shapes of BASELINE configs C and E - global batch G = 1024 and 2048 over W = 8 ranks (and W = 4) - on the one-GPU box.
+
+What a big world changes is the loss stage and its gradient routing: the packed all-gather of six feature blocks + idx
+(models/xvlm.py:50-70 semantics), G x G similarity terms of which each rank's backward keeps its own b rows (`local_rows`), and the mixed
+scaling under DDP averaging - 1/W for parameters in front of the gather, the FULL gradient for `temp` and (reference: post-gather)
+`cproj` / `vproj` (model_retrieval_caption.py:94-143).  The towers are tiny (that part is covered at full geometry
+elsewhere), the loss stage runs at the production embed_dim 256 / 4 queries and at the REAL G.
+
+Yardstick: the CPU oracle run under W-rank gloo (W real processes, DDP-style SUM / W of the parameter gradients) on the same seeded
+weights and the same global batch.
+
+HIP side, two ways:
+  * W = 4 real processes under gloo, all on cuda:0 (G = 1024: b = 256 per rank) - real collectives, real grad_sync;
+  * W = 8 through a LOOPBACK world in one process.  The GPU box's process guard allows at most 6 processes on the card, so eight
+    real ranks cannot share it.  The loopback replaces only the transport: torch.distributed's rank / world / all_gather entry points
+    are patched so that rank r's forward receives the blocks the other seven ranks produced (recorded in a first pass over all ranks;
+    eval mode, so the replayed blocks are bit-identical to what those ranks would send).  Everything else is the product code as it
+    runs on 8 GPUs: AllGatherPacked forward / backward, the `nccl` branch's flat all_gather_into_tensor layout (never executed before:
+    the development box has one GPU), local_rows, W-scaled dtemp / cproj / vproj.  Gradients are summed over the eight rank passes and
+    divided by W, as grad_sync + AdamW's grad_scale do.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+WORLD_VIT = dict(embed_dim=64, image_resolution=32, vision_layers=2, vision_width=64, vision_patch_size=16, context_length=8,
+                 vocab_size=32, transformer_width=64, transformer_heads=1, transformer_layers=1)          # 5 tokens, vision_width 64
+WORLD_BERT = dict(vocab_size=200, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                  max_position_embeddings=40)
+WORLD_CFG = {'embed_dim': 256, 'temp': 0.07, 'use_one_cl_proj_only': False, 'caption_encoder_name': 'mbert', 'num_queries': 4,
+             'caption_ca_layer': 2, 'caption_interaction_layer': 2, 'weight_reg_loss': 0.01, 'weight_caption_loss': 0.01,
+             'weight_dstl_loss': 0.5, 'weight_cv_loss': 0.01, 'clip_geometry': WORLD_VIT, 'text_config': WORLD_BERT,
+             'compute_dtype': 'fp32', 'clip_text_tower': False}
+WL = {k: WORLD_CFG[k] for k in ('weight_reg_loss', 'weight_caption_loss', 'weight_dstl_loss', 'weight_cv_loss')}
+
+
+def world_model():
+    """The model with name-seeded weights (tests.helpers.seeded_fill_: the same values in every process that builds it)."""
+    from leccr_amd.models import RetrievalModel
+    from tests.helpers import seeded_fill_
+    torch.manual_seed(0)
+    m = RetrievalModel(dict(WORLD_CFG))
+    m.init_caption_encoder()
+    seeded_fill_(m.named_parameters(), 201, std=0.08)
+    with torch.no_grad():
+        m.queries.normal_(0, 0.5, generator=torch.Generator().manual_seed(202))
+    return m
+
+
+def world_batch(G):
+    """The GLOBAL batch (rank r takes rows r*b .. (r+1)*b): 1 row in 16 repeats its neighbour's idx (soft labels, xvlm.py:283-290)."""
+    g = torch.Generator().manual_seed(203)
+    image = torch.randn(G, 3, 32, 32, generator=g)
+
+    def tokens(L):          # [CLS]=101 .. [SEP]=102, 0 padding; row 0 full length
+        ids = torch.randint(103, 200, (G, L), generator=g)
+        lens = torch.randint(3, L + 1, (G,), generator=g)
+        lens[0] = L
+        mask = (torch.arange(L)[None, :] < lens[:, None]).long()
+        ids[:, 0] = 101
+        ids[torch.arange(G), lens - 1] = 102
+        return ids * mask, mask
+    (ids_s, m_s), (ids_t, m_t), (ids_c, m_c) = tokens(8), tokens(8), tokens(12)
+    idx = torch.arange(G) + 1000
+    idx[15::16] = idx[14::16]
+    return dict(image=image, ids_s=ids_s, mask_s=m_s, ids_t=ids_t, mask_t=m_t, ids_c=ids_c, mask_c=m_c, idx=idx)
+
+
+# ----------------------------------------------------------------------------------------- the yardstick: oracle under W-rank gloo
+def _oracle_rank(rank, world, port, G, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from oracle import leccr_oracle as O
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in world_model().state_dict().items()
+          if not k.startswith('caption_encoder.')}
+    z = world_batch(G)
+    b = G // world
+    g = lambda k: z[k][rank * b:(rank + 1) * b]
+    losses = O.retrieval_forward(sd, WL, g('image'), g('ids_s'), g('mask_s'), g('ids_t'), g('mask_t'), g('ids_c'), g('mask_c'),
+                                 g('idx'), text_heads=2)
+    sum(losses).backward()
+    grads = {}
+    for k in sorted(sd):
+        if sd[k].grad is not None:
+            gr = sd[k].grad.clone()
+            dist.all_reduce(gr)                   # DDP: SUM, then / W (image_Retrieval_caption.py:390-392)
+            grads[k] = (gr / world).numpy()
+    ret[rank] = [float(l.detach()) for l in losses]
+    if rank == 0:
+        ret['grads'] = grads
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+_oracle_cache = {}
+
+
+def oracle_world(world, G):
+    """-> (per-rank losses [W][5], DDP-averaged gradients {name: array}) of the oracle under `world` gloo ranks (CPU processes)."""
+    if (world, G) not in _oracle_cache:
+        ret = mp.Manager().dict()
+        mp.spawn(_oracle_rank, args=(world, 29800 + world + G // 64, G, ret), nprocs=world, join=True)
+        _oracle_cache[(world, G)] = ([ret[r] for r in range(world)], dict(ret['grads']))
+    return _oracle_cache[(world, G)]
+
+
+def _check(losses_per_rank, grads, want_losses, want_grads):
+    bad = []
+    for r, (got, want) in enumerate(zip(losses_per_rank, want_losses)):
+        if max(abs(a - w) for a, w in zip(got, want)) > 1e-3:          # north star: fp32 logits / losses within 1e-3
+            bad.append(('losses', r, got, want))
+    # every rank reports the same five losses (each evaluates the full G x G terms), except the two local-batch terms
+    gmax = max(float(np.linalg.norm(v)) for v in want_grads.values())
+    n = 0
+    for k, want in want_grads.items():
+        got = grads[k]
+        wn, err = float(np.linalg.norm(want)), float(np.linalg.norm(got.astype(np.float64) - want))
+        if wn < 1e-6 * gmax:
+            continue
+        n += 1
+        if err > 2e-3 * wn:
+            bad.append((k, err / wn))
+    return n, bad
+
+
+# ----------------------------------------------------------------------------------------- W = 4, real processes on the GPU
+def _hip_rank(rank, world, port, G, ret):
+    from tests.test_dist_gpu import _init
+    _init(rank, world, port)
+    from leccr_amd.optim import create_optimizer
+    from leccr_amd.parallel import attach_grad_sync
+    from tests.test_model_gpu import Enc
+    model = world_model().to(DEV).eval()
+    opt = attach_grad_sync(create_optimizer(dict(lr=0.0, weight_decay=0.0), model))
+    z = world_batch(G)
+    b = G // world
+    g = lambda k: z[k][rank * b:(rank + 1) * b].to(DEV)
+    losses = model(g('image'), [Enc(g('ids_s'), g('mask_s')), Enc(g('ids_t'), g('mask_t'))], captions=Enc(g('ids_c'), g('mask_c')),
+                   idx=g('idx'))
+    opt.zero_grad()
+    sum(losses).backward()
+    opt.grad_sync()
+    ret[rank] = [float(l.detach()) for l in losses]
+    if rank == 0:
+        ret['grads'] = {k: (p.grad * opt.grad_scale).cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_real_ranks_at_global_batch_1024_match_the_oracle_world():
+    want_losses, want_grads = oracle_world(4, 1024)
+    ret = mp.Manager().dict()
+    mp.spawn(_hip_rank, args=(4, 29861, 1024, ret), nprocs=4, join=True)
+    n, bad = _check([ret[r] for r in range(4)], ret['grads'], want_losses, want_grads)
+    assert n > 60 and not bad, (n, bad[:6])
+
+
+# ----------------------------------------------------------------------------------------- W = 8, loopback world
+class LoopbackWorld:
+    """torch.distributed's entry points as the model sees them, for rank `rank` of `world`, served from recorded blocks."""
+
+    def __init__(self, world, backend):
+        self.world, self.backend, self.rank = world, backend, 0
+        self.sent = {}              # (rank, call number) -> the flat block that rank hands to its c-th all-gather
+        self.replay, self.calls = False, 0
+        self.into_tensor_calls = self.list_calls = 0
+
+    def install(self, monkeypatch):
+        monkeypatch.setattr(dist, 'is_initialized', lambda: True)
+        monkeypatch.setattr(dist, 'get_rank', lambda group=None: self.rank)
+        monkeypatch.setattr(dist, 'get_world_size', lambda group=None: self.world)
+        monkeypatch.setattr(dist, 'get_backend', lambda group=None: self.backend)
+        monkeypatch.setattr(dist, 'all_gather_into_tensor', self._into_tensor)
+        monkeypatch.setattr(dist, 'all_gather', self._list)
+
+    def begin(self, rank, replay):
+        self.rank, self.replay, self.calls = rank, replay, 0
+
+    def _blocks(self, mine):
+        c, self.calls = self.calls, self.calls + 1
+        if not self.replay:
+            self.sent[(self.rank, c)] = mine.detach().clone()
+            return [mine] * self.world                        # placeholder peers: only what this rank SENDS is wanted from this pass
+        assert torch.equal(self.sent[(self.rank, c)], mine), 'a rank does not reproduce the block it sent in the recording pass'
+        return [self.sent[(r, c)] for r in range(self.world)]
+
+    def _into_tensor(self, out, inp, group=None, async_op=False):          # RCCL layout: rank r's block at [r * n, (r + 1) * n)
+        self.into_tensor_calls += 1
+        assert out.dim() == 1 and inp.dim() == 1 and out.numel() == self.world * inp.numel()
+        out.view(self.world, -1).copy_(torch.stack(self._blocks(inp)))
+
+    def _list(self, outs, inp, group=None, async_op=False):
+        self.list_calls += 1
+        for o, blk in zip(outs, self._blocks(inp)):
+            o.copy_(blk)
+
+
+@pytest.mark.parametrize('backend', ['nccl', 'gloo'])         # which branch of AllGather / AllGatherPacked packs and unpacks
+@pytest.mark.parametrize('G', [1024, 2048])                   # BASELINE configs C (8 x 128) and E (8 x 256)
+def test_eight_rank_loopback_world_matches_the_oracle_world(G, backend, monkeypatch):
+    from tests.test_model_gpu import Enc
+    W = 8
+    want_losses, want_grads = oracle_world(W, G)
+    model = world_model().to(DEV).eval()
+    model._ensure_runtime()
+    z = world_batch(G)
+    b = G // W
+    lw = LoopbackWorld(W, backend)
+    lw.install(monkeypatch)
+
+    def step(rank, replay):
+        lw.begin(rank, replay)
+        g = lambda k: z[k][rank * b:(rank + 1) * b].to(DEV)
+        return model(g('image'), [Enc(g('ids_s'), g('mask_s')), Enc(g('ids_t'), g('mask_t'))], captions=Enc(g('ids_c'), g('mask_c')),
+                     idx=g('idx'))
+
+    with torch.no_grad():
+        for r in range(W):
+            step(r, False)
+    assert lw.calls == 1, 'one packed all-gather per step'          # six feature blocks + idx in ONE collective
+    total = torch.zeros_like(model.arena.grad)
+    losses = []
+    for r in range(W):
+        out = step(r, True)
+        model.arena.zero_grad()
+        sum(out).backward()
+        torch.cuda.synchronize()
+        total += model.arena.grad
+        losses.append([float(l.detach()) for l in out])
+    assert (lw.into_tensor_calls > 0) == (backend == 'nccl') and (lw.list_calls > 0) == (backend == 'gloo')
+    model.arena.grad.copy_(total / W)
+    grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
+    n, bad = _check(losses, grads, want_losses, want_grads)
+    assert n > 60 and not bad, (n, bad[:6])
+    # the mixed scaling is really in play: temp / cproj / vproj carry the FULL gradient, everything else 1/W of it - so against a
+    # single-process pass over the whole batch (W = 1 semantics) temp's gradient is equal and an encoder weight's is 1/W of it
+    assert float(np.abs(grads['temp']).max()) > 0 and float(np.abs(grads['cproj.weight']).max()) > 0
