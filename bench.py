@@ -291,7 +291,7 @@ def parity_probe(args, cfg, model, batch, fwd, rows=16, with_losses=True):
             ferr = [float((a - r).abs().max()) for a, r in zip(feats, ref)]
             pairs = ((0, 1), (0, 2), (1, 2))                 # v-s, v-t, s-t: the three get_contrastive_loss calls of a step
             lerr = [float(((feats[i] @ feats[j].t()) / temp - (ref[i] @ ref[j].t()) / temp).abs().max()) for i, j in pairs]
-            ftol, ltol = {'fp32': (1e-4, 1e-3), 'bf16': (2e-2, 0.3), 'fp8': (6e-2, 1.0)}[args.dtype]
+            ftol, ltol = {'fp32': (1e-4, 1e-3), 'bf16': (1e-2, 0.15), 'fp8': (4e-2, 0.6)}[args.dtype]      # bf16 measured: 2.5e-3 / 0.035
             out.update(max_abs_feature_err={'image': round(ferr[0], 7), 'text_src': round(ferr[1], 7), 'text_tgt': round(ferr[2], 7)},
                        max_abs_logits_err={'v_s': round(lerr[0], 6), 'v_t': round(lerr[1], 6), 's_t': round(lerr[2], 6)},
                        feature_tolerance=ftol, logits_tolerance=ltol, temp=round(temp, 6))

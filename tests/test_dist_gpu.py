@@ -13,6 +13,19 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
+_managers = []
+
+
+def _manager():
+    """An mp.Manager whose server process is SPAWNED (a forked one inherits this process's open GPU device and counts against the
+    GPU box's limit of 6 processes on the card for as long as it lives); earlier tests' managers are shut down first."""
+    while _managers:
+        _managers.pop().shutdown()
+    m = mp.get_context('spawn').Manager()
+    _managers.append(m)
+    return m
+
+
 def _init(rank, world, port):
     """Rendezvous of one test rank.  Default: gloo, every rank on cuda:0 (the one-GPU development box).  With
     LECCR_TEST_BACKEND=nccl (tests/test_rccl_gpu.py, nodes with >= 2 GPUs): RCCL, one rank per device - the production layout."""
@@ -60,7 +73,7 @@ def _worker(rank, world, port, ret):
 
 
 def test_two_rank_losses_and_gradients_match_reference_ddp():
-    mgr = mp.Manager()
+    mgr = _manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, 29651, ret), nprocs=2, join=True)
     for r in (0, 1):
@@ -95,7 +108,7 @@ def _train_worker(rank, world, port, fused, ret):
 def test_two_rank_training_with_the_optimizer_fused_into_backward():
     """Two optimizer steps on 2 ranks: every all-reduce phase (early region during the ViT backward, ViT thirds, rest at step())
     and the early parameter update behind its all-reduce give both ranks the same weights, equal to the plain optimizer's."""
-    mgr = mp.Manager()
+    mgr = _manager()
     ret = mgr.dict()
     mp.spawn(_train_worker, args=(2, 29671, True, ret), nprocs=2, join=True)
     mp.spawn(_train_worker, args=(2, 29673, False, ret), nprocs=2, join=True)
@@ -139,7 +152,7 @@ def _eval_worker(rank, world, port, ret):
 
 
 def test_two_rank_sharded_evaluation_matches_unsharded():
-    mgr = mp.Manager()
+    mgr = _manager()
     ret = mgr.dict()
     mp.spawn(_eval_worker, args=(2, 29653, ret), nprocs=2, join=True)
     for r in (0, 1):

@@ -413,5 +413,15 @@ def test_fp8_weight_copies_and_their_scale_stay_together_when_a_weight_grows():
             m.refresh_weights()                               # what optimizer.step() calls: compute copies + fp8 requantisation
         _forward(m8, batch)                                   # step 2: Fp8Sites.update() runs first - it must not move a weight's scale
         after = rel(m8.get_vision_embeds(image)[0], m16.get_vision_embeds(image)[0])
+        # the copies and the scale the products read belong together: dequantised, they ARE the bf16 weights to e4m3 rounding (2^-4
+        # relative per element; the round-2 bug left them 4x / 0.25x apart for a step)
+        blk = m8.clip_encoder.visual.transformer.resblocks[0]
+        for h in (blk.mlp.c_fc.weight, blk.attn.out_proj.weight, blk.attn.in_proj_weight):
+            inv = float(h._wsite.inv_scale)
+            for q8, lp in ((h._q8, h._lp), (h._q8t, h._lpt)):
+                deq = q8.float() * inv
+                assert rel(deq, lp) < 0.04, (rel(deq, lp), inv)
+                assert float(deq.abs().max()) <= 1.07 * float(lp.float().abs().max())
     assert before < 0.1, before
-    assert after < max(0.1, 2.0 * before), (before, after)
+    # (the 4x larger MLP branch of block 0 carries 4x its fp8 noise into the residual stream: measured 0.053 -> 0.138)
+    assert after < 0.3, (before, after)

@@ -27,7 +27,7 @@ def _nccl_backend(monkeypatch):
 
 def test_rccl_two_rank_losses_and_gradients_match_reference_ddp():
     """AllGatherPacked / AllGather over RCCL + the summed gradients: the reference's 2-rank DDP fixture, as under gloo."""
-    ret = mp.Manager().dict()
+    ret = D._manager().dict()
     mp.spawn(D._worker, args=(2, 29751, ret), nprocs=2, join=True)
     for r in (0, 1):
         n, bad = ret[r]
@@ -40,7 +40,7 @@ def test_rccl_phased_all_reduce_equals_plain_and_cu_reservation_changes_nothing(
     the optimizer fused into backward, against the plain optimizer; LECCR_RCCL_CUS = 16 (GEMMs on 240 CUs while a reduce is in
     flight, NCCL_MAX_NCHANNELS = 16) must give the same weights as 0."""
     monkeypatch.setenv('LECCR_RCCL_CUS', cus)
-    ret = mp.Manager().dict()
+    ret = D._manager().dict()
     mp.spawn(D._train_worker, args=(2, 29761 + int(cus), True, ret), nprocs=2, join=True)
     mp.spawn(D._train_worker, args=(2, 29781 + int(cus), False, ret), nprocs=2, join=True)
     (f0, n0), (f1, _), (p0, _), (p1, _) = ret[(True, 0)], ret[(True, 1)], ret[(False, 0)], ret[(False, 1)]
@@ -49,7 +49,7 @@ def test_rccl_phased_all_reduce_equals_plain_and_cu_reservation_changes_nothing(
 
 
 def test_rccl_sharded_evaluation_matches_unsharded():
-    ret = mp.Manager().dict()
+    ret = D._manager().dict()
     mp.spawn(D._eval_worker, args=(2, 29753, ret), nprocs=2, join=True)
     for r in (0, 1):
         shape, err, tr = ret[r]

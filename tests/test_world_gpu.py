@@ -20,6 +20,7 @@ HIP side, two ways:
     divided by W, as grad_sync + AdamW's grad_scale do.
 """
 import os
+import tempfile
 
 import numpy as np
 import pytest
@@ -74,13 +75,13 @@ def world_batch(G):
 
 
 # ----------------------------------------------------------------------------------------- the yardstick: oracle under W-rank gloo
-def _oracle_rank(rank, world, port, G, ret):
+def _oracle_rank(rank, world, port, G, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
     from oracle import leccr_oracle as O
-    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in world_model().state_dict().items()
-          if not k.startswith('caption_encoder.')}
+    # (the weights come from a file the parent wrote: an oracle rank imports torch and oracle/ only - never leccr_amd, never the GPU)
+    sd = {k: v.requires_grad_(v.is_floating_point()) for k, v in torch.load(os.path.join(out_dir, 'weights.pt')).items()}
     z = world_batch(G)
     b = G // world
     g = lambda k: z[k][rank * b:(rank + 1) * b]
@@ -93,9 +94,8 @@ def _oracle_rank(rank, world, port, G, ret):
             gr = sd[k].grad.clone()
             dist.all_reduce(gr)                   # DDP: SUM, then / W (image_Retrieval_caption.py:390-392)
             grads[k] = (gr / world).numpy()
-    ret[rank] = [float(l.detach()) for l in losses]
-    if rank == 0:
-        ret['grads'] = grads
+    torch.save({'losses': [float(l.detach()) for l in losses], 'grads': grads if rank == 0 else None},
+               os.path.join(out_dir, f'oracle_{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -106,9 +106,14 @@ _oracle_cache = {}
 def oracle_world(world, G):
     """-> (per-rank losses [W][5], DDP-averaged gradients {name: array}) of the oracle under `world` gloo ranks (CPU processes)."""
     if (world, G) not in _oracle_cache:
-        ret = mp.Manager().dict()
-        mp.spawn(_oracle_rank, args=(world, 29800 + world + G // 64, G, ret), nprocs=world, join=True)
-        _oracle_cache[(world, G)] = ([ret[r] for r in range(world)], dict(ret['grads']))
+        # results travel through files, not an mp.Manager: a Manager's server process is FORKED from this one and inherits its open
+        # GPU device - one more "process on the card" for the box's process guard (limit 6) per Manager alive
+        with tempfile.TemporaryDirectory() as d:
+            sd = {k: v.detach().clone() for k, v in world_model().state_dict().items() if not k.startswith('caption_encoder.')}
+            torch.save(sd, os.path.join(d, 'weights.pt'))
+            mp.spawn(_oracle_rank, args=(world, 29800 + world + G // 64, G, d), nprocs=world, join=True)
+            res = [torch.load(os.path.join(d, f'oracle_{r}.pt'), weights_only=False) for r in range(world)]
+        _oracle_cache[(world, G)] = ([r['losses'] for r in res], res[0]['grads'])
     return _oracle_cache[(world, G)]
 
 
@@ -132,7 +137,7 @@ def _check(losses_per_rank, grads, want_losses, want_grads):
 
 
 # ----------------------------------------------------------------------------------------- W = 4, real processes on the GPU
-def _hip_rank(rank, world, port, G, ret):
+def _hip_rank(rank, world, port, G, out_dir):
     from tests.test_dist_gpu import _init
     _init(rank, world, port)
     from leccr_amd.optim import create_optimizer
@@ -148,18 +153,18 @@ def _hip_rank(rank, world, port, G, ret):
     opt.zero_grad()
     sum(losses).backward()
     opt.grad_sync()
-    ret[rank] = [float(l.detach()) for l in losses]
-    if rank == 0:
-        ret['grads'] = {k: (p.grad * opt.grad_scale).cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
+    grads = {k: (p.grad * opt.grad_scale).cpu().numpy() for k, p in model.named_parameters() if p.grad is not None} if rank == 0 else None
+    torch.save({'losses': [float(l.detach()) for l in losses], 'grads': grads}, os.path.join(out_dir, f'hip_{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_four_real_ranks_at_global_batch_1024_match_the_oracle_world():
     want_losses, want_grads = oracle_world(4, 1024)
-    ret = mp.Manager().dict()
-    mp.spawn(_hip_rank, args=(4, 29861, 1024, ret), nprocs=4, join=True)
-    n, bad = _check([ret[r] for r in range(4)], ret['grads'], want_losses, want_grads)
+    with tempfile.TemporaryDirectory() as d:          # 4 ranks + this process = 5 processes on the card (the box allows 6)
+        mp.spawn(_hip_rank, args=(4, 29861, 1024, d), nprocs=4, join=True)
+        res = [torch.load(os.path.join(d, f'hip_{r}.pt'), weights_only=False) for r in range(4)]
+    n, bad = _check([r['losses'] for r in res], res[0]['grads'], want_losses, want_grads)
     assert n > 60 and not bad, (n, bad[:6])
 
 
