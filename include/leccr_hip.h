@@ -175,6 +175,9 @@ int leccr_layernorm_bwd_ex(const void* dy, const void* x_in, const float* gamma,
  * kept probabilities scaled by 1/(1-drop_p) AFTER the softmax normalisation (the row sum uses the undropped values);
  * the backward regenerates the mask from the same seed.  drop_p = 0 disables it.
  */
+int leccr_set_attn_variant(int v);            /* bf16 head-64 MFMA kernels: 32 = 32 rows per wave, v_mfma_f32_32x32x16_bf16 (default),
+                                                * 16 = the 16-row kernels (v_mfma_f32_16x16x32_bf16); 0 = back to the default
+                                                * (environment LECCR_ATTN_FWD); returns the variant in effect.  Tests / benchmarks */
 int leccr_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                    int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
                    int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream);

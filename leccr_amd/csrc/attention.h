@@ -26,5 +26,6 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
                   const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st);
 
 extern bool g_force_generic_attn;
+int attn_set_variant(int v);      // 0 = default (environment), 16 / 32 = queries per wave of the MFMA forward kernel; returns the one in effect
 
 }  // namespace leccr

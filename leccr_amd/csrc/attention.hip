@@ -33,6 +33,8 @@ extern "C" int leccr_attn_fwd(const void* q, const void* k, const void* v, void*
                               : attn_generic_fwd<bf16_t>(q, k, v, o, lse, kmask, D, st);
 }
 
+extern "C" int leccr_set_attn_variant(int v) { return attn_set_variant(v); }
+
 extern "C" int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
                               const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
                               int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,

@@ -18,6 +18,8 @@
 //
 // Replaces nn.MultiheadAttention / BertSelfAttention cores (see include/leccr_hip.h, leccr_attn_*).
 #include "attention.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace leccr {
 
@@ -479,6 +481,322 @@ __global__ __launch_bounds__(NW * 64, 4) void flash_fwd_kernel(FP p) {
         for (int nd = 0; nd < 4; ++nd) store4(op + nd * 16 + 4 * h4, o[nd] * inv);
         if (h4 == 0) p.lse[(b * p.heads + head) * p.Lq + qi] = l > 0.f ? (m * c + __log2f(l)) * kLn2 : INFINITY;
     }
+}
+
+// --------------------------------------------------------------------------------------------------- forward, 32-query waves
+// Round 3.  The 16-query kernel above is bound by VALU + MFMA ISSUE slots at head 64 (profiles/r02_attention_pmc_after.txt: matrix
+// pipe 29 % busy, vector issue 68 %): a 16x16x32 MFMA holds the SIMD's issue port 8 of its 16 cycles, and every K / V fragment read
+// from LDS serves 16 queries.  Here a wave owns 32 queries and computes with v_mfma_f32_32x32x16_bf16 (issue held 8 of 32 cycles):
+//     S^T[64 keys][32 q] = K Q^T     2 key blocks x 4 k-steps = 8 MFMAs; A = K rows (ds_read_b128), B = Q fragments in registers
+//     softmax                        the lane holds 32 scores of ONE query (its partner lane l ^ 32 the other 32 keys): row maximum =
+//                                    16 v_max3 + one permlane32 swap; p = exp2(s c - m c) as before
+//     O^T[64 d][32 q] += V^T P^T     2 d blocks x 4 key steps = 8 MFMAs; A = V^T by ds_read_b64_tr_b16, B = P straight from the S^T
+//                                    accumulators (registers 8s..8s+7 of a 32 x 32 tile are the k-step-s operand: keys
+//                                    16s + 8(j>>2) + 4h + (j&3), which is the row order the transposed V reads are issued in)
+//     l                              the row sum rides the matrix pipe as before (all-ones A operand), now as a 4-MFMA chain from a
+//                                    zero accumulator whose result is folded into l one tile LATER (l = l alpha + sum needs it only
+//                                    then), so no VALU instruction waits on it and no 16-register accumulator is rescaled
+// Per query this halves the LDS fragment traffic and the MFMA issue cycles, and the softmax's per-tile scalar work (maximum merge,
+// alpha, the 1/l bookkeeping) is shared by 32 scores per lane instead of 16.  4 waves = 128 queries per block as before (577 = 4.5
+// blocks either way), 2 blocks per CU.
+// LDS images (128-byte rows of one head's 64 dims, 16-byte chunks XOR-swizzled on the DMA's source address):
+//     K: chunk ^ ((row >> 1) & 7)   - a ds_read_b128 with the ROW on lane & 31 covers all 64 banks in each of its 16-lane groups
+//                                      ((row & 7) would put rows r and r + 24 of a group on the same banks)
+//     V: chunk ^ (4 * bit1(row))    - a transposed read's 32-lane half takes 4 consecutive rows x 64 bytes: rows of equal parity
+//                                      (same bank half) land in different 64-byte groups
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+template <int SW>
+__device__ __forceinline__ int swz32(int row) {
+    return SW == 1 ? (row >> 1) & 7 : ((row >> 1) & 1) << 2;
+}
+
+template <int NT, int SW>
+struct StageSrc32 {
+    const bf16_t* p[512 / NT];
+    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld) {
+#pragma unroll
+        for (int i = 0; i < 512 / NT; ++i) {
+            const int slot = i * NT + (int)threadIdx.x;
+            const int row = slot >> 3, lc = (slot & 7) ^ swz32<SW>(row);
+            p[i] = base + row * ld + lc * 8;
+        }
+    }
+    __device__ __forceinline__ void issue(int64_t elem_off, unsigned char* lds) const {
+        const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
+#pragma unroll
+        for (int i = 0; i < 512 / NT; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(p[i] + elem_off), LDS_PTR(lds + (size_t)(i * NT + wave_base) * 16), 16, 0, 0);
+    }
+    // ragged tile: rows past the end re-read a valid row one tile back (masked or never stored), as stage_tile64
+    __device__ __forceinline__ void issue_clamped(const bf16_t* base, int64_t ld, int64_t row0, int64_t n_rows, unsigned char* lds) const {
+        const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
+#pragma unroll
+        for (int i = 0; i < 512 / NT; ++i) {
+            const int slot = i * NT + (int)threadIdx.x;
+            const int row = slot >> 3, lc = (slot & 7) ^ swz32<SW>(row);
+            int64_t r = row0 + row;
+            if (r >= n_rows) {
+                const int64_t back = r - (n_rows < BT ? n_rows : BT);
+                r = back >= 0 && back < n_rows ? back : n_rows - 1;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(base + r * ld + lc * 8), LDS_PTR(lds + (size_t)(i * NT + wave_base) * 16), 16, 0, 0);
+        }
+    }
+};
+
+// transposed pair for the 32x32x16 A operand: 4 rows at IMM (elements 0..3) and the 4 rows 8 further down (elements 4..7)
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_tr16_pair8(uint32_t addr) {
+    int2_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(IMM));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(IMM + 1024));
+    int4_t v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }   // v_max3_f32
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int i0) {
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)a[i0 + j];
+    return r;
+}
+
+// Bit 16 kb + i set: key key0 + 32 kb + 8 (i >> 2) + (i & 3) is masked (key0 already holds the tile's first key + 4 h of this lane).
+template <int NKB>
+__device__ __forceinline__ uint32_t dead_keys32(const uint8_t* km, int64_t Lk, int64_t key0, bool ragged) {
+    uint32_t dead = 0;
+    if (km) {
+        uint8_t mk[16 * NKB];
+#pragma unroll
+        for (int i = 0; i < 16 * NKB; ++i) {
+            const int64_t key = key0 + 32 * (i >> 4) + 8 * ((i & 15) >> 2) + (i & 3);
+            mk[i] = km[key < Lk ? key : Lk - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 16 * NKB; ++i) dead |= mk[i] ? (1u << i) : 0u;
+    }
+    if (ragged) {
+#pragma unroll
+        for (int i = 0; i < 16 * NKB; ++i) dead |= key0 + 32 * (i >> 4) + 8 * ((i & 15) >> 2) + (i & 3) >= Lk ? (1u << i) : 0u;
+    }
+    return dead;
+}
+
+template <bool DROP, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 1 ? 1 : 2) void flash_fwd32_kernel(FP p) {
+    constexpr int BQ = NW * 32, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t nqb = (p.Lq + BQ - 1) / BQ;
+    const int64_t lb = xcd_block(p.xcd);
+    const int64_t bh = lb / nqb, b = bh / p.heads, head = bh % p.heads;
+    const int64_t q0 = (int64_t)(lb % nqb) * BQ + wave * 32;          // this wave's first query
+    const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
+    const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
+    const bf16_t* Vp = p.v + b * p.Lk * p.ldv + head * HD;
+    const uint8_t* km = p.kmask ? p.kmask + b * p.Lk : nullptr;
+    const float c = p.scale * kLog2e;
+
+    // B-role fragments of Q: lane (r, h) holds Q[q0 + r][16 ks + 8 h + 0..7]
+    bf16x8 qf[4];
+    {
+        const int64_t qr = q0 + r < p.Lq ? q0 + r : p.Lq - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qr * p.ldq + 16 * ks + 8 * h);
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    float m = -INFINITY, l = 0.f, a_prev = 0.f;
+    f32x16 lsum;                                    // row sums of the previous tile's p (every register holds the same value)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) lsum[i] = 0.f;
+
+    const int ntiles = (int)((p.Lk + BT - 1) / BT), nfull = (int)(p.Lk / BT);
+    StageSrc32<NT, 1> ksrc;
+    StageSrc32<NT, 2> vsrc;
+    ksrc.init(Kp, p.ldk);
+    vsrc.init(Vp, p.ldv);
+    auto stage = [&](int t) {
+        unsigned char* st = smem + (t & 1) * FWD_STAGE;
+        if (t < nfull) {
+            ksrc.issue((int64_t)t * BT * p.ldk, st);
+            vsrc.issue((int64_t)t * BT * p.ldv, st + TILE_BYTES);
+        } else {
+            ksrc.issue_clamped(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
+            vsrc.issue_clamped(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
+        }
+    };
+    // per-lane LDS byte offsets.  K rows: row r of a 32-key block, chunk 2 ks + h.  V^T: lane 16 g + 4 q + pp of a transposed read
+    // addresses row 4 h + q, d columns 16 (g & 1) + 4 pp .. + 3 of d block 0; d block 1 = the same ^ 64 (chunk bit 2)
+    uint32_t ka[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = (uint32_t)(r * 128 + (((2 * ks + h) ^ ((r >> 1) & 7)) << 4));
+    uint32_t tv[2];
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        tv[0] = (uint32_t)((4 * h + q) * 128 + (((2 * (g & 1) + (pp >> 1)) ^ (4 * (q >> 1))) << 4) + 8 * (pp & 1));
+        tv[1] = tv[0] ^ 64u;
+    }
+    const uint32_t smem_off = lds_u32(smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // retire the Q loads visibly (see flash_fwd_kernel)
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+    const bool active = __builtin_amdgcn_readfirstlane((int)(q0 < p.Lq));
+    const int rem = (int)(p.Lk - (int64_t)(ntiles - 1) * BT);          // keys of the last tile (1..64)
+    const int nloop = rem <= 32 ? ntiles - 1 : ntiles;                 // a last tile of <= 32 keys runs one key block, behind the loop
+    [[maybe_unused]] const uint32_t drop_row = (uint32_t)((bh * p.Lq + q0 + r) * p.Lk);
+
+    // One tile: NKB key blocks of 32; NS = 16-key steps of the LAST block that hold live keys (the PV product skips dead steps).
+    auto tile = [&](int t, auto nkb_tag, auto ns_tag, uint32_t dead) {
+        constexpr int NKB = decltype(nkb_tag)::value, NS = decltype(ns_tag)::value;
+        const uint32_t kt = smem_off + (t & 1) * FWD_STAGE, vt = kt + TILE_BYTES;
+        bf16x8 kf[NKB][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[0][ks] = lds_b128<0>(kt + ka[ks]);
+            if constexpr (NKB == 2) kf[1][ks] = lds_b128<4096>(kt + ka[ks]);
+        }
+        if constexpr (NKB == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]),
+                         "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]));
+        f32x16 s[NKB];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) s[kb] = MFMA32(kf[kb][ks], qf[ks], ks == 0 ? zero16 : s[kb]);
+        // s[kb][i] = <k[key = 32 kb + 8 (i >> 2) + 4 h + (i & 3)], q[query r]>
+        // V^T fragments of this tile: vf[dt][2 kb + st] = rows (keys) 32 kb + 16 st + 4 h + {0..3, 8..11}, d = 32 dt + r
+        constexpr int NSTEP = 2 * (NKB - 1) + NS;                 // live 16-key steps
+        bf16x8 vf[2][NSTEP];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            vf[dt][0] = lds_tr16_pair8<0>(vt + tv[dt]);
+            if constexpr (NSTEP > 1) vf[dt][1] = lds_tr16_pair8<2048>(vt + tv[dt]);
+            if constexpr (NSTEP > 2) vf[dt][2] = lds_tr16_pair8<4096>(vt + tv[dt]);
+            if constexpr (NSTEP > 3) vf[dt][3] = lds_tr16_pair8<6144>(vt + tv[dt]);
+        }
+        if (dead) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (dead & (1u << (16 * kb + i))) s[kb][i] = -INFINITY;
+        }
+        float mx = max3f(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+        for (int i = 3; i + 1 < 16; i += 2) mx = max3f(mx, s[0][i], s[0][i + 1]);
+        mx = fmaxf(mx, s[0][15]);
+        if constexpr (NKB == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) mx = max3f(mx, s[1][i], s[1][i + 1]);
+        }
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float mn = fmaxf(m, mx);
+        const float msafe = mn == -INFINITY ? 0.f : mn;       // every key so far masked: keep exp2 arguments finite
+        const float mc = msafe * c;
+        const float alpha = exp2_fast(m * c - mc);             // m = -inf -> 0
+        m = mn;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s[kb][i] = exp2_fast(__builtin_fmaf(s[kb][i], c, -mc));
+        if constexpr (DROP) {
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) rs += s[kb][i];
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rs), __float_as_uint(rs), false, false);
+            rs = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            l = l * alpha + rs;
+            // dropout on the probabilities that enter PV; the normaliser keeps the undropped sum
+            const uint32_t base = drop_row + (uint32_t)(t * BT + 4 * h);
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s[kb][i] *= drop_mul(p.drop, base + 32 * kb + 8 * (i >> 2) + (i & 3));
+        } else {
+            l = __builtin_fmaf(l, a_prev, lsum[0]);           // fold the PREVIOUS tile's row sum (its MFMAs have long retired)
+            a_prev = alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        bf16x8 pf[NSTEP];
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) pf[st] = pack8(s[st >> 1], 8 * (st & 1));
+        __builtin_amdgcn_sched_barrier(0);          // keep the softmax above the wait: it is what hides the V reads
+        if constexpr (NSTEP == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[0][2]), "+v"(vf[0][3]), "+v"(vf[1][0]),
+                         "+v"(vf[1][1]), "+v"(vf[1][2]), "+v"(vf[1][3]));
+        else if constexpr (NSTEP == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[1][0]));
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            o[0] = MFMA32(vf[0][st], pf[st], o[0]);
+            o[1] = MFMA32(vf[1][st], pf[st], o[1]);
+            if constexpr (!DROP) lsum = MFMA32(ones, pf[st], st == 0 ? zero16 : lsum);
+        }
+    };
+
+    stage(0);
+    for (int t = 0; t < nloop; ++t) {
+        // key mask bytes of this tile are fetched BEFORE the next tile's DMA is issued (vmcnt retires in order)
+        const bool ragged = t >= nfull;
+        const uint32_t dead = (km || ragged) ? dead_keys32<2>(km, p.Lk, (int64_t)t * BT + 4 * h, ragged) : 0u;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntiles) stage(t + 1);
+        if (!active) continue;
+        tile(t, std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, dead);
+    }
+    if (nloop < ntiles) {
+        const int t = ntiles - 1;
+        const uint32_t dead = dead_keys32<1>(km, p.Lk, (int64_t)t * BT + 4 * h, true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+            if (rem <= 16) tile(t, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, dead);
+            else tile(t, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, dead);
+        }
+    }
+    if constexpr (!DROP) l = __builtin_fmaf(l, a_prev, lsum[0]);
+    // o[dt][i] = O^T[d = 32 dt + 8 (i >> 2) + 4 h + (i & 3)][query r].  One permlane32 swap per register pair gives lane (r, h) the
+    // eight consecutive d of group 2 gg + h: 16-byte stores instead of 8-byte ones
+    const int64_t qi = q0 + r;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    bf16_t* op = p.out + (b * p.Lq + (qi < p.Lq ? qi : p.Lq - 1)) * p.ldo + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            bf16x8 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = o[dt][8 * gg + e] * inv, a1 = o[dt][8 * gg + 4 + e] * inv;
+                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+                w[e] = (bf16_t)__uint_as_float(sw[0]);
+                w[4 + e] = (bf16_t)__uint_as_float(sw[1]);
+            }
+            if (qi < p.Lq) *reinterpret_cast<bf16x8*>(op + 32 * dt + 16 * gg + 8 * h) = w;
+        }
+    if (qi < p.Lq && h == 0) p.lse[(b * p.heads + head) * p.Lq + qi] = l > 0.f ? (m * c + __log2f(l)) * kLn2 : INFINITY;
 }
 
 // --------------------------------------------------------------------------------------------------- backward
@@ -991,6 +1309,19 @@ static int attn_xcd_aware() {      // LECCR_ATTN_XCD=0: plain block order (A/B)
 
 }  // namespace
 
+// Which forward kernel: 32 = 32-query waves / 32x32x16 MFMAs (round 3, default), 16 = the 16-query kernel (LECCR_ATTN_FWD=16, or
+// leccr_set_attn_variant(16): kept as the measured alternative and as a second implementation the tests run against each other).
+static int g_attn_fwd_variant = 0;
+static int attn_fwd_variant() {
+    if (g_attn_fwd_variant) return g_attn_fwd_variant;
+    static const int v = [] { const char* e = getenv("LECCR_ATTN_FWD"); return (e && atoi(e) == 16) ? 16 : 32; }();
+    return v;
+}
+int attn_set_variant(int v) {
+    g_attn_fwd_variant = (v == 16 || v == 32) ? v : 0;
+    return attn_fwd_variant();
+}
+
 bool attn_mfma_supported(const AttnDims& D, int dtype) {
     return dtype == LECCR_BF16 && D.hd == HD && (D.ldq % 8) == 0 && (D.ldk % 8) == 0 && (D.ldv % 8) == 0 &&
            (D.ldo % 8) == 0 && D.b * D.heads * cdiv(D.Lq > D.Lk ? D.Lq : D.Lk, BT) < (1ll << 31);
@@ -1007,6 +1338,21 @@ int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* l
     p.kmask = kmask; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk; p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv;
     p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
     p.xcd = attn_xcd_aware();
+    if (attn_fwd_variant() == 32) {
+        // 32-query waves (v_mfma_f32_32x32x16_bf16): 4 waves = 128 queries per block; short query sets take fewer waves per block
+        // so that a block does not carry waves without rows (BERT: L = 32 / 64; the caption-query side of the interaction: 4)
+#define LAUNCH_F32(NW)                                                                                                   \
+        do {                                                                                                             \
+            dim3 grid((unsigned)(cdiv(D.Lq, 32 * NW) * D.b * D.heads));                                                  \
+            if (D.dropout) hipLaunchKernelGGL((flash_fwd32_kernel<true, NW>), grid, dim3(64 * NW), 2 * FWD_STAGE, st, p); \
+            else hipLaunchKernelGGL((flash_fwd32_kernel<false, NW>), grid, dim3(64 * NW), 2 * FWD_STAGE, st, p);         \
+        } while (0)
+        if (D.Lq <= 32) LAUNCH_F32(1);
+        else if (D.Lq <= 64) LAUNCH_F32(2);
+        else LAUNCH_F32(4);
+#undef LAUNCH_F32
+        return check_launch("flash_fwd32");
+    }
 #ifndef LECCR_ATTN_FWD_SPLIT
 #define LECCR_ATTN_FWD_SPLIT 64
 #endif

@@ -245,6 +245,37 @@ def test_attention(K, dtype, b, heads, Lq, Lk, hd, masked):
         assert e <= (1e-4 if dtype == torch.float32 else 3e-2) * s, (name, e, s)
 
 
+@pytest.mark.parametrize('b,heads,Lq,Lk,masked', [(2, 12, 145, 145, False), (2, 4, 129, 129, True), (2, 8, 4, 70, True), (1, 12, 577, 577, False)])
+def test_attention_16_row_forward_variant(K, b, heads, Lq, Lk, masked):
+    """The round-2 forward kernel (16 queries per wave, v_mfma_f32_16x16x32_bf16) stays selectable (leccr_set_attn_variant(16) /
+    LECCR_ATTN_FWD=16): same checks as test_attention on a few shapes, and the two kernels agree with each other."""
+    from leccr_amd import _lib
+    lib = _lib.lib()
+    d = heads * 64
+    q, kv = _rand((b, Lq, d), torch.bfloat16, 31), _rand((b, Lk, 2 * d), torch.bfloat16, 32)
+    kmask = None
+    if masked:
+        lens = torch.randint(1, Lk + 1, (b,), generator=torch.Generator().manual_seed(33))
+        lens[0] = Lk
+        kmask = (torch.arange(Lk)[None, :] >= lens[:, None]).to(torch.uint8).to(DEV)
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    try:
+        assert lib.leccr_set_attn_variant(16) == 16
+        o16, lse16 = K.attn_fwd(qd, kvd[..., :d], kvd[..., d:], heads, kmask)
+        assert lib.leccr_set_attn_variant(32) == 32
+        o32, lse32 = K.attn_fwd(qd, kvd[..., :d], kvd[..., d:], heads, kmask)
+    finally:
+        lib.leccr_set_attn_variant(0)
+    ref, ref_lse = _ref_attn(q.double(), kv[..., :d].double(), kv[..., d:].double(), heads, kmask.cpu() if masked else None)
+    for o, lse in ((o16, lse16), (o32, lse32)):
+        e, s_ = _err(o, ref)
+        assert e <= _tol(torch.bfloat16) * s_, (e, s_)
+        e, s_ = _err(lse, ref_lse)
+        assert e <= 3e-3, e
+    e, s_ = _err(o16, o32.double().cpu())
+    assert e <= 2 * 2 ** -8 * s_, (e, s_)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 def test_colsum_and_l2norm(K, dtype):
     x = _rand((1000, 772), dtype, 40)

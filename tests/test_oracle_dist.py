@@ -47,3 +47,36 @@ def test_oracle_two_ranks_match_reference_ddp():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, 29631, ret), nprocs=2, join=True)
     assert ret[0] == [] and ret[1] == [], (ret[0], ret[1])
+
+
+def test_world_fixtures_are_the_oracle_under_w_rank_gloo():
+    """tests/golden/world_oracle_w*_g*.npz (what tests/test_world_gpu.py holds the HIP path to at the world shapes of BASELINE configs C
+    and E) really are the oracle run under W-rank gloo: re-run live here at W = 4 and W = 8, G = 1024 (eight CPU processes), compared
+    with what the fixtures keep.  Also the invariant SURVEY.md section 4 names: every rank reports the same G x G losses (the two
+    local-batch terms differ per rank), and they equal the single-process losses on the concatenated batch."""
+    from tests.test_world_gpu import WL, grad_sample, load_world_fixture, oracle_world, world_batch, world_model
+    for world in (4, 8):
+        losses, grads = oracle_world(world, 1024)
+        z = load_world_fixture(world, 1024)
+        assert np.max(np.abs(np.asarray(losses) - z['losses'])) < 1e-5
+        names = [k[2:] for k in z if k.startswith('n/')]
+        assert set(names) == set(grads) and len(names) > 100
+        for k in names:
+            wn = float(z['n/' + k])
+            assert abs(float(np.linalg.norm(grads[k].astype(np.float64))) - wn) <= 1e-4 * wn + 1e-9, k
+            assert np.max(np.abs(grad_sample(grads[k]) - z['s/' + k])) <= 1e-4 * max(np.max(np.abs(z['s/' + k])), 1e-7) + 1e-8, k
+        lo = np.asarray(losses)
+        assert np.max(np.abs(lo[:, :3] - lo[0, :3])) < 1e-5          # the three gathered terms: identical on every rank
+    # W = 1 on the whole batch gives the same gathered-loss values (dropout off)
+    from oracle import leccr_oracle as O
+    sd = {k: v.detach() for k, v in world_model().state_dict().items() if not k.startswith('caption_encoder.')}
+    zb = world_batch(1024)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29899')
+    dist.init_process_group('gloo', rank=0, world_size=1)
+    try:
+        with torch.no_grad():
+            one = O.retrieval_forward(sd, WL, zb['image'], zb['ids_s'], zb['mask_s'], zb['ids_t'], zb['mask_t'], zb['ids_c'], zb['mask_c'],
+                                      zb['idx'], text_heads=2)
+    finally:
+        dist.destroy_process_group()
+    assert abs(float(one[2]) - float(lo[0, 2])) < 1e-4, (float(one[2]), lo[0, 2])

@@ -7,7 +7,10 @@ scaling under DDP averaging - 1/W for parameters in front of the gather, the FUL
 elsewhere), the loss stage runs at the production embed_dim 256 / 4 queries and at the REAL G.
 
 Yardstick: the CPU oracle run under W-rank gloo (W real processes, DDP-style SUM / W of the parameter gradients) on the same seeded
-weights and the same global batch.
+weights and the same global batch.  That run happens in the build container (tests/golden/make_world_golden.py writes the five losses of
+every rank and, per gradient tensor, its norm and a strided 1024-element sample to tests/golden/world_oracle_w*_g*.npz;
+tests/test_oracle_dist.py re-runs it live on the CPU and checks the fixtures): on the GPU box every torch process counts against the
+guard's 6 processes per card, CPU-only oracle ranks included.
 
 HIP side, two ways:
   * W = 4 real processes under gloo, all on cuda:0 (G = 1024: b = 256 per rank) - real collectives, real grad_sync;
@@ -104,10 +107,11 @@ _oracle_cache = {}
 
 
 def oracle_world(world, G):
-    """-> (per-rank losses [W][5], DDP-averaged gradients {name: array}) of the oracle under `world` gloo ranks (CPU processes)."""
+    """-> (per-rank losses [W][5], DDP-averaged gradients {name: array}) of the oracle under `world` gloo ranks (CPU processes).
+    Runs in the BUILD container only (tests/golden/make_world_golden.py, tests/test_oracle_dist.py): on the GPU box every process that
+    imports torch counts as a process on the card (the guard allows 6), so eight oracle ranks beside the test process are refused
+    there - the GPU tests read the committed fixtures instead."""
     if (world, G) not in _oracle_cache:
-        # results travel through files, not an mp.Manager: a Manager's server process is FORKED from this one and inherits its open
-        # GPU device - one more "process on the card" for the box's process guard (limit 6) per Manager alive
         with tempfile.TemporaryDirectory() as d:
             sd = {k: v.detach().clone() for k, v in world_model().state_dict().items() if not k.startswith('caption_encoder.')}
             torch.save(sd, os.path.join(d, 'weights.pt'))
@@ -117,22 +121,55 @@ def oracle_world(world, G):
     return _oracle_cache[(world, G)]
 
 
-def _check(losses_per_rank, grads, want_losses, want_grads):
+SAMPLE = 1024
+
+
+def grad_sample(a):
+    """What a world fixture keeps of one gradient tensor: every SAMPLE-th-of-the-tensor element (<= SAMPLE of them, the whole tensor
+    when it is that small)."""
+    a = np.asarray(a).reshape(-1)
+    return a[::max(1, a.size // SAMPLE)][:SAMPLE]
+
+
+def world_fixture_name(world, G):
+    return f'world_oracle_w{world}_g{G}.npz'
+
+
+def pack_world_fixture(losses, grads):
+    out = {'losses': np.asarray(losses, dtype=np.float64)}
+    for k, g in grads.items():
+        out['n/' + k] = np.array(float(np.linalg.norm(g.astype(np.float64))))
+        out['s/' + k] = grad_sample(g).astype(np.float32)
+    return out
+
+
+def load_world_fixture(world, G):
+    from tests.helpers import load_npz
+    return load_npz(world_fixture_name(world, G))
+
+
+def _check(losses_per_rank, grads, z):
+    """HIP losses (per rank) and rank-averaged gradients against a world fixture: losses to the north-star 1e-3; every gradient's norm
+    to 2e-3 and its sampled elements to 2e-3 of the sample's norm (or of the share of the tensor's norm a sample of that size carries,
+    where the sample happens to be small)."""
     bad = []
-    for r, (got, want) in enumerate(zip(losses_per_rank, want_losses)):
-        if max(abs(a - w) for a, w in zip(got, want)) > 1e-3:          # north star: fp32 logits / losses within 1e-3
-            bad.append(('losses', r, got, want))
-    # every rank reports the same five losses (each evaluates the full G x G terms), except the two local-batch terms
-    gmax = max(float(np.linalg.norm(v)) for v in want_grads.values())
+    for r, (got, want) in enumerate(zip(losses_per_rank, z['losses'])):
+        if max(abs(a - w) for a, w in zip(got, want)) > 1e-3:
+            bad.append(('losses', r, got, want.tolist()))
+    names = [k[2:] for k in z if k.startswith('n/')]
+    gmax = max(float(z['n/' + k]) for k in names)
     n = 0
-    for k, want in want_grads.items():
-        got = grads[k]
-        wn, err = float(np.linalg.norm(want)), float(np.linalg.norm(got.astype(np.float64) - want))
+    for k in names:
+        wn = float(z['n/' + k])
         if wn < 1e-6 * gmax:
             continue
         n += 1
-        if err > 2e-3 * wn:
-            bad.append((k, err / wn))
+        got = np.asarray(grads[k], dtype=np.float64)
+        gs, ws = grad_sample(got), z['s/' + k].astype(np.float64)
+        floor = max(float(np.linalg.norm(ws)), wn * (ws.size / got.size) ** 0.5)
+        err = float(np.linalg.norm(gs - ws))
+        if abs(float(np.linalg.norm(got)) - wn) > 2e-3 * wn or err > 2e-3 * floor:
+            bad.append((k, float(np.linalg.norm(got)) / wn, err / floor))
     return n, bad
 
 
@@ -160,11 +197,11 @@ def _hip_rank(rank, world, port, G, out_dir):
 
 
 def test_four_real_ranks_at_global_batch_1024_match_the_oracle_world():
-    want_losses, want_grads = oracle_world(4, 1024)
+    z = load_world_fixture(4, 1024)
     with tempfile.TemporaryDirectory() as d:          # 4 ranks + this process = 5 processes on the card (the box allows 6)
         mp.spawn(_hip_rank, args=(4, 29861, 1024, d), nprocs=4, join=True)
         res = [torch.load(os.path.join(d, f'hip_{r}.pt'), weights_only=False) for r in range(4)]
-    n, bad = _check([r['losses'] for r in res], res[0]['grads'], want_losses, want_grads)
+    n, bad = _check([r['losses'] for r in res], res[0]['grads'], z)
     assert n > 60 and not bad, (n, bad[:6])
 
 
@@ -213,7 +250,7 @@ class LoopbackWorld:
 def test_eight_rank_loopback_world_matches_the_oracle_world(G, backend, monkeypatch):
     from tests.test_model_gpu import Enc
     W = 8
-    want_losses, want_grads = oracle_world(W, G)
+    z = load_world_fixture(W, G)
     model = world_model().to(DEV).eval()
     model._ensure_runtime()
     z = world_batch(G)
@@ -243,7 +280,7 @@ def test_eight_rank_loopback_world_matches_the_oracle_world(G, backend, monkeypa
     assert (lw.into_tensor_calls > 0) == (backend == 'nccl') and (lw.list_calls > 0) == (backend == 'gloo')
     model.arena.grad.copy_(total / W)
     grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
-    n, bad = _check(losses, grads, want_losses, want_grads)
+    n, bad = _check(losses, grads, z)
     assert n > 60 and not bad, (n, bad[:6])
     # the mixed scaling is really in play: temp / cproj / vproj carry the FULL gradient, everything else 1/W of it - so against a
     # single-process pass over the whole batch (W = 1 semantics) temp's gradient is equal and an encoder weight's is 1/W of it
