@@ -513,23 +513,29 @@ __device__ __forceinline__ int swz32(int row) {
 
 template <int NT, int SW>
 struct StageSrc32 {
-    const bf16_t* p[512 / NT];
-    __device__ __forceinline__ void init(const bf16_t* base, int64_t ld) {
+    // per-thread BYTE offsets (32-bit: a (batch, head) slice is far below 2^31 bytes) from the wave-uniform tile base: the DMA then
+    // takes its address as SGPR base + zero-extended VGPR offset (the saddr form; an ELEMENT offset's scaling by 2 is done in 64 bits
+    // and the compiler then keeps hoisted 64-bit per-lane pointers, which it spills around the tile loop at 3-4 waves per SIMD)
+    uint32_t off[512 / NT];
+    const bf16_t* base;
+    __device__ __forceinline__ void init(const bf16_t* b, int64_t ld) {
+        base = b;
 #pragma unroll
         for (int i = 0; i < 512 / NT; ++i) {
             const int slot = i * NT + (int)threadIdx.x;
             const int row = slot >> 3, lc = (slot & 7) ^ swz32<SW>(row);
-            p[i] = base + row * ld + lc * 8;
+            off[i] = (uint32_t)(row * (int)ld + lc * 8) * 2u;
         }
     }
     __device__ __forceinline__ void issue(int64_t elem_off, unsigned char* lds) const {
         const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
+        const char* tb = reinterpret_cast<const char*>(base + elem_off);               // wave-uniform
 #pragma unroll
         for (int i = 0; i < 512 / NT; ++i)
-            __builtin_amdgcn_global_load_lds(GLB_PTR(p[i] + elem_off), LDS_PTR(lds + (size_t)(i * NT + wave_base) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(tb + off[i]), LDS_PTR(lds + (size_t)(i * NT + wave_base) * 16), 16, 0, 0);
     }
     // ragged tile: rows past the end re-read a valid row one tile back (masked or never stored), as stage_tile64
-    __device__ __forceinline__ void issue_clamped(const bf16_t* base, int64_t ld, int64_t row0, int64_t n_rows, unsigned char* lds) const {
+    __device__ __forceinline__ void issue_clamped(const bf16_t* b, int64_t ld, int64_t row0, int64_t n_rows, unsigned char* lds) const {
         const int wave_base = __builtin_amdgcn_readfirstlane((int)threadIdx.x & ~63);
 #pragma unroll
         for (int i = 0; i < 512 / NT; ++i) {
@@ -540,7 +546,7 @@ struct StageSrc32 {
                 const int64_t back = r - (n_rows < BT ? n_rows : BT);
                 r = back >= 0 && back < n_rows ? back : n_rows - 1;
             }
-            __builtin_amdgcn_global_load_lds(GLB_PTR(base + r * ld + lc * 8), LDS_PTR(lds + (size_t)(i * NT + wave_base) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b + r * ld + lc * 8), LDS_PTR(lds + (size_t)(i * NT + wave_base) * 16), 16, 0, 0);
         }
     }
 };
@@ -585,8 +591,14 @@ __device__ __forceinline__ uint32_t dead_keys32(const uint8_t* km, int64_t Lk, i
     return dead;
 }
 
-template <bool DROP, int NW>
-__global__ __launch_bounds__(NW * 64, NW == 1 ? 1 : 2) void flash_fwd32_kernel(FP p) {
+// WPS = waves per SIMD the kernel is built for (2; 1 for the one-wave blocks of tiny query sets).  The loop is written for a small
+// register footprint (one set of K fragments for both key blocks, V^T fragments two key steps at a time behind the softmax, the row-sum
+// accumulator in the registers the scores vacate, DMA addresses as 32-bit byte offsets from a scalar base) with 3-4 waves per SIMD
+// in mind; hipcc's builds for 168 / 128 registers still spill loop-invariant addresses around the tile loop (19 / 88 registers, their
+// reloads drain the DMA queue: 660 us / 2.5 ms against 500 us), so those instantiations are not dispatched - see
+// profiles/r03_attention_fwd_experiments.txt for what the what-if builds say would be gained (about 12 %).
+template <bool DROP, int NW, int WPS>
+__global__ __launch_bounds__(NW * 64, WPS) void flash_fwd32_kernel(FP p) {
     constexpr int BQ = NW * 32, NT = NW * 64;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
@@ -612,9 +624,7 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? 1 : 2) void flash_fwd32_kernel(F
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
     float m = -INFINITY, l = 0.f, a_prev = 0.f;
-    f32x16 lsum;                                    // row sums of the previous tile's p (every register holds the same value)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) lsum[i] = 0.f;
+    float ls_keep = 0.f;                            // row sum of the previous tile's p, read out of its MFMA chain's accumulator
 
     const int ntiles = (int)((p.Lk + BT - 1) / BT), nfull = (int)(p.Lk / BT);
     StageSrc32<NT, 1> ksrc;
@@ -657,34 +667,29 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? 1 : 2) void flash_fwd32_kernel(F
     auto tile = [&](int t, auto nkb_tag, auto ns_tag, uint32_t dead) {
         constexpr int NKB = decltype(nkb_tag)::value, NS = decltype(ns_tag)::value;
         const uint32_t kt = smem_off + (t & 1) * FWD_STAGE, vt = kt + TILE_BYTES;
-        bf16x8 kf[NKB][4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            kf[0][ks] = lds_b128<0>(kt + ka[ks]);
-            if constexpr (NKB == 2) kf[1][ks] = lds_b128<4096>(kt + ka[ks]);
-        }
-        if constexpr (NKB == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]),
-                         "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]));
-        f32x16 s[NKB];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // ---- S^T: key block 0's four fragments and its MFMA chain, then key block 1's
+        f32x16 s[NKB];
+        {
+            bf16x8 k0[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < 4; ++ks) k0[ks] = lds_b128<0>(kt + ka[ks]);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]));
 #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) s[kb] = MFMA32(kf[kb][ks], qf[ks], ks == 0 ? zero16 : s[kb]);
-        // s[kb][i] = <k[key = 32 kb + 8 (i >> 2) + 4 h + (i & 3)], q[query r]>
-        // V^T fragments of this tile: vf[dt][2 kb + st] = rows (keys) 32 kb + 16 st + 4 h + {0..3, 8..11}, d = 32 dt + r
-        constexpr int NSTEP = 2 * (NKB - 1) + NS;                 // live 16-key steps
-        bf16x8 vf[2][NSTEP];
+            for (int ks = 0; ks < 4; ++ks) s[0] = MFMA32(k0[ks], qf[ks], ks == 0 ? zero16 : s[0]);
+            if constexpr (NKB == 2) {
+                // key block 1 in the SAME four fragment registers (at 4 waves per SIMD the other waves cover this second LDS round trip;
+                // a second set of fragments in flight is what pushed the loop past 128 registers)
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            vf[dt][0] = lds_tr16_pair8<0>(vt + tv[dt]);
-            if constexpr (NSTEP > 1) vf[dt][1] = lds_tr16_pair8<2048>(vt + tv[dt]);
-            if constexpr (NSTEP > 2) vf[dt][2] = lds_tr16_pair8<4096>(vt + tv[dt]);
-            if constexpr (NSTEP > 3) vf[dt][3] = lds_tr16_pair8<6144>(vt + tv[dt]);
+                for (int ks = 0; ks < 4; ++ks) k0[ks] = lds_b128<4096>(kt + ka[ks]);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(k0[0]), "+v"(k0[1]), "+v"(k0[2]), "+v"(k0[3]));
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) s[1] = MFMA32(k0[ks], qf[ks], ks == 0 ? zero16 : s[1]);
+            }
         }
+        // s[kb][i] = <k[key = 32 kb + 8 (i >> 2) + 4 h + (i & 3)], q[query r]>
+        constexpr int NSTEP = 2 * (NKB - 1) + NS;                 // live 16-key steps
         if (dead) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? 1 : 2) void flash_fwd32_kernel(F
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s[kb][i] *= drop_mul(p.drop, base + 32 * kb + 8 * (i >> 2) + (i & 3));
         } else {
-            l = __builtin_fmaf(l, a_prev, lsum[0]);           // fold the PREVIOUS tile's row sum (its MFMAs have long retired)
+            l = __builtin_fmaf(l, a_prev, ls_keep);           // fold the PREVIOUS tile's row sum
             a_prev = alpha;
         }
 #pragma unroll
@@ -737,20 +742,57 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? 1 : 2) void flash_fwd32_kernel(F
         bf16x8 pf[NSTEP];
 #pragma unroll
         for (int st = 0; st < NSTEP; ++st) pf[st] = pack8(s[st >> 1], 8 * (st & 1));
-        __builtin_amdgcn_sched_barrier(0);          // keep the softmax above the wait: it is what hides the V reads
-        if constexpr (NSTEP == 4)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[0][2]), "+v"(vf[0][3]), "+v"(vf[1][0]),
-                         "+v"(vf[1][1]), "+v"(vf[1][2]), "+v"(vf[1][3]));
-        else if constexpr (NSTEP == 2)
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));
-        else
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[1][0]));
-#pragma unroll
-        for (int st = 0; st < NSTEP; ++st) {
-            o[0] = MFMA32(vf[0][st], pf[st], o[0]);
-            o[1] = MFMA32(vf[1][st], pf[st], o[1]);
-            if constexpr (!DROP) lsum = MFMA32(ones, pf[st], st == 0 ? zero16 : lsum);
+        __builtin_amdgcn_sched_barrier(0);          // the scores are dead from here: their registers take the V^T fragments
+        // ---- O^T += V^T P^T, row sums first in each step (their chain then ends two MFMAs before the tile does).  V^T fragments
+        // vf[dt] of step st = rows (keys) 32 kb + 16 st' + 4 h + {0..3, 8..11}, d = 32 dt + r: two steps' worth in flight
+        f32x16 ls;
+        bf16x8 va[2], vb[2];
+        va[0] = lds_tr16_pair8<0>(vt + tv[0]);
+        va[1] = lds_tr16_pair8<0>(vt + tv[1]);
+        if constexpr (NSTEP > 1) {
+            vb[0] = lds_tr16_pair8<2048>(vt + tv[0]);
+            vb[1] = lds_tr16_pair8<2048>(vt + tv[1]);
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(va[0]), "+v"(va[1]));
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[0]), "+v"(va[1]));
         }
+        if constexpr (!DROP) ls = MFMA32(ones, pf[0], zero16);
+        o[0] = MFMA32(va[0], pf[0], o[0]);
+        o[1] = MFMA32(va[1], pf[0], o[1]);
+        if constexpr (NSTEP > 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NSTEP > 2) {
+                va[0] = lds_tr16_pair8<4096>(vt + tv[0]);
+                va[1] = lds_tr16_pair8<4096>(vt + tv[1]);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vb[0]), "+v"(vb[1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vb[0]), "+v"(vb[1]));
+            }
+            if constexpr (!DROP) ls = MFMA32(ones, pf[1], ls);
+            o[0] = MFMA32(vb[0], pf[1], o[0]);
+            o[1] = MFMA32(vb[1], pf[1], o[1]);
+        }
+        if constexpr (NSTEP > 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NSTEP > 3) {
+                vb[0] = lds_tr16_pair8<6144>(vt + tv[0]);
+                vb[1] = lds_tr16_pair8<6144>(vt + tv[1]);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(va[0]), "+v"(va[1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[0]), "+v"(va[1]));
+            }
+            if constexpr (!DROP) ls = MFMA32(ones, pf[2], ls);
+            o[0] = MFMA32(va[0], pf[2], o[0]);
+            o[1] = MFMA32(va[1], pf[2], o[1]);
+        }
+        if constexpr (NSTEP > 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vb[0]), "+v"(vb[1]));
+            if constexpr (!DROP) ls = MFMA32(ones, pf[3], ls);
+            o[0] = MFMA32(vb[0], pf[3], o[0]);
+            o[1] = MFMA32(vb[1], pf[3], o[1]);
+        }
+        if constexpr (!DROP) ls_keep = ls[0];           // (the chain's last MFMA is two MFMAs old here)
     };
 
     stage(0);
@@ -776,9 +818,389 @@ __global__ __launch_bounds__(NW * 64, NW == 1 ? 1 : 2) void flash_fwd32_kernel(F
             else tile(t, std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{}, dead);
         }
     }
-    if constexpr (!DROP) l = __builtin_fmaf(l, a_prev, lsum[0]);
+    if constexpr (!DROP) l = __builtin_fmaf(l, a_prev, ls_keep);
     // o[dt][i] = O^T[d = 32 dt + 8 (i >> 2) + 4 h + (i & 3)][query r].  One permlane32 swap per register pair gives lane (r, h) the
     // eight consecutive d of group 2 gg + h: 16-byte stores instead of 8-byte ones
+    const int64_t qi = q0 + r;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    bf16_t* op = p.out + (b * p.Lq + (qi < p.Lq ? qi : p.Lq - 1)) * p.ldo + head * HD;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+            bf16x8 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a0 = o[dt][8 * gg + e] * inv, a1 = o[dt][8 * gg + 4 + e] * inv;
+                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+                w[e] = (bf16_t)__uint_as_float(sw[0]);
+                w[4 + e] = (bf16_t)__uint_as_float(sw[1]);
+            }
+            if (qi < p.Lq) *reinterpret_cast<bf16x8*>(op + 32 * dt + 16 * gg + 8 * h) = w;
+        }
+    if (qi < p.Lq && h == 0) p.lse[(b * p.heads + head) * p.Lq + qi] = l > 0.f ? (m * c + __log2f(l)) * kLn2 : INFINITY;
+}
+
+// --------------------------------------------------------------------------------------------------- forward, software-pipelined
+// What the counters say about flash_fwd32_kernel (profiles/r03_attention_fwd32_pmc.txt): the SIMD's vector issue port is the bound
+// (VALU active 0.59 of the kernel, matrix pipe 0.33, and the two hardly ever at the same time): per 32 x 64 tile a wave issues ~185
+// VALU instructions (33 v_exp at 8 cycles, the rest at 4: ~700-870 cycles) and 20 MFMAs (640 pipe cycles), and in program order
+// QK^T -> softmax -> PV a wave's MFMAs and its VALU work never coexist - only the other wave of the SIMD can fill in, and a wave that
+// issues MFMAs back to back is stalled 32 cycles on each.
+// Here the loop is skewed by one tile in BOTH directions: iteration t runs the softmax of tile t on the VALU while the matrix pipe
+// works on PV(t - 1) (P and the V^T fragments were left in registers by the previous iteration) and then on QK^T(t + 1) - one MFMA
+// per ~35 cycles of VALU work, in a fixed order pinned by sched_barrier fences:
+//     maximum (3 MFMAs under it) | exp2 (11) | pack P (2) | rescale O by alpha (4; it follows the last PV MFMA)
+// Three K|V tile slots (tile t's V, tile t + 1's K, tile t + 2 in flight).  No key mask, no dropout (ViT self-attention, the image
+// side of the interaction); everything else takes flash_fwd32_kernel.
+constexpr int FWDP_SLOTS = 3;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+#ifndef FWDP_EXP
+#define FWDP_EXP 0        // diagnostic builds (wrong results): 1 no v_exp, 2 no barrier in the loop, 4 no O rescale, 8 no MFMAs, 16 no DMA in the loop, 32 no maximum
+#endif
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void flash_fwd32p_kernel(FP p) {
+    constexpr int BQ = NW * 32, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t nqb = (p.Lq + BQ - 1) / BQ;
+    const int64_t lb = xcd_block(p.xcd);
+    const int64_t bh = lb / nqb, b = bh / p.heads, head = bh % p.heads;
+    const int64_t q0 = (int64_t)(lb % nqb) * BQ + wave * 32;
+    const bf16_t* Q = p.q + b * p.Lq * p.ldq + head * HD;
+    const bf16_t* Kp = p.k + b * p.Lk * p.ldk + head * HD;
+    const bf16_t* Vp = p.v + b * p.Lk * p.ldv + head * HD;
+    const float c = p.scale * kLog2e;
+
+    bf16x8 qf[4];
+    {
+        const int64_t qr = q0 + r < p.Lq ? q0 + r : p.Lq - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(Q + qr * p.ldq + 16 * ks + 8 * h);
+    }
+    f32x16 o[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+    // l is folded two tiles late: iteration t adds the row sum of tile t - 2 (the MFMA chain issued during iteration t - 1) under the
+    // rescale factor of that tile, a_pp = alpha(t - 2); a_p = alpha(t - 1)
+    float m = -INFINITY, l = 0.f, a_pp = 0.f, a_p = 0.f;
+    float ls_keep = 0.f;           // row sum of the tile whose PV chain ran in the previous iteration (read out of the accumulator there)
+    f32x16 lsum;                   // that chain's accumulator: live only inside an iteration
+
+    const int ntiles = (int)((p.Lk + BT - 1) / BT), nfull = (int)(p.Lk / BT), last = ntiles - 1;
+    StageSrc32<NT, 1> ksrc;
+    StageSrc32<NT, 2> vsrc;
+    ksrc.init(Kp, p.ldk);
+    vsrc.init(Vp, p.ldv);
+    auto stage = [&](int t, int slot) __attribute__((always_inline)) {
+        unsigned char* st = smem + slot * FWD_STAGE;
+        if (t < nfull) {
+            ksrc.issue((int64_t)t * BT * p.ldk, st);
+            vsrc.issue((int64_t)t * BT * p.ldv, st + TILE_BYTES);
+        } else {
+            ksrc.issue_clamped(Kp, p.ldk, (int64_t)t * BT, p.Lk, st);
+            vsrc.issue_clamped(Vp, p.ldv, (int64_t)t * BT, p.Lk, st + TILE_BYTES);
+        }
+    };
+    uint32_t ka[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) ka[ks] = (uint32_t)(r * 128 + (((2 * ks + h) ^ ((r >> 1) & 7)) << 4));
+    uint32_t tv[2];
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+        tv[0] = (uint32_t)((4 * h + q) * 128 + (((2 * (g & 1) + (pp >> 1)) ^ (4 * (q >> 1))) << 4) + 8 * (pp & 1));
+        tv[1] = tv[0] ^ 64u;
+    }
+    const uint32_t smem_off = lds_u32(smem);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (bf16_t)1.0f;
+    const bool active = __builtin_amdgcn_readfirstlane((int)(q0 < p.Lq));
+    const int rem = (int)(p.Lk - (int64_t)last * BT);                  // keys of the last tile (1..64)
+    const bool short_tail = rem <= 32;                                 // the last tile then runs one key block
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+
+    // registers that cross iterations: P (packed) and the V^T fragments of the tile whose PV product is still to be issued
+    bf16x8 pfp[4], vfp[2][4];
+
+    auto read_k = [&](int slot, auto nkb_tag, bf16x8 (&kf)[2][4]) __attribute__((always_inline)) {
+        constexpr int NKB = decltype(nkb_tag)::value;
+        const uint32_t kt = smem_off + slot * FWD_STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kf[0][ks] = lds_b128<0>(kt + ka[ks]);
+            if constexpr (NKB == 2) kf[1][ks] = lds_b128<4096>(kt + ka[ks]);
+        }
+    };
+    auto wait_k = [&](auto nkb_tag, bf16x8 (&kf)[2][4]) __attribute__((always_inline)) {
+        constexpr int NKB = decltype(nkb_tag)::value;
+        if constexpr (NKB == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]), "+v"(kf[1][0]),
+                         "+v"(kf[1][1]), "+v"(kf[1][2]), "+v"(kf[1][3]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[0][0]), "+v"(kf[0][1]), "+v"(kf[0][2]), "+v"(kf[0][3]));
+    };
+    auto read_v = [&](int slot) __attribute__((always_inline)) {           // all four 16-key steps of the (full) tile in `slot`
+        const uint32_t vt = smem_off + slot * FWD_STAGE + TILE_BYTES;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            vfp[dt][0] = lds_tr16_pair8<0>(vt + tv[dt]);
+            vfp[dt][1] = lds_tr16_pair8<2048>(vt + tv[dt]);
+            vfp[dt][2] = lds_tr16_pair8<4096>(vt + tv[dt]);
+            vfp[dt][3] = lds_tr16_pair8<6144>(vt + tv[dt]);
+        }
+    };
+    // PV MFMA number i (0..11) of the pending tile: key step i / 3; O^T d block 0, d block 1, row sum
+    auto pv = [&](auto ic) __attribute__((always_inline)) {
+        constexpr int i = decltype(ic)::value, st = i / 3, w = i % 3;
+        if constexpr (w == 0) o[0] = MFMA32(vfp[0][st], pfp[st], o[0]);
+        else if constexpr (w == 1) o[1] = MFMA32(vfp[1][st], pfp[st], o[1]);
+        else lsum = MFMA32(ones, pfp[st], st == 0 ? zero16 : lsum);
+    };
+
+    // One iteration: softmax of tile t (scores `sc`, complete, a full tile) on the VALU; under it the matrix pipe runs PV(t - 1)
+    // (PREV) and QK^T(t + 1) -> `sn` (NEXT key blocks of the tile in slot ns).  Leaves P(t) and V^T(t) in pfp / vfp.
+    auto iter = [&](int t, int cs, int ns, f32x16 (&sc)[2], f32x16 (&sn)[2], auto prev_tag, auto next_tag) __attribute__((always_inline)) {
+        constexpr bool PREV = decltype(prev_tag)::value != 0;
+        constexpr int NEXT = decltype(next_tag)::value;
+        constexpr int NPV = PREV ? 12 : 0, NM = NPV + 4 * NEXT;          // MFMAs of this iteration, in issue order PV0.. then QK0..
+        const float ls_old = ls_keep;          // row sum of tile t - 2
+        // K fragments of tile t + 1: key block 0 now, key block 1 (NEXT == 2) under the exponentials - the QK^T MFMAs run key block
+        // 0's chain first, so its four fragments are all that is needed for a while (register pressure: 2 x 32 scores, 32 O, 16 Q,
+        // 32 V^T, 16 P and these)
+        bf16x8 kf[2][4];
+        {
+            const uint32_t kt = smem_off + ns * FWD_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[0][ks] = lds_b128<0>(kt + ka[ks]);
+        }
+        if constexpr (PREV)          // the V^T fragments of tile t - 1 (read last iteration) have landed; the 4 K reads may still fly
+            asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vfp[0][0]), "+v"(vfp[0][1]), "+v"(vfp[0][2]), "+v"(vfp[0][3]), "+v"(vfp[1][0]),
+                         "+v"(vfp[1][1]), "+v"(vfp[1][2]), "+v"(vfp[1][3]));
+        FENCE();
+        auto mf = [&](auto kc) __attribute__((always_inline)) {       // the k-th MFMA of the iteration (nothing once they are used up)
+            constexpr int k = decltype(kc)::value;
+            if constexpr ((FWDP_EXP & 8) != 0) { FENCE(); return; }
+            if constexpr (k < NPV) pv(kc);
+            else if constexpr (k < NM) {
+                constexpr int j = k - NPV, kb = j / 4, ks = j % 4;            // key block 0's chain, then key block 1's
+                if constexpr (ks == 0)
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kf[kb][0]), "+v"(kf[kb][1]), "+v"(kf[kb][2]), "+v"(kf[kb][3]));
+                sn[kb] = MFMA32(kf[kb][ks], qf[ks], ks == 0 ? zero16 : sn[kb]);
+            }
+            if constexpr (NEXT == 2 && k == (PREV ? 9 : 1)) {               // key block 1's fragments, ~6 MFMAs ahead of their first use
+                const uint32_t kt = smem_off + ns * FWD_STAGE;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) kf[1][ks] = lds_b128<4096>(kt + ka[ks]);
+            }
+            FENCE();
+        };
+        // ---- A: row maximum (16 max3, the lane pair's exchange, the running maximum, alpha): MFMAs 0-2
+        mf(C0{});
+        float mx = max3f(sc[0][0], sc[0][1], sc[0][2]);
+        if constexpr ((FWDP_EXP & 32) == 0) {
+#pragma unroll
+        for (int i = 3; i + 1 < 16; i += 2) mx = max3f(mx, sc[0][i], sc[0][i + 1]);
+        mx = fmaxf(mx, sc[0][15]);
+        }
+        FENCE();
+        mf(C1{});
+        if constexpr ((FWDP_EXP & 32) == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) mx = max3f(mx, sc[1][i], sc[1][i + 1]);
+        }
+        FENCE();
+        mf(C2{});
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float mn = fmaxf(m, mx);
+        const float msafe = mn == -INFINITY ? 0.f : mn;
+        const float mc = msafe * c;
+        const float alpha = exp2_fast(m * c - mc);
+        m = mn;
+        l = __builtin_fmaf(l, a_pp, ls_old);              // l(t - 2) = l(t - 3) alpha(t - 2) + rowsum(t - 2)
+        a_pp = a_p;
+        a_p = alpha;
+        FENCE();
+        // ---- B: p = exp2(s c - m c), 32 per lane, three per MFMA: MFMAs 3-13
+        sfor<0, 11>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            mf(std::integral_constant<int, 3 + g>{});
+#pragma unroll
+            for (int e = 3 * g; e < (g == 10 ? 32 : 3 * g + 3); ++e) {
+                if constexpr ((FWDP_EXP & 1) != 0) sc[e >> 4][e & 15] = __builtin_fmaf(sc[e >> 4][e & 15], c, -mc);
+                else sc[e >> 4][e & 15] = exp2_fast(__builtin_fmaf(sc[e >> 4][e & 15], c, -mc));
+            }
+            FENCE();
+        });
+        // ---- D: P -> bf16 fragments (the PV operands of the NEXT iteration; the old ones went with MFMA 11): MFMAs 14-15
+        mf(std::integral_constant<int, 14>{});
+        pfp[0] = pack8(sc[0], 0);
+        pfp[1] = pack8(sc[0], 8);
+        if constexpr (PREV) ls_keep = lsum[0];       // PV(t - 1)'s row sum (its chain ended with MFMA 11)
+        FENCE();
+        mf(std::integral_constant<int, 15>{});
+        pfp[2] = pack8(sc[1], 0);
+        pfp[3] = pack8(sc[1], 8);
+        FENCE();
+        // ---- C: O *= alpha (behind the last PV MFMA, which was number 11): MFMAs 16-19
+        sfor<0, 4>([&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            mf(std::integral_constant<int, 16 + g>{});
+            if constexpr ((FWDP_EXP & 4) == 0) {
+#pragma unroll
+                for (int i = 4 * g; i < 4 * g + 4; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+            }
+            FENCE();
+        });
+        // V^T(t) for the next iteration's PV (the old fragments have been consumed: same registers)
+        read_v(cs);
+        FENCE();
+    };
+    // loop top: tile t + 1 (issued one iteration ago) has landed for this thread; after the barrier for every thread, and the slot
+    // of tile t - 1 is free (its V^T fragments are in registers): tile t + 2 goes there
+    auto top = [&](int t, int fs) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr ((FWDP_EXP & 2) == 0) __builtin_amdgcn_s_barrier();
+        FENCE();
+        if constexpr ((FWDP_EXP & 16) == 0)
+        if (t + 2 <= last) stage(t + 2, fs);
+    };
+    // The last tile (scores `sl`): the pending PV(last - 1), then softmax + PV of the last tile itself (NKB key blocks, NS live
+    // 16-key steps in the last of them, keys beyond Lk masked), unpipelined.
+    auto finish = [&](int cs, f32x16 (&sl)[2], auto nkb_tag, auto ns_tag) __attribute__((always_inline)) {
+        constexpr int NKB = decltype(nkb_tag)::value, NS = decltype(ns_tag)::value, NSTEP = 2 * (NKB - 1) + NS;
+        l = __builtin_fmaf(l, a_pp, ls_keep);              // l(last - 2); the chain below computes the row sum of tile last - 1
+        FENCE();
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vfp[0][0]), "+v"(vfp[0][1]), "+v"(vfp[0][2]), "+v"(vfp[0][3]), "+v"(vfp[1][0]),
+                     "+v"(vfp[1][1]), "+v"(vfp[1][2]), "+v"(vfp[1][3]));
+        sfor<0, 12>([&](auto ic) { pv(ic); });
+        const uint32_t vt = smem_off + cs * FWD_STAGE + TILE_BYTES;
+        bf16x8 vf[2][NSTEP];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            vf[dt][0] = lds_tr16_pair8<0>(vt + tv[dt]);
+            if constexpr (NSTEP > 1) vf[dt][1] = lds_tr16_pair8<2048>(vt + tv[dt]);
+            if constexpr (NSTEP > 2) vf[dt][2] = lds_tr16_pair8<4096>(vt + tv[dt]);
+            if constexpr (NSTEP > 3) vf[dt][3] = lds_tr16_pair8<6144>(vt + tv[dt]);
+        }
+        const uint32_t dead = rem < BT ? dead_keys32<NKB>(nullptr, p.Lk, (int64_t)last * BT + 4 * h, true) : 0u;
+        if (dead) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (dead & (1u << (16 * kb + i))) sl[kb][i] = -INFINITY;
+        }
+        float mx = max3f(sl[0][0], sl[0][1], sl[0][2]);
+#pragma unroll
+        for (int i = 3; i + 1 < 16; i += 2) mx = max3f(mx, sl[0][i], sl[0][i + 1]);
+        mx = fmaxf(mx, sl[0][15]);
+        if constexpr (NKB == 2) {
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) mx = max3f(mx, sl[1][i], sl[1][i + 1]);
+        }
+        {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        const float mn = fmaxf(m, mx);
+        const float msafe = mn == -INFINITY ? 0.f : mn;
+        const float mc = msafe * c;
+        const float alpha = exp2_fast(m * c - mc);
+        m = mn;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) sl[kb][i] = exp2_fast(__builtin_fmaf(sl[kb][i], c, -mc));
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        l = __builtin_fmaf(l, a_p, lsum[0]);               // l(last - 1) = l(last - 2) alpha(last - 1) + rowsum(last - 1)
+        bf16x8 pf[NSTEP];
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) pf[st] = pack8(sl[st >> 1], 8 * (st & 1));
+        FENCE();
+        if constexpr (NSTEP == 4)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[0][2]), "+v"(vf[0][3]), "+v"(vf[1][0]),
+                         "+v"(vf[1][1]), "+v"(vf[1][2]), "+v"(vf[1][3]));
+        else if constexpr (NSTEP == 2)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[0][1]), "+v"(vf[1][0]), "+v"(vf[1][1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vf[0][0]), "+v"(vf[1][0]));
+        f32x16 ls2 = zero16;
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            o[0] = MFMA32(vf[0][st], pf[st], o[0]);
+            o[1] = MFMA32(vf[1][st], pf[st], o[1]);
+            ls2 = MFMA32(ones, pf[st], st == 0 ? zero16 : ls2);
+        }
+        l = __builtin_fmaf(l, alpha, ls2[0]);              // l(last) = l(last - 1) alpha(last) + rowsum(last)
+    };
+
+    // tiles 0 and 1 into slots 0 and 1; S^T(0)
+    stage(0, 0);
+    stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    FENCE();
+    f32x16 sA[2], sB[2];
+    if (active) {
+        bf16x8 kf[2][4];
+        read_k(0, C2{}, kf);
+        wait_k(C2{}, kf);
+        sfor<0, 8>([&](auto jc) {
+            constexpr int j = decltype(jc)::value, ks = j / 2, kb = j % 2;
+            sA[kb] = MFMA32(kf[kb][ks], qf[ks], ks == 0 ? zero16 : sA[kb]);
+        });
+    }
+    // slots: tile t lives in slot t % 3.  The score buffers swap roles every iteration; the loop is unrolled by two so that the roles
+    // are static (a run-time choice of buffer puts the accumulators in scratch memory).  Iteration t: cur = sA for even t.
+    int s0 = 0, s1 = 1, s2 = 2;            // slots of tiles t, t + 1, t + 2
+#define ROT() do { const int x_ = s0; s0 = s1; s1 = s2; s2 = x_; } while (0)
+#define ITER(T, SC, SN, PREVC, NEXTC)                                  \
+    do {                                                               \
+        top((T), s2);                                                  \
+        if (active) iter((T), s0, s1, SC, SN, PREVC, NEXTC);           \
+        ROT();                                                         \
+    } while (0)
+    // iteration 0 has no pending PV.  (Every iteration computes both key blocks of the next tile, also when the last tile is short:
+    // four spare MFMAs once per block are cheaper than a second set of loop bodies - with them the tail iterations spilled.)
+    ITER(0, sA, sB, C0{}, C2{});
+    int t = 1;
+    for (; t + 1 < last; t += 2) {
+        ITER(t, sB, sA, C1{}, C2{});
+        ITER(t + 1, sA, sB, C1{}, C2{});
+    }
+    if (t < last) {                        // one more: the last tile's scores end up in sA; otherwise they are in sB
+        ITER(t, sB, sA, C1{}, C2{});
+    } else if (active) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { sA[0][i] = sB[0][i]; sA[1][i] = sB[1][i]; }
+    }
+#undef ITER
+#undef ROT
+    if (active) {
+        if (!short_tail) finish(s0, sA, C2{}, C2{});
+        else if (rem <= 16) finish(s0, sA, C1{}, C1{});
+        else finish(s0, sA, C1{}, C2{});
+    }
     const int64_t qi = q0 + r;
     const float inv = l > 0.f ? 1.f / l : 0.f;
     bf16_t* op = p.out + (b * p.Lq + (qi < p.Lq ? qi : p.Lq - 1)) * p.ldo + head * HD;
@@ -1344,9 +1766,17 @@ int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* l
 #define LAUNCH_F32(NW)                                                                                                   \
         do {                                                                                                             \
             dim3 grid((unsigned)(cdiv(D.Lq, 32 * NW) * D.b * D.heads));                                                  \
-            if (D.dropout) hipLaunchKernelGGL((flash_fwd32_kernel<true, NW>), grid, dim3(64 * NW), 2 * FWD_STAGE, st, p); \
-            else hipLaunchKernelGGL((flash_fwd32_kernel<false, NW>), grid, dim3(64 * NW), 2 * FWD_STAGE, st, p);         \
+            if (D.dropout) hipLaunchKernelGGL((flash_fwd32_kernel<true, NW, (NW == 1 ? 1 : 2)>), grid, dim3(64 * NW), 2 * FWD_STAGE, st, p); \
+            else hipLaunchKernelGGL((flash_fwd32_kernel<false, NW, (NW == 1 ? 1 : 2)>), grid, dim3(64 * NW), 2 * FWD_STAGE, st, p);         \
         } while (0)
+        // long, unmasked, no dropout (ViT self-attention, the image side of the interaction): the software-pipelined kernel
+        // (LECCR_ATTN_FWD_PIPE=0: the plain loop instead - the measured alternative)
+        static const int pipelined = [] { const char* e = getenv("LECCR_ATTN_FWD_PIPE"); return (e && e[0] == '0') ? 0 : 1; }();
+        if (pipelined && !D.dropout && !kmask && D.Lq > 64 && D.Lk > BT) {
+            dim3 grid((unsigned)(cdiv(D.Lq, 128) * D.b * D.heads));
+            hipLaunchKernelGGL((flash_fwd32p_kernel<4>), grid, dim3(256), FWDP_SLOTS * FWD_STAGE, st, p);
+            return check_launch("flash_fwd32p");
+        }
         if (D.Lq <= 32) LAUNCH_F32(1);
         else if (D.Lq <= 64) LAUNCH_F32(2);
         else LAUNCH_F32(4);

@@ -250,7 +250,7 @@ class LoopbackWorld:
 def test_eight_rank_loopback_world_matches_the_oracle_world(G, backend, monkeypatch):
     from tests.test_model_gpu import Enc
     W = 8
-    z = load_world_fixture(W, G)
+    fx = load_world_fixture(W, G)
     model = world_model().to(DEV).eval()
     model._ensure_runtime()
     z = world_batch(G)
@@ -280,7 +280,7 @@ def test_eight_rank_loopback_world_matches_the_oracle_world(G, backend, monkeypa
     assert (lw.into_tensor_calls > 0) == (backend == 'nccl') and (lw.list_calls > 0) == (backend == 'gloo')
     model.arena.grad.copy_(total / W)
     grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters() if p.grad is not None}
-    n, bad = _check(losses, grads, z)
+    n, bad = _check(losses, grads, fx)
     assert n > 60 and not bad, (n, bad[:6])
     # the mixed scaling is really in play: temp / cproj / vproj carry the FULL gradient, everything else 1/W of it - so against a
     # single-process pass over the whole batch (W = 1 semantics) temp's gradient is equal and an encoder weight's is 1/W of it
