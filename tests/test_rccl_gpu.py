@@ -67,3 +67,21 @@ def test_bench_self_launch_two_gpus():
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out['n_gpus'] == 2 and out['config']['backend'] == 'nccl' and out['config']['global_batch'] == 64
     assert out['value'] > 0 and out['config']['rccl_version']
+
+
+@pytest.mark.parametrize('world,G', [(4, 1024), (8, 1024), (8, 2048)])
+def test_rccl_world_shapes_of_configs_c_and_e_match_the_oracle_world(world, G):
+    """BASELINE configs C / E world shapes over RCCL, one rank per GPU (W = 4 and W = 8, global batch 1024 / 2048, tiny towers, production
+    loss stage): per-rank losses and rank-averaged gradients against the oracle run under W-rank gloo (tests/golden/world_oracle_*.npz) -
+    the same check tests/test_world_gpu.py makes with W = 4 gloo ranks on one GPU and with the 8-rank loopback world.  Lights up on a
+    node with >= W GPUs (the first 8-GPU lease), skipped below."""
+    if torch.cuda.device_count() < world:
+        pytest.skip(f'needs >= {world} GPUs')
+    import tempfile
+    from tests import test_world_gpu as Wd
+    z = Wd.load_world_fixture(world, G)
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(Wd._hip_rank, args=(world, 29871 + world + G // 1024, G, d), nprocs=world, join=True)
+        res = [torch.load(os.path.join(d, f'hip_{r}.pt'), weights_only=False) for r in range(world)]
+    n, bad = Wd._check([r['losses'] for r in res], res[0]['grads'], z)
+    assert n > 60 and not bad, (n, bad[:6])
