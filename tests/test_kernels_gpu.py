@@ -289,7 +289,10 @@ def test_flash_bf16_noise_model_physics_matches_the_f32_kernel_fed_rounded_outpu
     d = heads * hd
     r16 = lambda t: t.bfloat16().float()          # bf16-representable operands: the products below are then exact up to f32 sums
     q, k = r16(0.05 * torch.randn(b, L, d, generator=g)), r16(0.05 * torch.randn(b, L, d, generator=g))       # near-uniform attention
-    v, do = r16(torch.randn(b, L, d, generator=g)), r16(torch.randn(b, L, d, generator=g))
+    # value rows that differ little from key to key (as the hidden states of a random-init BERT's last layers do): dP_ij - delta_i is
+    # then a small difference of O(1) numbers, and the 2^-9 rounding of the stored output is a sizeable part of it
+    vbar = torch.randn(b, 1, d, generator=g)
+    v, do = r16(vbar + 0.02 * torch.randn(b, L, d, generator=g)), r16(torch.randn(b, L, d, generator=g))
     qd, kd, vd, dod = q.to(DEV), k.to(DEV), v.to(DEV), do.to(DEV)
     o, lse = K.attn_fwd(qd, kd, vd, heads)
     o_r = o.bfloat16().float()
@@ -312,7 +315,7 @@ def test_flash_bf16_noise_model_physics_matches_the_f32_kernel_fed_rounded_outpu
     om = O._FlashBF16.apply(qh, kh, vh, None, scale)
     (om * split(do).float()).sum().backward()
     model_dev = float((merge(qh.grad.double()) - dq_e.cpu().double()).norm() / dq_e.cpu().double().norm())
-    assert 0.02 < rel < NOISE_CEILING_HINT and 0.6 * rel <= model_dev <= 2.0 * rel, (rel, model_dev)
+    assert 0.02 < rel < NOISE_CEILING_HINT and 0.6 * rel <= model_dev <= 2.0 * rel, (rel, model_dev)       # CPU run: 0.093 / 0.093
 
 
 NOISE_CEILING_HINT = 0.4        # tests.helpers.NOISE_CEILING
