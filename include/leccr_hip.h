@@ -39,7 +39,8 @@ int leccr_set_force_generic(int on);           /* 1: route every op through the 
  * roofline leg).  read(): ms[5], work[5] (algorithmic FLOPs), launches[5] indexed
  * {gemm_mfma_nt, gemm_mfma_tn, gemm_generic, attn_fwd, attn_bwd}; synchronises on the recorded events. */
 int leccr_set_gemm_variant(int v);             /* 0 auto (default), 1 force the 128x128 kernel, 2 / 3 force the 8-wave /
-                                                * 4-wave 256x256 kernel where it is legal */
+                                                * 4-wave 256x256 kernel where it is legal, 4 force the 4-wave TN (weight-gradient)
+                                                * kernel where it is legal (everything else as auto) */
 int leccr_set_gemm_max_blocks(int n);          /* workgroups (= CUs) a persistent 256x256 GEMM launch may use: 0 / 256 = all
                                                 * (default); rounded down to a multiple of 8; returns the value in effect.
                                                 * leccr_amd.parallel lowers it while an all-reduce overlaps the backward pass */
@@ -47,7 +48,8 @@ int leccr_get_gemm_max_blocks(void);
 int leccr_set_gemm_max_blocks_for(int n, int64_t launches);   /* the same limit for the next `launches` persistent-GEMM launches
                                                 * only, after which all CUs are used again (the expected duration of a collective) */
 int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_gemm launched: 0 generic, 1 MFMA 128x128,
-                                                * 2 MFMA 256x256 (8 waves), 3 MFMA 256x256 (4 waves); tests use it */
+                                                * 2 MFMA 256x256 (8 waves), 3 MFMA 256x256 (4 waves), 4 the fp8 4-wave kernel,
+                                                * 5 the 4-wave TN weight-gradient kernel; tests use it */
 int leccr_prof_enable(int on);
 int leccr_prof_read(double* ms, double* work, int64_t* launches);
 /* The first n <= 11 kinds: the five above, then {layernorm_fwd, layernorm_bwd, colsum, embedding stages, adamw, dropout} -

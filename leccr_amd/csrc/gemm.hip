@@ -15,6 +15,7 @@
 //
 // Reference op sequences replaced: see include/leccr_hip.h (leccr_gemm).
 #include "common.h"
+#include <stdlib.h>
 
 namespace leccr {
 
@@ -358,6 +359,14 @@ void gemm256_set_max_blocks(int n, int64_t launches);
 int gemm256_max_blocks();
 bool gemm256w4_legal(const leccr_gemm_params& p);
 int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st);
+bool gemm256t4_legal(const leccr_gemm_params& p);
+int gemm256t4_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
+// Weight-gradient (TN) products: 1 = the 4-wave kernel of gemm256t4.hip wherever it is legal (LECCR_GEMM_TN4, default below), 0 = the
+// 8-wave TN instantiation of gemm256.hip.  leccr_set_gemm_variant(4) / (2) force one or the other for A/B runs and tests.
+static int tn4_default() {
+    static const int v = [] { const char* e = getenv("LECCR_GEMM_TN4"); return e ? atoi(e) : 0; }();
+    return v;
+}
 // 0 auto, 1 force the 128x128 kernel, 2 force the 8-wave 256x256 kernel where legal, 3 force the 4-wave 256x256 kernel where legal
 static int g_gemm_variant = 0;
 static int g_last_kernel = 0;
@@ -401,6 +410,10 @@ static int gemm_dispatch(const leccr_gemm_params& p, hipStream_t st, bool* colsu
         if (g_gemm_variant == 3 && gemm256w4_legal(p)) {
             g_last_kernel = 3;
             return gemm256w4_launch(p, st);
+        }
+        if ((g_gemm_variant == 4 || (g_gemm_variant == 0 && tn4_default())) && gemm256t4_legal(p)) {
+            g_last_kernel = 5;
+            return gemm256t4_launch(p, gemm256_max_blocks(), st);
         }
         if (((g_gemm_variant == 2 || g_gemm_variant == 3) && gemm256_legal(p)) || (g_gemm_variant == 0 && gemm256_wanted(p))) {
             *colsum_fused = gemm256_fuses_colsum(p);
@@ -460,7 +473,7 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     int rc = gemm_dispatch(p, st, &colsum_fused);
     if (rc == LECCR_OK && p.colsum && !colsum_fused)     // paths without the fused epilogue: one pass over the C just written
         rc = leccr_colsum(p.C, p.colsum, p.M, p.N, p.ldc, p.c_dtype, stream);
-    if (rc == LECCR_OK && p.asum && !(g_last_kernel == 2 && gemm256_fuses_asum(p))) {
+    if (rc == LECCR_OK && p.asum && !(g_last_kernel == 5 || (g_last_kernel == 2 && gemm256_fuses_asum(p)))) {
         // kernels without the fused sum: one pass over A ([K, M] row-major), scaled like the product
         if (p.alpha == 1.0f) rc = leccr_colsum(p.A, p.asum, p.K, p.M, p.lda, p.ab_dtype, stream);
         else { set_error("gemm: asum with alpha != 1 needs the 256x256 kernel"); rc = LECCR_EINVAL; }

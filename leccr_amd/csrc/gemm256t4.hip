@@ -1,0 +1,375 @@
+// gemm256t4.hip - the weight-gradient product C[M,N] (f32) += alpha * A[K,M]^T B[K,N] (bf16 operands, TN) on a 256 x 256 x 64 tile
+// run by FOUR waves, one per SIMD (round 3).
+//
+// Why.  gemm256.hip's TN instantiation (8 waves, wave tile 128 x 64, LOAD / COMPUTE segments alternating between the two waves of a
+// SIMD, 8 barriers per K-tile) is the largest single kernel of the train step (33 ms of 137) and the one whose schedule has the most
+// slack (profiles/r02_gemm256_pmc_step_shapes.txt: matrix pipe 0.49 busy, 39 % of wave-cycles waiting): a TN fragment is two
+// transposing LDS reads whose results form one operand, and with 128 accumulator + 96 fragment registers per wave the 8-wave kernel
+// cannot software-pipeline them without spilling.  With four waves a wave owns 512 registers:
+//   * wave tile 128 x 128 = 4 x 4 accumulators of v_mfma_f32_32x32x16_bf16 (256 registers), fragments of the NEXT k-step (32
+//     registers) read while the current k-step's 16 MFMAs run - every transposing read and every DMA piece sits between two MFMAs,
+//     ONE barrier per K-tile (the schedule of gemm256w4.hip);
+//   * half the LDS fragment bytes per MFMA cycle of the 8-wave kernel (a fragment feeds four 32-cycle MFMAs instead of 4-8 16-cycle ones);
+//   * the MFMAs are issued A-role = A^T rows (m), B-role = B columns (n), so an accumulator register holds 32 consecutive n of two rows:
+//     the split-K partial sums go to memory as global_atomic_add_f32 of 2 x 128 contiguous bytes STRAIGHT from the accumulators - no
+//     LDS transpose in the epilogue (the 8-wave kernel's lane holds 4 n of one m and needs one);
+//   * the bias gradient asum[m] += alpha sum_k A[k, m] is summed from the A fragments already in registers (v_dot2c_f32_bf16 against a
+//     (1, 1) literal: 8 instructions per k-step), two of the wave's four m-tiles per wave column, the tiles_n items of a tile row taking
+//     turns K-tile by K-tile as in gemm256.hip.  (Two more 32 x 32 MFMAs per k-step with an all-ones operand, as the 8-wave kernel does it
+//     with 16 x 16 ones, made hipcc shuttle their 32 accumulator registers between VGPRs and AGPRs around every k-step.)
+//
+// LDS image of an operand K-tile: [64 k][256 columns] bf16, 512-byte rows, 16-byte chunks; physical chunk = logical chunk ^ ((k & 3) << 2):
+// a ds_read_b64_tr_b16's 32-lane half takes 4 consecutive k x 64 bytes, and the XOR puts the four rows in the four 64-byte bank groups of
+// the 256-byte bank window (plain rows would be 4-way conflicts: the row stride is a multiple of 256 bytes).  The swizzle is applied to the
+// SOURCE address of the LDS-DMA (global_load_lds_dwordx4 writes lane-linear).
+//
+// Replaces the backward of every nn.Linear on the path (clip/model.py:177-191, HF BertModel dense layers via models/xvlm.py:238,
+// models/attention.py:27-54): dW = dY^T X, db = colsum(dY).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace leccr {
+namespace t4 {
+
+constexpr int BM = 256, BN = 256, BK = 64;
+constexpr int OPT = 32768;                        // bytes of one operand K-tile (64 k x 256 columns)
+constexpr int SLOT = 2 * OPT, NTH = 256;
+constexpr int LDS_BYTES = 2 * SLOT;               // 131072: no epilogue staging
+constexpr int F_ASUM = 1;
+
+struct Args {
+    const bf16_t* A;
+    const bf16_t* B;
+    float* C;
+    int64_t M, N, K, lda, ldb, ldc;
+    float alpha;
+    int tiles_m, tiles_n, splits, nkt, ktiles, n_items;        // nkt: K-tiles per split (the last one may have fewer)
+    float* asum;
+};
+
+typedef __attribute__((ext_vector_type(4))) int int4_t;
+typedef __attribute__((ext_vector_type(2))) int int2_t;
+
+// one operand fragment of v_mfma_f32_32x32x16_bf16 from a [k][column] tile: lane (column r = lane & 31, k group h = lane >> 5) gets
+// k = 8 h + 0..7 of its column: the 4 rows at IMM and the 4 rows below them (IMM + 4 * 512)
+template <int IMM>
+__device__ __forceinline__ bf16x8 lds_tr_pair(uint32_t addr) {
+    int2_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(addr), "n"(IMM));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(addr), "n"(IMM + 2048));
+    int4_t v = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// acc + the sum of the 8 bf16 of a fragment (v_dot2c_f32_bf16 with a packed (1, 1) literal): the bias gradient's share of one k-step
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ float colsum8(const bf16x8& f, float acc) {
+    const bf16x2_t one2 = {(bf16_t)1.0f, (bf16_t)1.0f};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{f[2 * w], f[2 * w + 1]}, one2, acc, false);
+    return acc;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+#define SEG_BARRIER()                          \
+    do {                                       \
+        __builtin_amdgcn_sched_barrier(0);     \
+        __builtin_amdgcn_s_barrier();          \
+        __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+
+struct Cursor {                // position of one K-tile of this block's stream (wave-uniform)
+    int j, kt, nkt;            // item ordinal, K-tile within the item, K-tiles of the item (the last split may be shorter)
+    int64_t m0, n0;
+    const bf16_t* pa;          // A + k0 * lda + m0
+    const bf16_t* pb;          // B + k0 * ldb + n0
+};
+
+__device__ __forceinline__ void decode(const Args& a, int first_item, int stride, Cursor& c) {
+    const int item = first_item + c.j * stride;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int split = item / tiles;
+    const int tile = item - split * tiles;
+    const int tm = tile / a.tiles_n;
+    c.m0 = (int64_t)tm * BM;
+    c.n0 = (int64_t)(tile - tm * a.tiles_n) * BN;
+    const int kt0 = split * a.nkt, left = a.ktiles - kt0;
+    c.nkt = left < a.nkt ? left : a.nkt;
+    const int64_t k0 = (int64_t)(kt0 + c.kt) * BK;
+    c.pa = a.A + k0 * a.lda + c.m0;
+    c.pb = a.B + k0 * a.ldb + c.n0;
+}
+
+// next K-tile of the stream; at the end it stays on the last one (harmless re-reads keep the vmcnt counts uniform)
+__device__ __forceinline__ void advance(const Args& a, int first_item, int stride, int n_mine, Cursor& c) {
+    if (c.kt + 1 < c.nkt) {
+        ++c.kt;
+        c.pa += (int64_t)BK * a.lda;
+        c.pb += (int64_t)BK * a.ldb;
+    } else if (c.j + 1 < n_mine) {
+        ++c.j;
+        c.kt = 0;
+        decode(a, first_item, stride, c);
+    }
+}
+
+// One DMA piece = 256 threads x 16 bytes = 8 k-rows of one operand tile.  PN 0..7: A rows 8 PN .., PN 8..15: B rows 8 (PN - 8) ..
+// Thread -> (row r8 = tid >> 5 of the 8, physical chunk tid & 31); the logical chunk (the swizzle depends on k & 3 = r8 & 3 only) is the same
+// for every piece: SGPR base + 32-bit byte offset.  No tails: the launcher takes this kernel for M, N multiples of 256 and K a multiple of
+// 64 only (every Linear of the ViT-B / ViT-L / BERT geometries at the training batch sizes; the rest stays on gemm256.hip's TN kernel).
+template <int PN>
+__device__ __forceinline__ void issue_piece(const Args& a, const Cursor& c, uint32_t toffA, uint32_t toffB, uint32_t lds_slot_off,
+                                            uint32_t wave_off) {
+    constexpr bool isA = PN < 8;
+    constexpr int P = PN & 7;
+    const int64_t ld = isA ? a.lda : a.ldb;
+    const char* ub = reinterpret_cast<const char*>(isA ? c.pa : c.pb) + (int64_t)(8 * P) * ld * 2;        // wave-uniform
+    __builtin_amdgcn_global_load_lds(GLB_PTR(ub + (isA ? toffA : toffB)),
+                                     (__attribute__((address_space(3))) void*)(size_t)(lds_slot_off + (isA ? 0 : OPT) + P * 4096 + wave_off),
+                                     16, 0, 0);
+}
+
+// pieces issued behind MFMA i of k-step ks (0..15 = this K-tile's successor(s); -1: none) - the schedule of gemm256w4.hip: the first eight
+// pieces of K-tile t+2 go out in k-step 3, right behind the barrier that frees their slot, the other eight in k-step 0 of the next K-tile
+constexpr int N3 = 8;
+__host__ __device__ constexpr int piece_at(int ks, int i) {
+    if (ks == 3) return i >= 8 ? i - 8 : -1;
+    if (ks == 0) return i >= 8 ? N3 + i - 8 : -1;
+    return -1;
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // persistent item assignment: XCD x (= block id % 8) owns a contiguous range of items (as gemm256.hip)
+    const int G = gridDim.x, bid = blockIdx.x;
+    int first_item, stride, n_mine;
+    if ((G & 7) == 0) {
+        const int gx = G >> 3, x = bid & 7, j = bid >> 3;
+        const int q = a.n_items >> 3, r = a.n_items & 7;
+        const int beg = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int cnt = x < r ? q + 1 : q;
+        first_item = beg + j;
+        stride = gx;
+        n_mine = j < cnt ? (cnt - j + gx - 1) / gx : 0;
+    } else {
+        const int x = bid & 7, jx = bid >> 3;
+        int off = 0;
+        for (int y = 0; y < x; ++y) off += (G + 7 - y) >> 3;
+        first_item = off + jx;
+        stride = 1;
+        n_mine = 1;
+    }
+    if (n_mine == 0) return;
+
+    const uint32_t smem_off = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t wave_off = smem_off + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
+    // staging: thread -> row r8 of a piece's 8, physical chunk tid & 31, logical chunk lc
+    const int st_r8 = tid >> 5, st_lc = (tid & 31) ^ ((st_r8 & 3) << 2);
+    const uint32_t toffA = ((uint32_t)st_r8 * (uint32_t)a.lda + (uint32_t)st_lc * 8u) * 2u;
+    const uint32_t toffB = ((uint32_t)st_r8 * (uint32_t)a.ldb + (uint32_t)st_lc * 8u) * 2u;
+#define ISSUE_PN(PN, slot) issue_piece<(PN)>(a, cB, toffA, toffB, (slot), wave_off)
+
+    Cursor cB, cur;
+    cur.j = 0; cur.kt = 0;
+    decode(a, first_item, stride, cur);
+    cB = cur;
+    // prologue: all of K-tile 0, the first N3 pieces of K-tile 1 (what k-step 3 of "K-tile -1" would have issued)
+    static_for<0, 16>([&](auto pn) { ISSUE_PN(decltype(pn)::value, 0u); });
+    advance(a, first_item, stride, n_mine, cB);                     // cB -> K-tile 1
+    static_for<0, N3>([&](auto pn) { ISSUE_PN(decltype(pn)::value, (uint32_t)SLOT); });
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");
+    SEG_BARRIER();
+
+    // fragment addresses.  Lane 16 g + 4 q + p of a transposing read addresses row (k) 8 h + q (h = g >> 1), columns 16 (g & 1) + 4 p .. + 3
+    // of a 32-column tile; tile ti of the wave's 128 columns starts at column 128 w + 32 ti: logical chunk 16 w + 4 ti + 2 (g & 1) + (p >> 1),
+    // physical = logical ^ (q << 2) = 16 w + 4 (ti ^ q) + .. - one address register per tile (the XOR is not an immediate)
+    uint32_t la[4], lb[4];
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const uint32_t rowb = (uint32_t)((8 * h + q) * 512), inb = (uint32_t)(8 * (p & 1));
+            la[ti] = rowb + (uint32_t)((16 * wr + 4 * (ti ^ q) + 2 * (g & 1) + (p >> 1)) << 4) + inb;
+            lb[ti] = rowb + (uint32_t)((16 * wc + 4 * (ti ^ q) + 2 * (g & 1) + (p >> 1)) << 4) + inb + (uint32_t)OPT;
+        }
+    }
+    bf16x8 fa[2][4], fb[2][4];      // [k-step parity][32-column tile]
+    // fragment i (0..3: A tile i, 4..7: B tile i - 4) of k-step KS (rows 16 KS ..) of the slot at byte S
+#define RD_FRAG(buf, S, KS, i)                                                                 \
+    do {                                                                                         \
+        if ((i) < 4) fa[buf][(i) & 3] = lds_tr_pair<(KS) * 8192>(la[(i) & 3] + smem_off + (S));  \
+        else fb[buf][(i) & 3] = lds_tr_pair<(KS) * 8192>(lb[(i) & 3] + smem_off + (S));          \
+    } while (0)
+    static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; RD_FRAG(0, 0u, 0, i); });
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[0][2]), "+v"(fa[0][3]), "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[0][2]), "+v"(fb[0][3]));
+    __builtin_amdgcn_sched_barrier(0);
+
+    // bias gradient: column sums of the A panel, for the two m-tiles 2 wc, 2 wc + 1 of this wave's four (its partner wave column takes the
+    // others), in the K-tiles whose turn it is for this item (tile column c takes K-tiles kt = c mod tiles_n: see gemm256.hip)
+    [[maybe_unused]] float cs[2] = {0.f, 0.f};
+    [[maybe_unused]] const bool cs_on = (FLAGS & F_ASUM) != 0 && a.asum != nullptr;
+
+    int t = 0;
+    for (int j = 0; j < n_mine; ++j) {
+        f32x16 acc[16];                      // [mi * 4 + ni]
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+        if constexpr ((FLAGS & F_ASUM) != 0) { cs[0] = 0.f; cs[1] = 0.f; }
+        [[maybe_unused]] int cs_ctr = (int)(cur.n0 >> 8);      // K-tiles until this item's next turn (BN = 256)
+
+        for (int kt = 0; kt < cur.nkt; ++kt, ++t) {
+            const uint32_t sc = (t & 1) * SLOT, sn = SLOT - sc;
+            [[maybe_unused]] bool do_cs = false;
+            if constexpr ((FLAGS & F_ASUM) != 0) {
+                do_cs = cs_on && cs_ctr == 0;
+                cs_ctr = cs_ctr == 0 ? a.tiles_n - 1 : cs_ctr - 1;
+            }
+            // per-lane address pieces go through an opaque asm each K-tile so that the derived addresses are formed at their use
+            asm volatile("" : "+v"(la[0]), "+v"(la[1]), "+v"(la[2]), "+v"(la[3]), "+v"(lb[0]), "+v"(lb[1]), "+v"(lb[2]), "+v"(lb[3]));
+            // k-step KS: 16 MFMAs on buffer KS & 1; fill(i) behind MFMA i
+            auto kstep = [&](auto ks_tag, auto&& fill) {
+                constexpr int KS = decltype(ks_tag)::value, cb = KS & 1;
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, mi = i >> 2, ni = i & 3;
+                    acc[mi * 4 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][mi], fb[cb][ni], acc[mi * 4 + ni], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fill(ic);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if constexpr ((FLAGS & F_ASUM) != 0) {
+                    if (do_cs) {           // (the fragments just used: their registers are rewritten only by the NEXT k-step's fill)
+                        if (wc == 0) { cs[0] = colsum8(fa[cb][0], cs[0]); cs[1] = colsum8(fa[cb][1], cs[1]); }
+                        else { cs[0] = colsum8(fa[cb][2], cs[0]); cs[1] = colsum8(fa[cb][3], cs[1]); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+#define WAIT_FRAGS(buf)                                                                                                     \
+    do {                                                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                     : "+v"(fa[buf][0]), "+v"(fa[buf][1]), "+v"(fa[buf][2]), "+v"(fa[buf][3]), "+v"(fb[buf][0]),            \
+                       "+v"(fb[buf][1]), "+v"(fb[buf][2]), "+v"(fb[buf][3]));                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    } while (0)
+#define FILL(KS, buf, S, RKS, slot)                                                          \
+    [&](auto ic) {                                                                            \
+        constexpr int i = decltype(ic)::value;                                                \
+        if constexpr (i < 8) RD_FRAG(buf, S, RKS, i);                                         \
+        if constexpr (piece_at(KS, i) >= 0) ISSUE_PN(piece_at(KS, i), slot);                  \
+    }
+            // k-steps 0..2 read the next k-step of this slot and issue the rest of K-tile t+1 (into the other slot)
+            kstep(std::integral_constant<int, 0>{}, FILL(0, 1, sc, 1, sn));
+            WAIT_FRAGS(1);
+            kstep(std::integral_constant<int, 1>{}, FILL(1, 0, sc, 2, sn));
+            WAIT_FRAGS(0);
+            kstep(std::integral_constant<int, 2>{}, FILL(2, 1, sc, 3, sn));
+            advance(a, first_item, stride, n_mine, cB);           // cB -> K-tile t+2
+            WAIT_FRAGS(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of K-tile t+1 have landed
+            SEG_BARRIER();                                        // slot sc is free, slot sn is complete
+            // k-step 3 reads k-step 0 of K-tile t+1 and starts K-tile t+2 into the slot just freed
+            kstep(std::integral_constant<int, 3>{}, FILL(3, 0, sn, 0, sc));
+            WAIT_FRAGS(0);
+        }
+
+        // ---- epilogue of this item: f32 atomics straight from the accumulators.  Register i of acc[mi * 4 + ni], lane (r, h):
+        // C[m = m0 + 128 wr + 32 mi + (i & 3) + 8 (i >> 2) + 4 h][n = n0 + 128 wc + 32 ni + r] - 2 x 128 contiguous bytes per instruction
+        {
+            const int64_t m0 = cur.m0 + wr * 128, n0 = cur.n0 + wc * 128;
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int r = lane_e & 31, h = lane_e >> 5;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    float* cp = a.C + (m0 + 32 * mi + 4 * h) * a.ldc + n0 + 32 * ni + r;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) atomicAdd(cp + (int64_t)((i & 3) + 8 * (i >> 2)) * a.ldc, acc[mi * 4 + ni][i] * a.alpha);
+                }
+            if constexpr ((FLAGS & F_ASUM) != 0) {
+                // cs[u]: sum over this lane's k half (8 h ..) of column m = m0 + 32 (2 wc + u) + r: add the two halves, one atomic per column
+                if (cs_on) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs[u]), __float_as_uint(cs[u]), false, false);
+                        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                        if (h == 0) atomicAdd(a.asum + m0 + 32 * (2 * wc + u) + r, tot * a.alpha);
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0x0F70);       // (keeps hipcc's conservative vmcnt(0) out of the K loop, as in gemm256.hip)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j + 1 < n_mine) {
+            cur.j = j + 1;
+            cur.kt = 0;
+            decode(a, first_item, stride, cur);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail prefetches still target this block's LDS
+}
+
+template <int FLAGS>
+static void launch_inst(const Args& a, int grid, hipStream_t st) {
+    auto kfn = gemm256t4_kernel<FLAGS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(NTH), LDS_BYTES, st, a);
+}
+
+}  // namespace t4
+
+// bf16 TN weight-gradient products this kernel takes: f32 C accumulated in place, no epilogue, whole 8-column chunks, rows 16-byte aligned
+bool gemm256t4_legal(const leccr_gemm_params& p) {
+    if (p.trans_a != 1 || p.trans_b != 1 || p.ab_dtype != LECCR_BF16 || p.c_dtype != LECCR_F32 || !p.accumulate) return false;
+    if (p.epilogue != LECCR_EPI_NONE || p.residual || p.aux || p.aux_out || p.bias || p.colsum) return false;
+    if (p.M < 256 || p.N < 256 || (p.M & 255) || (p.N & 255) || (p.K & 63) || (p.lda & 7) || (p.ldb & 7)) return false;      // no tails
+    if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda >= (1 << 22) || p.ldb >= (1 << 22)) return false;
+    return p.K >= 4096;                // deep reductions only (split-K over up to 256 workgroups)
+}
+
+int gemm256t4_launch(const leccr_gemm_params& p, int cap, hipStream_t st) {
+    using namespace t4;
+    Args a{};
+    a.A = (const bf16_t*)p.A; a.B = (const bf16_t*)p.B; a.C = (float*)p.C;
+    a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc;
+    a.alpha = p.alpha; a.asum = p.asum;
+    a.tiles_m = (int)cdiv(p.M, BM); a.tiles_n = (int)cdiv(p.N, BN);
+    const int64_t ktiles = cdiv(p.K, BK);
+    const int tiles = a.tiles_m * a.tiles_n;
+    // one item per CU in ONE round: tiles * splits <= cap (a second, partial round would double the time)
+    int splits = tiles >= cap ? 1 : cap / tiles;
+    if (splits > ktiles / 8) splits = (int)(ktiles / 8);
+    if (splits < 1) splits = 1;
+    a.nkt = (int)cdiv(ktiles, splits);
+    splits = (int)cdiv(ktiles, a.nkt);        // no empty last split
+    a.splits = splits;
+    a.ktiles = (int)ktiles;
+    a.n_items = tiles * splits;
+    const int grid = a.n_items < cap ? a.n_items : cap;
+    if (a.asum) launch_inst<F_ASUM>(a, grid, st);
+    else launch_inst<0>(a, grid, st);
+    return check_launch("gemm256t4");
+}
+
+}  // namespace leccr

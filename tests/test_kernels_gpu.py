@@ -692,6 +692,50 @@ def test_gemm_tn_fused_bias_gradient(K, Kt, M, N, alpha):
         K.gemm(dy.t().contiguous().to(DEV), x.t().contiguous().to(DEV), asum=bsum)
 
 
+@pytest.mark.parametrize('Kt,M,N,alpha,with_bias', [(64 * 300, 768, 768, 1.0, True), (577 * 64, 2304, 768, 1.0, True), (64 * 72, 3072, 768, 2.0, True),
+                                                    (64 * 257, 768, 3072, 1.0, True), (4096, 256, 256, 1.0, False), (64 * 65, 512, 1024, 0.5, True),
+                                                    (64 * 1000, 256, 512, 1.0, False)])
+def test_gemm256_tn_four_wave_kernel(K, Kt, M, N, alpha, with_bias):
+    """gemm256t4.hip (round 3): the weight-gradient product dW += alpha dY^T X and the bias gradient db += alpha colsum(dY) on the 4-wave
+    TN kernel (v_mfma_f32_32x32x16_bf16, transposing LDS reads pipelined between the MFMAs, f32 atomics straight from the accumulators)
+    against f64 - uneven split-K (65, 257, 300 K-tiles over the workgroups), 1 .. 48 output tiles, twice into the same outputs
+    (accumulation) - and against the 8-wave kernel of gemm256.hip on the same operands.  Shapes it does not take (tails) fall back."""
+    from leccr_amd import _lib
+    lib = _lib.lib()
+    dy, x = _rand((Kt, M), torch.bfloat16, 394), _rand((Kt, N), torch.bfloat16, 395)
+    dy[:, 7] += 0.25
+    base = _rand((M, N), torch.float32, 396)
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    outs = {}
+    try:
+        for variant in (4, 2):
+            lib.leccr_set_gemm_variant(variant)
+            out, bsum = base.clone().to(DEV), torch.full((M,), 3.0, device=DEV)
+            for _ in range(2):
+                K.gemm(dyd, xd, trans_a=True, trans_b=True, out=out, accumulate=True, alpha=alpha, asum=bsum if with_bias else None)
+            assert lib.leccr_last_gemm_kernel() == (5 if variant == 4 else 2)
+            outs[variant] = (out.cpu(), bsum.cpu())
+    finally:
+        lib.leccr_set_gemm_variant(0)
+    ref = base.double() + 2 * alpha * (dy.double().t() @ x.double())
+    want = 3.0 + 2 * alpha * dy.double().sum(0)
+    for variant, (out, bsum) in outs.items():
+        e, s_ = _err(out, ref)
+        assert e <= 1e-4 * s_, (variant, e, s_)
+        if with_bias:
+            err = float((bsum.double() - want).abs().max())
+            assert err <= 4e-5 * float(dy.double().abs().sum(0).max()) + 1e-5, (variant, err)
+    # a shape with tails is not this kernel's: the dispatcher keeps it on the 8-wave one even when the variant is forced
+    try:
+        lib.leccr_set_gemm_variant(4)
+        o2 = torch.zeros(264, 520, device=DEV)
+        K.gemm(_rand((5000, 264), torch.bfloat16, 1).to(DEV), _rand((5000, 520), torch.bfloat16, 2).to(DEV), trans_a=True, trans_b=True, out=o2,
+               accumulate=True)
+        assert lib.leccr_last_gemm_kernel() == 2
+    finally:
+        lib.leccr_set_gemm_variant(0)
+
+
 def test_gemm256_with_fewer_workgroups(K):
     """leccr_set_gemm_max_blocks: the persistent GEMMs on 240 of the 256 CUs (what the all-reduce overlap window uses) give the
     same results - NT bit for bit (same per-tile arithmetic), split-K TN to summation order."""
