@@ -361,10 +361,12 @@ bool gemm256w4_legal(const leccr_gemm_params& p);
 int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st);
 bool gemm256t4_legal(const leccr_gemm_params& p);
 int gemm256t4_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
-// Weight-gradient (TN) products: 1 = the 4-wave kernel of gemm256t4.hip wherever it is legal (LECCR_GEMM_TN4, default below), 0 = the
-// 8-wave TN instantiation of gemm256.hip.  leccr_set_gemm_variant(4) / (2) force one or the other for A/B runs and tests.
+// Weight-gradient (TN) products: the 4-wave kernel of gemm256t4.hip wherever it is legal (default; LECCR_GEMM_TN4=0: the 8-wave TN
+// instantiation of gemm256.hip instead).  leccr_set_gemm_variant(4) / (2) force one or the other for A/B runs and tests.
+// Measured on the step's shapes (scripts/gemm_bench.py, same box): dW qkv 834 -> 1010 TFLOP/s, out 757 -> 818, fc1 960 -> 1076,
+// fc2 1020 -> 1120, BERT dW fc1 618 -> 683, out 259 -> 292 (profiles/r03_gemm_tn4_vs_tn8.txt).
 static int tn4_default() {
-    static const int v = [] { const char* e = getenv("LECCR_GEMM_TN4"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("LECCR_GEMM_TN4"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
 }
 // 0 auto, 1 force the 128x128 kernel, 2 force the 8-wave 256x256 kernel where legal, 3 force the 4-wave 256x256 kernel where legal
@@ -415,7 +417,7 @@ static int gemm_dispatch(const leccr_gemm_params& p, hipStream_t st, bool* colsu
             g_last_kernel = 5;
             return gemm256t4_launch(p, gemm256_max_blocks(), st);
         }
-        if (((g_gemm_variant == 2 || g_gemm_variant == 3) && gemm256_legal(p)) || (g_gemm_variant == 0 && gemm256_wanted(p))) {
+        if (((g_gemm_variant == 2 || g_gemm_variant == 3) && gemm256_legal(p)) || ((g_gemm_variant == 0 || g_gemm_variant == 4) && gemm256_wanted(p))) {
             *colsum_fused = gemm256_fuses_colsum(p);
             g_last_kernel = 2;
             return gemm256_launch(p, st);
