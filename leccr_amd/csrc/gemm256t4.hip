@@ -137,13 +137,28 @@ __device__ __forceinline__ void issue_piece(const Args& a, const Cursor& c, uint
                                      16, 0, 0);
 }
 
-// pieces issued behind MFMA i of k-step ks (0..15 = this K-tile's successor(s); -1: none) - the schedule of gemm256w4.hip: the first eight
-// pieces of K-tile t+2 go out in k-step 3, right behind the barrier that frees their slot, the other eight in k-step 0 of the next K-tile
-constexpr int N3 = 8;
+// pieces issued behind MFMA i of k-step ks (0..15 = the 16 pieces of the K-tile being prefetched; -1: none).  The first pieces of K-tile
+// t+2 go out in k-step 3, right behind the barrier that frees their slot, the rest in k-steps 0 (and 1) of the next K-tile.
+// T4_SCHED 0: as gemm256w4.hip - eight in consecutive gaps of k-step 3, eight in k-step 0 (the last piece then has two k-steps to land);
+// T4_SCHED 1: spread - one piece every third gap over k-steps 3, 0 and 1 (a piece costs the issuing wave ~60-80 cycles against a 32-cycle
+//             MFMA gap: back to back they starve the matrix pipe for a whole burst; the last piece keeps one k-step + the barrier to land)
+#ifndef T4_SCHED
+#define T4_SCHED 1
+#endif
+constexpr int N3 = T4_SCHED == 1 ? 6 : 8;        // pieces issued in k-step 3 (the prologue issues as many of K-tile 1)
 __host__ __device__ constexpr int piece_at(int ks, int i) {
-    if (ks == 3) return i >= 8 ? i - 8 : -1;
-    if (ks == 0) return i >= 8 ? N3 + i - 8 : -1;
-    return -1;
+    if constexpr (T4_SCHED == 1) {
+        if (i % 3 != 2 && !(ks == 3 && i == 0)) return -1;       // gaps 2, 5, 8, 11, 14 (+ gap 0 of k-step 3)
+        const int n = i / 3;                                     // 0..4
+        if (ks == 3) return i == 0 ? 0 : 1 + n;                  // 0, 1..5
+        if (ks == 0) return 6 + n;                               // 6..10
+        if (ks == 1) return 11 + n;                              // 11..15
+        return -1;
+    } else {
+        if (ks == 3) return i >= 8 ? i - 8 : -1;
+        if (ks == 0) return i >= 8 ? N3 + i - 8 : -1;
+        return -1;
+    }
 }
 
 template <int FLAGS>
