@@ -49,7 +49,7 @@ int leccr_set_gemm_max_blocks_for(int n, int64_t launches);   /* the same limit 
                                                 * only, after which all CUs are used again (the expected duration of a collective) */
 int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_gemm launched: 0 generic, 1 MFMA 128x128,
                                                 * 2 MFMA 256x256 (8 waves), 3 MFMA 256x256 (4 waves), 4 the fp8 4-wave kernel,
-                                                * 5 the 4-wave TN weight-gradient kernel; tests use it */
+                                                * 5 the 4-wave TN weight-gradient kernel, 6 its fp8 form; tests use it */
 int leccr_prof_enable(int on);
 int leccr_prof_read(double* ms, double* work, int64_t* launches);
 /* The first n <= 11 kinds: the five above, then {layernorm_fwd, layernorm_bwd, colsum, embedding stages, adamw, dropout} -
@@ -88,7 +88,10 @@ typedef struct leccr_gemm_params {
                                     operands quantised by leccr_quantize_fp8 with per-tensor scales sa, sb; pass alpha = 1 / (sa sb).
                                     trans_a = trans_b = 0, bf16 C, M, N >= 256, K % 128 == 0, lda / ldb % 16 == 0 only: the product runs on
                                     v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 1.0) in the 4-wave 256x256 kernel, f32 accumulation, the forward /
-                                    dX epilogues of the bf16 path.  lda / ldb / K count fp8 ELEMENTS (= bytes). */
+                                    dX epilogues of the bf16 path.  lda / ldb / K count fp8 ELEMENTS (= bytes).
+                                    LECCR_FP8_BF8A with trans_a = trans_b = 1: the weight-gradient product dW += alpha dY^T X on the same
+                                    instruction - A = dY e5m2 [K, M], B = X e4m3 [K, N], both row-major as the forward / dX products hold
+                                    them, f32 C with accumulate = 1, no epilogue / sums, M, N % 256 == 0, K % 128 == 0, K >= 2048. */
     int32_t c_dtype;             /* dtype of C, aux, aux_out, residual */
     int32_t trans_a, trans_b;
     const float* bias;           /* [N] f32 or NULL */

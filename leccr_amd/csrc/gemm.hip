@@ -361,6 +361,8 @@ bool gemm256w4_legal(const leccr_gemm_params& p);
 int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st);
 bool gemm256t4_legal(const leccr_gemm_params& p);
 int gemm256t4_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
+bool gemm256t4_fp8_legal(const leccr_gemm_params& p);
+int gemm256t4_fp8_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
 // Weight-gradient (TN) products: the 4-wave kernel of gemm256t4.hip wherever it is legal (default; LECCR_GEMM_TN4=0: the 8-wave TN
 // instantiation of gemm256.hip instead).  leccr_set_gemm_variant(4) / (2) force one or the other for A/B runs and tests.
 // Measured on the step's shapes (scripts/gemm_bench.py, same box): dW qkv 834 -> 1010 TFLOP/s, out 757 -> 818, fc1 960 -> 1076,
@@ -451,6 +453,15 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     const bool fp8_ab = p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A;
     LECCR_REQUIRE(fp8_ab || (p.alpha_dev[0] == nullptr && p.alpha_dev[1] == nullptr), LECCR_EINVAL,
                   "gemm: alpha_dev (device-side operand scales) exists for fp8 operands only");
+    if (fp8_ab && p.trans_a == 1 && p.trans_b == 1) {
+        // fp8 weight-gradient product dW += alpha dY^T X: e5m2 dY [K, M] against e4m3 X [K, N], f32 C accumulated in place (gemm256t4.hip)
+        LECCR_REQUIRE(gemm256t4_fp8_legal(p), LECCR_EINVAL, "gemm: fp8 TN operands need ab_dtype LECCR_FP8_BF8A, an accumulated f32 C, no epilogue, "
+                      "M, N %% 256 == 0, K %% 128 == 0, K >= 2048 and 16-byte aligned rows");
+        hipStream_t st8 = as_stream(stream);
+        ProfScope prof(PROF_GEMM_TN, 2.0 * (double)p.M * (double)p.N * (double)p.K, st8);
+        g_last_kernel = 6;
+        return gemm256t4_fp8_launch(p, gemm256_max_blocks(), st8);
+    }
     if (fp8_ab) {
         // fp8 MFMA GEMM inputs: only the 4-wave 256x256 kernel has them (no generic / small-shape fp8 path: callers keep those in bf16)
         LECCR_REQUIRE(gemm256w4_fp8_legal(p), LECCR_EINVAL, "gemm: fp8 operands need trans_a = trans_b = 0, a bf16 C, M, N >= 256, K %% 128 == 0, "

@@ -341,6 +341,231 @@ __global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tail prefetches still target this block's LDS
 }
 
+// ---------------------------------------------------------------------------------------------------- fp8 operands (BASELINE configs[4])
+// The same kernel with OCP fp8 operands: A = dY in e5m2 [K, M], B = X in e4m3 [K, N] (the copies the forward / dX products of the Linear
+// already use, row-major as they are - no transposed copies), v_mfma_scale_f32_32x32x64_f8f6f4 with block scales 1.0; the per-tensor
+// inverse scales are device scalars folded into alpha at kernel start.  A K-tile is 128 k: an operand tile [128 k][256 bytes] has the
+// bytes of the bf16 tile, 16 DMA pieces and 64 transposing reads per K-tile as before, and 32 scaled MFMAs (64 cycles each) in place of
+// 64 bf16 ones - twice the k per K-tile in the same matrix-pipe time.
+//   * ds_read_b64_tr_b8 (probed: scripts/mb/ds_tr8_probe.hip): per 16 lanes an 8 row x 16 byte block; lane 2 q + p supplies the address of
+//     row q, bytes 8 p .. 8 p + 7; lane i receives byte column i of the 8 rows.  A fragment = 4 such reads = 32 k of one column; which k
+//     a lane half holds is immaterial as long as A and B agree (here k = 64 ks + 32 h + 8 j + e for read j, element e).
+//   * LDS image: 256-byte rows; the 8 rows of a read would share banks (row stride = the bank window), so the 32-byte group index of a
+//     chunk is XORed with k & 7: physical 16-byte chunk = logical ^ ((k & 7) << 1).
+//   * no fused bias sums (they must come from the unquantised dY: leccr_gemm runs its column-sum pass over the bf16 tensor instead).
+typedef __attribute__((ext_vector_type(8))) int v8i_t;
+
+template <int IMM>
+__device__ __forceinline__ v8i_t lds_tr8_quad(uint32_t addr) {       // 4 x 8 rows: IMM, + 8, + 16, + 24 rows (256 bytes each)
+    int2_t r0, r1, r2, r3;
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r0) : "v"(addr), "n"(IMM));
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r1) : "v"(addr), "n"(IMM + 2048));
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r2) : "v"(addr), "n"(IMM + 4096));
+    asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(r3) : "v"(addr), "n"(IMM + 6144));
+    return v8i_t{r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
+}
+
+struct Args8 {
+    const uint8_t* A;
+    const uint8_t* B;
+    float* C;
+    int64_t M, N, K, lda, ldb, ldc;
+    float alpha;
+    const float* alpha_dev[2];
+    int tiles_m, tiles_n, splits, nkt, ktiles, n_items;
+};
+constexpr int BK8 = 128;
+
+struct Cursor8 {
+    int j, kt, nkt;
+    int64_t m0, n0;
+    const uint8_t* pa;
+    const uint8_t* pb;
+};
+
+__device__ __forceinline__ void decode8(const Args8& a, int first_item, int stride, Cursor8& c) {
+    const int item = first_item + c.j * stride;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int split = item / tiles;
+    const int tile = item - split * tiles;
+    const int tm = tile / a.tiles_n;
+    c.m0 = (int64_t)tm * BM;
+    c.n0 = (int64_t)(tile - tm * a.tiles_n) * BN;
+    const int kt0 = split * a.nkt, left = a.ktiles - kt0;
+    c.nkt = left < a.nkt ? left : a.nkt;
+    const int64_t k0 = (int64_t)(kt0 + c.kt) * BK8;
+    c.pa = a.A + k0 * a.lda + c.m0;
+    c.pb = a.B + k0 * a.ldb + c.n0;
+}
+
+__device__ __forceinline__ void advance8(const Args8& a, int first_item, int stride, int n_mine, Cursor8& c) {
+    if (c.kt + 1 < c.nkt) {
+        ++c.kt;
+        c.pa += (int64_t)BK8 * a.lda;
+        c.pb += (int64_t)BK8 * a.ldb;
+    } else if (c.j + 1 < n_mine) {
+        ++c.j;
+        c.kt = 0;
+        decode8(a, first_item, stride, c);
+    }
+}
+
+// One DMA piece = 256 threads x 16 bytes = 16 k-rows (256 bytes each) of one operand tile; PN 0..7: A rows 16 PN .., 8..15: B.
+template <int PN>
+__device__ __forceinline__ void issue_piece8(const Args8& a, const Cursor8& c, uint32_t toffA, uint32_t toffB, uint32_t lds_slot_off,
+                                             uint32_t wave_off) {
+    constexpr bool isA = PN < 8;
+    constexpr int P = PN & 7;
+    const int64_t ld = isA ? a.lda : a.ldb;
+    const char* ub = reinterpret_cast<const char*>(isA ? c.pa : c.pb) + (int64_t)(16 * P) * ld;        // wave-uniform
+    __builtin_amdgcn_global_load_lds(GLB_PTR(ub + (isA ? toffA : toffB)),
+                                     (__attribute__((address_space(3))) void*)(size_t)(lds_slot_off + (isA ? 0 : OPT) + P * 4096 + wave_off),
+                                     16, 0, 0);
+}
+
+// pieces behind MFMA i of k-step ks (two k-steps of 16 scaled MFMAs per K-tile: k-step 1 follows the barrier that frees the slot of K-tile
+// t+2, k-step 0 of the next K-tile takes the rest): every second gap (a scaled MFMA gap is 64 cycles)
+__host__ __device__ constexpr int piece8_at(int ks, int i) {
+    if ((i & 1) == 0) return -1;
+    return ks == 1 ? i / 2 : 8 + i / 2;
+}
+
+__global__ __launch_bounds__(NTH) void gemm256t4_fp8_kernel(Args8 a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int G = gridDim.x, bid = blockIdx.x;
+    int first_item, stride, n_mine;
+    if ((G & 7) == 0) {
+        const int gx = G >> 3, x = bid & 7, j = bid >> 3;
+        const int q = a.n_items >> 3, r = a.n_items & 7;
+        const int beg = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int cnt = x < r ? q + 1 : q;
+        first_item = beg + j;
+        stride = gx;
+        n_mine = j < cnt ? (cnt - j + gx - 1) / gx : 0;
+    } else {
+        const int x = bid & 7, jx = bid >> 3;
+        int off = 0;
+        for (int y = 0; y < x; ++y) off += (G + 7 - y) >> 3;
+        first_item = off + jx;
+        stride = 1;
+        n_mine = 1;
+    }
+    if (n_mine == 0) return;
+    if (a.alpha_dev[0]) a.alpha *= *a.alpha_dev[0];          // 1 / (scale_A scale_B), both kept on the device
+    if (a.alpha_dev[1]) a.alpha *= *a.alpha_dev[1];
+
+    const uint32_t smem_off = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t wave_off = smem_off + (uint32_t)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
+    // staging: thread -> row r16 = tid >> 4 of a piece's 16, physical chunk tid & 15, logical chunk = physical ^ ((row & 7) << 1)
+    const int st_r = tid >> 4, st_lc = (tid & 15) ^ ((st_r & 7) << 1);
+    const uint32_t toffA = (uint32_t)st_r * (uint32_t)a.lda + (uint32_t)st_lc * 16u;
+    const uint32_t toffB = (uint32_t)st_r * (uint32_t)a.ldb + (uint32_t)st_lc * 16u;
+#define ISSUE8(PN, slot) issue_piece8<(PN)>(a, cB, toffA, toffB, (slot), wave_off)
+
+    Cursor8 cB, cur;
+    cur.j = 0; cur.kt = 0;
+    decode8(a, first_item, stride, cur);
+    cB = cur;
+    static_for<0, 16>([&](auto pn) { ISSUE8(decltype(pn)::value, 0u); });
+    advance8(a, first_item, stride, n_mine, cB);                    // cB -> K-tile 1
+    static_for<0, 8>([&](auto pn) { ISSUE8(decltype(pn)::value, (uint32_t)SLOT); });
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    SEG_BARRIER();
+
+    // fragment addresses: lane 16 g + 2 q + p of a transposing read addresses row 32 h + q (h = g >> 1), bytes 16 (g & 1) + 8 p .. of a
+    // 32-column tile; tile ti of the wave's 128 columns is 32-byte group 4 w + ti of the 256-byte row; physical group = logical ^ (row & 7)
+    uint32_t la[4], lb[4];
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 1, pp = i & 1, h = g >> 1;
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const uint32_t rowb = (uint32_t)((32 * h + q) * 256), inb = (uint32_t)(16 * (g & 1) + 8 * pp);
+            la[ti] = smem_off + rowb + (uint32_t)(((4 * wr + ti) ^ q) << 5) + inb;
+            lb[ti] = smem_off + rowb + (uint32_t)(((4 * wc + ti) ^ q) << 5) + inb + (uint32_t)OPT;
+        }
+    }
+    v8i_t fa[2][4], fb[2][4];
+#define RD_FRAG8(buf, S, KS, i)                                                          \
+    do {                                                                                   \
+        if ((i) < 4) fa[buf][(i) & 3] = lds_tr8_quad<(KS) * 16384>(la[(i) & 3] + (S));     \
+        else fb[buf][(i) & 3] = lds_tr8_quad<(KS) * 16384>(lb[(i) & 3] + (S));             \
+    } while (0)
+#define WAIT_FRAGS8(buf)                                                                                                    \
+    do {                                                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                     : "+v"(fa[buf][0]), "+v"(fa[buf][1]), "+v"(fa[buf][2]), "+v"(fa[buf][3]), "+v"(fb[buf][0]),            \
+                       "+v"(fb[buf][1]), "+v"(fb[buf][2]), "+v"(fb[buf][3]));                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    } while (0)
+    static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; RD_FRAG8(0, 0u, 0, i); });
+    WAIT_FRAGS8(0);
+
+    int t = 0;
+    for (int j = 0; j < n_mine; ++j) {
+        f32x16 acc[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+        for (int kt = 0; kt < cur.nkt; ++kt, ++t) {
+            const uint32_t sc = (t & 1) * SLOT, sn = SLOT - sc;
+            asm volatile("" : "+v"(la[0]), "+v"(la[1]), "+v"(la[2]), "+v"(la[3]), "+v"(lb[0]), "+v"(lb[1]), "+v"(lb[2]), "+v"(lb[3]));
+            auto kstep = [&](auto ks_tag, auto&& fill) {
+                constexpr int cb = decltype(ks_tag)::value & 1;
+                static_for<0, 16>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value, mi = i >> 2, ni = i & 3;
+                    // first operand = dY^T rows (e5m2: format 1), second = X columns (e4m3: format 0); block scales 2^0
+                    acc[mi * 4 + ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[cb][mi], fb[cb][ni], acc[mi * 4 + ni], 1, 0, 0,
+                                                                                       0x7F7F7F7F, 0, 0x7F7F7F7F);
+                    __builtin_amdgcn_sched_barrier(0);
+                    fill(ic);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+#define FILL8T(KSP, buf, S, RKS, slot)                                                        \
+    [&](auto ic) {                                                                            \
+        constexpr int i = decltype(ic)::value;                                                \
+        if constexpr (i < 8) RD_FRAG8(buf, S, RKS, i);                                        \
+        if constexpr (piece8_at(KSP, i) >= 0) ISSUE8(piece8_at(KSP, i), slot);                \
+    }
+            // k-step 0 (buffer 0): reads k-step 1 of this slot; the rest (pieces 8-15) of K-tile t+1  -> wait; vmcnt(0); BARRIER
+            kstep(std::integral_constant<int, 0>{}, FILL8T(0, 1, sc, 1, sn));
+            advance8(a, first_item, stride, n_mine, cB);          // cB -> K-tile t+2
+            WAIT_FRAGS8(1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            SEG_BARRIER();
+            // k-step 1 (buffer 1): reads k-step 0 of K-tile t+1; pieces 0-7 of K-tile t+2 into the slot the barrier freed
+            kstep(std::integral_constant<int, 1>{}, FILL8T(1, 0, sn, 0, sc));
+            WAIT_FRAGS8(0);
+        }
+        {
+            const int64_t m0 = cur.m0 + wr * 128, n0 = cur.n0 + wc * 128;
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int r = lane_e & 31, h = lane_e >> 5;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    float* cp = a.C + (m0 + 32 * mi + 4 * h) * a.ldc + n0 + 32 * ni + r;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) atomicAdd(cp + (int64_t)((i & 3) + 8 * (i >> 2)) * a.ldc, acc[mi * 4 + ni][i] * a.alpha);
+                }
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j + 1 < n_mine) {
+            cur.j = j + 1;
+            cur.kt = 0;
+            decode8(a, first_item, stride, cur);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 template <int FLAGS>
 static void launch_inst(const Args& a, int grid, hipStream_t st) {
     auto kfn = gemm256t4_kernel<FLAGS>;
@@ -353,6 +578,42 @@ static void launch_inst(const Args& a, int grid, hipStream_t st) {
 }
 
 }  // namespace t4
+
+// fp8 weight-gradient products: A = dY e5m2 [K, M], B = X e4m3 [K, N] (ab_dtype LECCR_FP8_BF8A, trans_a = trans_b = 1), f32 C in place
+bool gemm256t4_fp8_legal(const leccr_gemm_params& p) {
+    if (p.trans_a != 1 || p.trans_b != 1 || p.ab_dtype != LECCR_FP8_BF8A || p.c_dtype != LECCR_F32 || !p.accumulate) return false;
+    if (p.epilogue != LECCR_EPI_NONE || p.residual || p.aux || p.aux_out || p.bias || p.colsum || p.asum || p.c8) return false;
+    if (p.M < 256 || p.N < 256 || (p.M & 255) || (p.N & 255) || (p.K & 127) || (p.lda & 15) || (p.ldb & 15)) return false;
+    if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda >= (1 << 23) || p.ldb >= (1 << 23)) return false;
+    return p.K >= 2048;
+}
+
+int gemm256t4_fp8_launch(const leccr_gemm_params& p, int cap, hipStream_t st) {
+    using namespace t4;
+    Args8 a{};
+    a.A = (const uint8_t*)p.A; a.B = (const uint8_t*)p.B; a.C = (float*)p.C;
+    a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc;
+    a.alpha = p.alpha; a.alpha_dev[0] = p.alpha_dev[0]; a.alpha_dev[1] = p.alpha_dev[1];
+    a.tiles_m = (int)cdiv(p.M, BM); a.tiles_n = (int)cdiv(p.N, BN);
+    const int64_t ktiles = p.K / BK8;
+    const int tiles = a.tiles_m * a.tiles_n;
+    int splits = tiles >= cap ? 1 : cap / tiles;
+    if (splits > ktiles / 4) splits = (int)(ktiles / 4);
+    if (splits < 1) splits = 1;
+    a.nkt = (int)cdiv(ktiles, splits);
+    splits = (int)cdiv(ktiles, a.nkt);
+    a.splits = splits;
+    a.ktiles = (int)ktiles;
+    a.n_items = tiles * splits;
+    const int grid = a.n_items < cap ? a.n_items : cap;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256t4_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm256t4_fp8_kernel, dim3(grid), dim3(NTH), LDS_BYTES, st, a);
+    return check_launch("gemm256t4 fp8");
+}
 
 // bf16 TN weight-gradient products this kernel takes: f32 C accumulated in place, no epilogue, whole 8-column chunks, rows 16-byte aligned
 bool gemm256t4_legal(const leccr_gemm_params& p) {

@@ -37,7 +37,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     p.M, p.N, p.K = M, N, K
     p.lda, p.ldb, p.ldc = a.stride(0), b.stride(0), out.stride(0)
     if fp8:     # fp8 operands (quantize_fp8): b e4m3, a e4m3 (forward) or e5m2 (gradients); alpha_dev = their two inverse scales
-        assert b.dtype == torch.float8_e4m3fn and not trans_a and not trans_b
+        assert b.dtype == torch.float8_e4m3fn and trans_a == trans_b      # NT (forward / dX) or the weight-gradient form dY^T X
         p.ab_dtype, p.c_dtype = (FP8 if a.dtype == torch.float8_e4m3fn else FP8_BF8A), dtype_code(out)
     else:
         p.ab_dtype, p.c_dtype = dtype_code(a), dtype_code(out)

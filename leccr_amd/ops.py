@@ -123,6 +123,26 @@ def _fp8_ok(x2, w8):
             and x2.stride(0) % 16 == 0)
 
 
+# fp8 mode: the weight-gradient products take the SAME fp8 copies as the forward / dX products of their Linear (e4m3 X saved by the
+# forward, e5m2 dY of the dX product) on leccr_gemm's LECCR_FP8_BF8A trans_a = trans_b = 1 form.  LECCR_FP8_DW=0: bf16 dW as in round 2.
+fp8_dw = os.environ.get('LECCR_FP8_DW', '1') != '0'
+fp8_dw_launches = 0          # fp8 weight-gradient products launched (tests read it)
+
+
+def x8_of(fp8, x2, w, x8=None):
+    """The e4m3 copy of x2 that Linear `w` multiplies in fp8 mode (x8 if the producer wrote it), None when that product is bf16."""
+    if not (fp8 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8)):
+        return None
+    return x8 if x8 is not None else w._xsite.quantize(x2)
+
+
+def g8_of(fp8, dy2, w, g8=None):
+    """The e5m2 copy of the incoming gradient dy2 of Linear `w` in fp8 mode, None when its dX product is bf16."""
+    if not (fp8 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t)):
+        return None
+    return g8 if g8 is not None else w._gsite.quantize(dy2)
+
+
 def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, **kw):
     """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free).
     fp8 (compute_dtype 'fp8', the encoder blocks' Linears): x2 is quantised to e4m3 under the Linear's activation site and
@@ -218,22 +238,29 @@ def join_wgrad_stream(stream=None):
         cur.wait_stream(s)
 
 
-def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None):
+def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None):
     """dW += scale * dY^T X (f32, into the gradient arena) and db += scale * colsum(dY).
     dy_bias: the tensor whose column sums are the bias gradient when it is not dy2 itself (an f32 head's incoming gradient,
-    of which dy2 is the bf16 GEMM operand: the bias sum cancels heavily and is taken from the unrounded values)."""
+    of which dy2 is the bf16 GEMM operand: the bias sum cancels heavily and is taken from the unrounded values).
+    g8, x8 (fp8 mode): the e5m2 copy of dy2 and the e4m3 copy of x2 under w's gradient / activation sites - the product then runs on
+    the fp8 weight-gradient kernel (the bias sums still come from the bf16 dy2)."""
     global _wgrad_stream, _wgrad_join_queued
+    if not (fp8_dw and g8 is not None and x8 is not None and _fp8_dw_ok(g8, x8)):
+        g8 = x8 = None
     if not (wgrad_overlap and dy2.is_cuda):
-        return _lin_dw(dy2, x2, w, b, scale, dy_bias)
+        return _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8)
     main = torch.cuda.current_stream()
     if _wgrad_stream is None:
         _wgrad_stream = torch.cuda.Stream(device=dy2.device)
     side = _wgrad_stream
     side.wait_stream(main)                      # dY and X were produced on the main stream
     with torch.cuda.stream(side):
-        _lin_dw(dy2, x2, w, b, scale, dy_bias)
+        _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8)
     dy2.record_stream(side)                     # the caching allocator must not recycle them under the side stream
     x2.record_stream(side)
+    if g8 is not None:
+        g8.record_stream(side)
+        x8.record_stream(side)
     if dy_bias is not None:
         dy_bias.record_stream(side)
     if not _wgrad_join_queued:
@@ -250,12 +277,30 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None):
             main.wait_stream(side)
 
 
-def _lin_dw(dy2, x2, w, b, scale, dy_bias=None):
+def _fp8_dw_ok(g8, x8):
+    """leccr_gemm's fp8 weight-gradient form: whole 256 x 256 output tiles, >= 2048 rows (whole 128-row K-tiles; a shorter tail goes
+    to the bf16 kernel), 16-byte aligned rows."""
+    return (g8.shape[0] >= 2048 and g8.shape[1] % 256 == 0 and x8.shape[1] % 256 == 0 and g8.stride(0) % 16 == 0 and x8.stride(0) % 16 == 0
+            and g8.data_ptr() % 16 == 0 and x8.data_ptr() % 16 == 0)
+
+
+def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None):
     # the bias gradient colsum(dY) rides in the dW GEMM (leccr_gemm_params.asum: on the matrix cores beside the product in the
     # 256x256 kernel, a colsum pass inside leccr_gemm otherwise) unless it comes from another tensor or carries a scale
     fused = b is not None and dy_bias is None and scale == 1.0 and fuse_bias_grad
-    K.gemm(dy2, x2, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale,
-           asum=b._g.reshape(-1) if fused else None)
+    if g8 is not None:
+        # fp8 operands: whole 128-row K-tiles on the scaled-MFMA kernel, the (< 128-row) tail and the bias sums from the bf16 tensors
+        global fp8_dw_launches
+        fp8_dw_launches += 1
+        rows = g8.shape[0] // 128 * 128
+        K.gemm(g8[:rows], x8[:rows], trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale,
+               alpha_dev=(w._gsite.inv_scale, w._xsite.inv_scale))
+        if rows < g8.shape[0]:
+            K.gemm(dy2[rows:], x2[rows:], trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale)
+        fused = False
+    else:
+        K.gemm(dy2, x2, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale,
+               asum=b._g.reshape(-1) if fused else None)
     _mark(w)
     if b is not None and fused:
         _mark(b)
@@ -410,17 +455,23 @@ class ViTBlockFn(torch.autograd.Function):
         # (fp8: the LayerNorm passes also write the e4m3 copy their consumer multiplies - no quantise pass over h1 / h2)
         h1, mean1, rstd1, _, h1_8 = _ln_fwd(x, blk.ln_1.weight.data, blk.ln_1.bias.data, 1e-5,
                                             site=_q8_site(blk.fp8, M, blk.attn.in_proj_weight, '_xsite'))
+        h1_8 = x8_of(blk.fp8, _rows(h1), blk.attn.in_proj_weight, h1_8)
         qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8, x8=h1_8).view(b, N, 3 * d)
         o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
-        x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, residual=_rows(x)).view(b, N, d)
+        o_8 = x8_of(blk.fp8, _rows(o), blk.attn.out_proj.weight)
+        x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, x8=o_8, residual=_rows(x)).view(b, N, d)
         h2, mean2, rstd2, _, h2_8 = _ln_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5,
                                             site=_q8_site(blk.fp8, M, blk.mlp.c_fc.weight, '_xsite'))
         pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
+        h2_8 = x8_of(blk.fp8, _rows(h2), blk.mlp.c_fc.weight, h2_8)
         # (fp8: the activation's e4m3 copy for c_proj comes out of c_fc's epilogue - no quantise pass over the 4d-wide tensor)
         act, act8 = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, x8=h2_8, epilogue=EPI_QUICKGELU, aux_out=pre,
                             c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True)
+        act8 = x8_of(blk.fp8, act, blk.mlp.c_proj.weight, act8)
         x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
         ctx.save_for_backward(x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act)
+        # fp8: the e4m3 copies the forward products multiplied are the weight-gradient products' X operands
+        ctx.x8 = (h1_8, o_8, h2_8, act8) if fp8_dw else (None,) * 4
         ctx.blk = blk
         return x2
 
@@ -432,27 +483,32 @@ class ViTBlockFn(torch.autograd.Function):
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
+        h1_8, o_8, h2_8, act8 = ctx.x8
         g2_8 = _g8_take(g2) if blk.fp8 else None          # written by the next block's LayerNorm-1 backward (fp8 mode)
+        g2_8 = g8_of(blk.fp8, g2, blk.mlp.c_proj.weight, g2_8)
         dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, g8=g2_8, epilogue=EPI_DQUICKGELU, aux=pre,
                              c8_site=_site(blk.mlp.c_fc.weight, '_gsite'), want8=True)
         # bias gradients of c_proj / out_proj = column sums of dx2 / dx1.  They ride the weight-gradient stream as 40 us HBM-bound
         # passes beside the dX chain: folded into the LayerNorm backward launches (whose `dres` operands those tensors are) they
         # cost that kernel a fifth of its occupancy - 253 us against 201 us per launch on the main chain
-        lin_dw(g2, act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias)
+        lin_dw(g2, act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, g8=g2_8, x8=act8)
+        dpre8 = g8_of(blk.fp8, dpre, blk.mlp.c_fc.weight, dpre8)
         dh2 = lin_dx(dpre, blk.mlp.c_fc.weight, fp8=blk.fp8, g8=dpre8)
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
-        lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias)
+        lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, g8=dpre8, x8=h2_8)
         dx1, _, g1_8 = _ln_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g, blk.ln_2.bias._g,
                                site=_q8_site(blk.fp8, b * N, blk.attn.out_proj.weight, '_gsite'), dres=dx2)
         g1 = _rows(dx1)
+        g1_8 = g8_of(blk.fp8, g1, blk.attn.out_proj.weight, g1_8)
         do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8, g8=g1_8).view(b, N, d)
-        lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias)
+        lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, g8=g1_8, x8=o_8)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
-        dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8)
-        lin_dw(_rows(dqkv), _rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias)
+        dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight)
+        dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)
+        lin_dw(_rows(dqkv), _rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
         # (fp8: dx is the gradient the previous block's c_proj dX product consumes: its e5m2 copy goes with it)
         prev = getattr(blk, '_dx_consumer', (None,))[0]
         dx, _, dx_8 = _ln_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g, blk.ln_1.bias._g,
@@ -536,21 +592,25 @@ class BertLayerFn(torch.autograd.Function):
         b, L, d = x.shape
         ph, pa = _p(layer, 'hidden_dropout_p'), _p(layer, 'attn_dropout_p')
         seeds = (_next_seed(), _next_seed(), _next_seed())
-        qkv = lin_fwd(_rows(x), layer._qkv_w, layer._qkv_b, fp8=layer.fp8).view(b, L, 3 * d)
+        x_8 = x8_of(layer.fp8, _rows(x), layer._qkv_w)
+        qkv = lin_fwd(_rows(x), layer._qkv_w, layer._qkv_b, fp8=layer.fp8, x8=x_8).view(b, L, 3 * d)
         o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask, pa, seeds[0])
         ao = layer.attention.output
+        o_8 = x8_of(layer.fp8, _rows(o), ao.dense.weight)
         x1_site = _q8_site(layer.fp8, b * L, layer.intermediate.dense.weight, '_xsite')      # fp8: x1's e4m3 copy out of its LayerNorm pass
         if ph > 0:      # dense -> dropout -> + residual (inside the LayerNorm kernel)
-            a1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8)
+            a1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8, x8=o_8)
             x1, mean1, rstd1, s1, x1_8 = _ln_fwd(a1.view(b, L, d), ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps,
                                                  site=x1_site, add=x, want_sum=True, drop=(ph, seeds[1]))
         else:
-            s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8, residual=_rows(x)).view(b, L, d)
+            s1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8, x8=o_8, residual=_rows(x)).view(b, L, d)
             x1, mean1, rstd1, _, x1_8 = _ln_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps, site=x1_site)
         pre = torch.empty(b * L, layer.intermediate.dense.weight.shape[0], device=x.device, dtype=x.dtype)
+        x1_8 = x8_of(layer.fp8, _rows(x1), layer.intermediate.dense.weight, x1_8)
         h, h8 = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, x8=x1_8, epilogue=EPI_GELU,
                         aux_out=pre, c8_site=_site(layer.output.dense.weight, '_xsite'), want8=True)
         out = layer.output
+        h8 = x8_of(layer.fp8, h, out.dense.weight, h8)
         if ph > 0:
             a2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8)
             x2, mean2, rstd2, s2 = K.layernorm_fwd(a2.view(b, L, d), out.LayerNorm.weight.data, out.LayerNorm.bias.data,
@@ -560,6 +620,7 @@ class BertLayerFn(torch.autograd.Function):
             x2, mean2, rstd2, _ = K.layernorm_fwd(s2, out.LayerNorm.weight.data, out.LayerNorm.bias.data, layer.eps)
         ctx.save_for_backward(x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2)
         ctx.layer, ctx.drop = layer, (ph, pa, seeds)
+        ctx.x8 = (x_8, o_8, x1_8, h8) if fp8_dw else (None,) * 4          # fp8: the weight-gradient products' X operands
         return x2
 
     @staticmethod
@@ -576,22 +637,27 @@ class BertLayerFn(torch.autograd.Function):
                                  out.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, out.dense.weight, '_gsite'),
                                  drop=(ph, seeds[2]) if ph > 0 else None)
         g2, gd2 = _rows(g2), _rows(gd2)
+        x_8, o_8, x1_8, h8 = ctx.x8
+        gd2_8 = g8_of(layer.fp8, gd2, out.dense.weight, gd2_8)
         dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, g8=gd2_8, epilogue=EPI_DGELU, aux=pre,
                              c8_site=_site(layer.intermediate.dense.weight, '_gsite'), want8=True)
-        lin_dw(gd2, h, out.dense.weight, out.dense.bias)
+        lin_dw(gd2, h, out.dense.weight, out.dense.bias, g8=gd2_8, x8=h8)
+        dpre8 = g8_of(layer.fp8, dpre, layer.intermediate.dense.weight, dpre8)
         dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
-        lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias)
+        lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, g8=dpre8, x8=x1_8)
         g1, gd1, gd1_8 = _ln_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                                  ao.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, ao.dense.weight, '_gsite'),
                                  drop=(ph, seeds[1]) if ph > 0 else None)
         g1, gd1 = _rows(g1), _rows(gd1)
+        gd1_8 = g8_of(layer.fp8, gd1, ao.dense.weight, gd1_8)
         do = lin_dx(gd1, ao.dense.weight, fp8=layer.fp8, g8=gd1_8).view(b, L, d)
-        lin_dw(gd1, _rows(o), ao.dense.weight, ao.dense.bias)
+        lin_dw(gd1, _rows(o), ao.dense.weight, ao.dense.bias, g8=gd1_8, x8=o_8)
         dqkv = torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, layer.heads, kmask,
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], drop_p=pa, seed=seeds[0])
-        dx = lin_dx(_rows(dqkv), layer._qkv_w, fp8=layer.fp8, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
-        lin_dw(_rows(dqkv), _rows(x), layer._qkv_w, layer._qkv_b)
+        dqkv8 = g8_of(layer.fp8, _rows(dqkv), layer._qkv_w)
+        dx = lin_dx(_rows(dqkv), layer._qkv_w, fp8=layer.fp8, g8=dqkv8, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
+        lin_dw(_rows(dqkv), _rows(x), layer._qkv_w, layer._qkv_b, g8=dqkv8, x8=x_8)
         for p in (out.LayerNorm.weight, out.LayerNorm.bias, ao.LayerNorm.weight, ao.LayerNorm.bias):
             _mark(p)
         return (dx, None, None) + (None,) * len(ctx.needs_input_grad[3:])

@@ -32,24 +32,26 @@ import torch.nn.functional as F
 # from the fp32 result is the yardstick the HIP bf16 path's own deviation is held against, tensor by tensor.
 _LOWP = False
 _FP8 = False
+_FP8_DW = False
 
 
 class lowp:
     """with lowp(): bf16 storage model.  with lowp(fp8=True): additionally the fp8 operand model of compute_dtype 'fp8' (BASELINE
     configs[4]): the big Linears of the ViT blocks and BERT layers multiply per-tensor scaled OCP e4m3 copies of their input and
-    weight (power-of-two scale from the tensor's amax), and their dX product takes the incoming gradient in e5m2; weight gradients,
-    everything else as under lowp()."""
+    weight (power-of-two scale from the tensor's amax), and their dX product takes the incoming gradient in e5m2; with fp8_dw (round 3)
+    the weight-gradient product dY^T X of those Linears takes the same e5m2 / e4m3 copies where the HIP path has an fp8 kernel for it
+    (>= 2048 rows, in / out whole 256-tiles); everything else as under lowp()."""
 
-    def __init__(self, fp8=False):
-        self.fp8 = fp8
+    def __init__(self, fp8=False, fp8_dw=True):
+        self.fp8, self.fp8_dw = fp8, fp8 and fp8_dw
 
     def __enter__(self):
-        global _LOWP, _FP8
-        self.prev, _LOWP, _FP8 = (_LOWP, _FP8), True, self.fp8
+        global _LOWP, _FP8, _FP8_DW
+        self.prev, _LOWP, _FP8, _FP8_DW = (_LOWP, _FP8, _FP8_DW), True, self.fp8, self.fp8_dw
 
     def __exit__(self, *exc):
-        global _LOWP, _FP8
-        _LOWP, _FP8 = self.prev
+        global _LOWP, _FP8, _FP8_DW
+        _LOWP, _FP8, _FP8_DW = self.prev
 
 
 def _q8(t, dtype, fmax):
@@ -62,7 +64,8 @@ def _q8(t, dtype, fmax):
 
 
 class _Fp8Linear(torch.autograd.Function):
-    """y = q4(x) q4(w)^T + b;  dx = q5(dy) q4(w);  dw = dy^T x, db = colsum(dy) from the bf16 tensors (as the bf16 path)."""
+    """y = q4(x) q4(w)^T + b;  dx = q5(dy) q4(w);  db = colsum(dy) from the bf16 tensor;  dw = dy^T x from the bf16 tensors, or
+    q5(dy)^T q4(x) where the HIP path's fp8 weight-gradient kernel applies (lowp(fp8_dw=True); its < 128-row bf16 tail is not modelled)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
@@ -77,8 +80,13 @@ class _Fp8Linear(torch.autograd.Function):
     def backward(ctx, dy):
         x, wq = ctx.saved_tensors
         dy2, x2 = dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1])
-        dx = (_q8(dy2, torch.float8_e5m2, 57344.0) @ wq).reshape(x.shape)
-        return dx, dy2.t() @ x2, (dy2.sum(0) if ctx.has_b else None)
+        dq = _q8(dy2, torch.float8_e5m2, 57344.0)
+        dx = (dq @ wq).reshape(x.shape)
+        if _FP8_DW and dy2.shape[0] >= 2048 and dy2.shape[1] % 256 == 0 and x2.shape[1] % 256 == 0:
+            dw = dq.t() @ _q8(x2, torch.float8_e4m3fn, 448.0)
+        else:
+            dw = dy2.t() @ x2
+        return dx, dw, (dy2.sum(0) if ctx.has_b else None)
 
 
 class _RoundAct(torch.autograd.Function):

@@ -148,8 +148,8 @@ def oracle_step(sd_src, batch, text_heads, lowp=False, temp=None):
             sd['temp'].fill_(temp)
     args = (sd, WL, batch['image'], batch['ids_s'], batch['mask_s'], batch['ids_t'], batch['mask_t'], batch['ids_c'],
             batch['mask_c'], batch['idx'], text_heads)
-    if lowp:        # True: bf16 storage model; 'fp8': + fp8 operands in the encoder blocks' Linears
-        with O.lowp(fp8=(lowp == 'fp8')):
+    if lowp:        # True: bf16 storage model; 'fp8': + fp8 operands in the encoder blocks' Linears ('fp8_bf16dw': weight gradients in bf16)
+        with O.lowp(fp8=(lowp in ('fp8', 'fp8_bf16dw')), fp8_dw=(lowp == 'fp8')):
             losses = O.retrieval_forward(*args)
             sum(losses).backward()
     else:
@@ -295,17 +295,20 @@ def test_config_e_geometry_vit_l14_xlmr_large_vs_oracle(dtype):
     assert not bad, (len(bad), bad[:8])
 
 
-@pytest.mark.parametrize('fuse_ln', [False, True])
-def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, monkeypatch):
+@pytest.mark.parametrize('fuse_ln,dw8', [(False, True), (True, True), (False, False)])
+def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, dw8, monkeypatch):
     """compute_dtype 'fp8' (BASELINE configs[4]: "fp8 MFMA"): the ViT-L/14 + XLM-R-large shaped model (two layers each, b = 8 so
     that every encoder Linear has >= 256 rows and takes the fp8 kernel) with e4m3 activations / weights in the forward products and
-    e5m2 gradients in the dX products.  Held against the fp32 oracle through the oracle's OWN fp8 operand model (oracle.lowp(fp8=
+    e5m2 gradients in the dX products - and (dw8, round 3) the SAME copies in the weight-gradient products dY^T X of the ViT blocks
+    (5840 token rows = 45 K-tiles of 128 on the fp8 kernel + an 80-row bf16 tail; the text layers' 256-row products stay bf16).  Held against the fp32 oracle through the oracle's OWN fp8 operand model (oracle.lowp(fp8=
     True): the same per-tensor power-of-two scaling and formats at the same Linears): losses within 3x what that model moves them,
     every parameter gradient within 3x its noise."""
     from leccr_amd import _lib, ops
     from leccr_amd.models import RetrievalModel
     from leccr_amd.synthetic import MULTI30K_CFG, make_batch
     monkeypatch.setattr(ops, 'fuse_fp8_copies', fuse_ln)      # LECCR_FP8_FUSE_LN: fp8 copies out of the LayerNorm passes (step 2 on)
+    monkeypatch.setattr(ops, 'fp8_dw', dw8)                   # LECCR_FP8_DW
+    monkeypatch.setattr(ops, 'fp8_dw_launches', 0)
     torch.manual_seed(17)
     model = RetrievalModel(dict(MULTI30K_CFG, clip_geometry=L14_GEOMETRY, text_config=dict(XLMR_LARGE_2L, vocab_size=30000),
                                 compute_dtype='fp8', clip_text_tower=False))
@@ -317,7 +320,7 @@ def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, monkeypatch):
                  mask_t=m['text'][1].attention_mask, ids_c=m['captions'].input_ids, mask_c=m['captions'].attention_mask, idx=m['idx'])
     torch.set_num_threads(16)
     ref_losses, sd = oracle_step(model.state_dict(), batch, 16)
-    noise_losses, sd_noise = oracle_step(model.state_dict(), batch, 16, lowp='fp8')
+    noise_losses, sd_noise = oracle_step(model.state_dict(), batch, 16, lowp='fp8' if dw8 else 'fp8_bf16dw')
     losses = _forward(model, batch)
     # the fp8 kernel really ran: every encoder Linear's activation site was used, and the last product of the text tower was fp8
     blk = model.clip_encoder.visual.transformer.resblocks[0]
@@ -330,6 +333,7 @@ def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, monkeypatch):
     model.arena.zero_grad()
     sum(losses).backward()
     assert all(h._gsite.primed for h in (blk.attn.in_proj_weight, blk.mlp.c_proj.weight, lay._qkv_w, lay.intermediate.dense.weight))
+    assert ops.fp8_dw_launches == (2 * 4 if dw8 else 0)       # the four Linears of both ViT blocks
     rows = grad_rows(model, sd, sd_noise)
     bad = outside_noise_model(rows)
     assert len(rows) > 150 and not bad, (len(bad), bad[:8])

@@ -975,8 +975,48 @@ def test_gemm_fp8_rejects_what_it_does_not_implement(K):
         K.gemm(a8[:, :192].contiguous(), b8[:, :192].contiguous())
     with pytest.raises(RuntimeError):                       # small N: no fp8 path below the 256-tile (callers keep those in bf16)
         K.gemm(a8, b8[:128])
-    with pytest.raises((RuntimeError, AssertionError)):     # weight-gradient layout: not an fp8 product here
+    with pytest.raises((RuntimeError, AssertionError)):     # weight-gradient layout: e5m2 gradients only, K >= 2048, whole 256-tiles
         K.gemm(a8, b8, trans_a=True, trans_b=True, out=torch.zeros(256, 256, device=DEV), accumulate=True)
+    g8 = K.Fp8Sites(DEV, 2).new(1).quantize(_rand((4096, 384), torch.bfloat16, 532).to(DEV))
+    x8 = sb.quantize(_rand((4096, 256), torch.bfloat16, 533).to(DEV))
+    with pytest.raises(RuntimeError):                       # M = 384 is not whole 256-tiles
+        K.gemm(g8, x8, trans_a=True, trans_b=True, out=torch.zeros(384, 256, device=DEV), accumulate=True)
+    with pytest.raises(RuntimeError):                       # not accumulated
+        K.gemm(g8[:, :256], x8, trans_a=True, trans_b=True, out=torch.zeros(256, 256, device=DEV))
+
+
+@pytest.mark.parametrize('Kt,M,N,alpha', [(4096, 256, 256, 1.0), (128 * 77, 768, 1024, 1.0), (65792, 1024, 1024, 0.5), (16384, 4096, 1024, 1.0),
+                                          (128 * 129, 1024, 3072, 1.0), (2048, 512, 256, 2.0)])
+def test_gemm_fp8_weight_gradient_operands(K, Kt, M, N, alpha):
+    """ab_dtype LECCR_FP8_BF8A with trans_a = trans_b = 1 (gemm256t4.hip, round 3): dW += alpha dY^T X from the e5m2 copy of dY [K, M]
+    and the e4m3 copy of X [K, N] - the row-major copies the dX and forward products of the same Linear already use - read through
+    ds_read_b64_tr_b8, split-K with f32 atomics into the accumulated C.  Exact arithmetic on the dequantised operands up to f32
+    accumulation order; strided operands (dY a column slice of a packed tensor)."""
+    from leccr_amd import _lib
+    sites = K.Fp8Sites(DEV, 4)
+    sg, sx = sites.new(1), sites.new(0)
+    dy_full = _rand((Kt, M + 256), torch.bfloat16, 540, 1e-3).to(DEV)
+    dy = dy_full[:, 128:128 + M]                            # a strided view: lda = M + 256
+    x = _rand((Kt, N), torch.bfloat16, 541).to(DEV)
+    g8_full = torch.empty(Kt, M + 256, device=DEV, dtype=torch.float8_e5m2)
+    g8 = sg.quantize(dy, out=g8_full[:, 128:128 + M])
+    x8 = sx.quantize(x)
+    base = _rand((M, N), torch.float32, 542, 1e-2)
+    out = base.clone().to(DEV)
+    K.gemm(g8, x8, trans_a=True, trans_b=True, out=out, accumulate=True, alpha=alpha, alpha_dev=(sg.inv_scale, sx.inv_scale))
+    assert _lib.lib().leccr_last_gemm_kernel() == 6
+    gd, xd = _fp8_deq(g8, sg), _fp8_deq(x8, sx)
+    ref = base.double() + alpha * (gd.t() @ xd)
+    e, s = _err(out, ref)
+    assert e <= 2e-5 * s + 1e-7, (e, s)
+    # accumulates: a second launch adds the same product again
+    K.gemm(g8, x8, trans_a=True, trans_b=True, out=out, accumulate=True, alpha=alpha, alpha_dev=(sg.inv_scale, sx.inv_scale))
+    e, s = _err(out, 2 * ref - base.double())
+    assert e <= 4e-5 * s + 1e-7, (e, s)
+    # and the quantisation is a small perturbation of the bf16 product (e5m2: 2 mantissa bits, averaged over K)
+    full = alpha * (dy.double().cpu().t() @ x.double().cpu())
+    got = (out.double().cpu() - base.double()) / 2
+    assert float((got - full).norm() / full.norm()) < 0.12
 
 
 @pytest.mark.parametrize('grad', [False, True])
