@@ -498,6 +498,8 @@ def _main(args, real_stdout):
                        'step_tflops_algorithmic': round(fpair * value / 1e3, 1) if fpair else None,
                        'losses': [round(float(l.detach()), 4) for l in losses],
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+                       'peak_hbm_reserved_gb': round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
+                       'alloc_retries': int(torch.cuda.memory_stats().get('num_alloc_retries', 0)),
                        'world': world, 'backend': backend if world > 1 else None, 'rccl_version': rccl,
                        'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'LECCR_RCCL_CUS': rccl_cus()},
             'roofline': {'bound': 'mfma', 'kernel': 'gemm256_kernel (bf16 256x256x64 MFMA GEMM: NT forward/dX + TN weight-gradient instantiations)',

@@ -11,6 +11,7 @@ Design (MI355X-first, not a translation of the reference's op-by-op eager graph)
 Every tensor op here is a launch from libleccr_hip.so (kernels.py); torch supplies allocation, views and the autograd
 graph only.
 """
+import collections
 import os
 
 import torch
@@ -66,9 +67,9 @@ def _site(w, name):
 # fp8 mode: LECCR_FP8_FUSE_LN=1 lets the LayerNorm passes write the fp8 copies of their outputs (leccr_layernorm_fwd_ex / _bwd_ex) instead
 # of separate quantise passes over h1 / h2 / x1 and the dense layers' incoming gradients.  Measured on the config-E step (ViT-L/14 +
 # XLM-R-large, batch 256): 39 ms per step less kernel time (quantise passes 294 -> 158 ms over 3 profiled steps, LayerNorm +15), wall
-# 515 -> 518 ms per step - the backward is paced by the bf16 weight-gradient stream, not by the main chain these passes sit on.  Off by
-# default until the dW product is fp8 as well; the steady-state fp8 test runs both settings.
-fuse_fp8_copies = os.environ.get('LECCR_FP8_FUSE_LN', '0') != '0'
+# 515 -> 518 ms per step while the weight-gradient products were bf16 (round 2: the backward was paced by that stream); with the fp8 dW
+# product of round 3 the same switch takes the step from 474.5 to 461.3 ms and is on by default.  The steady-state fp8 test runs both settings.
+fuse_fp8_copies = os.environ.get('LECCR_FP8_FUSE_LN', '1') != '0'
 
 
 def _q8_site(on, rows, w, which):
@@ -143,6 +144,17 @@ def g8_of(fp8, dy2, w, g8=None):
     return g8 if g8 is not None else w._gsite.quantize(dy2)
 
 
+def dw_keep(x2, x8, w):
+    """What the backward pass must keep of a Linear's input x2 for its weight-gradient product: x2 itself, or - when that product will
+    run from the fp8 copy x8 (fp8_dw, >= 2048 rows, in / out whole 256-tiles) - only the rows past the last whole 128-row K-tile, which
+    go to the bf16 kernel (an empty tensor when there are none).  The bf16 h1 / h2 / activation tensors of a block are needed for
+    nothing else, so fp8 mode holds 1 byte per element of them instead of 2 (+1)."""
+    if (fp8_dw and x8 is not None and x2.shape[0] >= 2048 and x2.shape[1] % 256 == 0 and w._q8.shape[0] % 256 == 0
+            and x8.stride(0) % 16 == 0 and x8.data_ptr() % 16 == 0):
+        return x2[x2.shape[0] // 128 * 128:].clone()
+    return x2
+
+
 def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, **kw):
     """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free).
     fp8 (compute_dtype 'fp8', the encoder blocks' Linears): x2 is quantised to e4m3 under the Linear's activation site and
@@ -186,6 +198,10 @@ fuse_bias_grad = os.environ.get('LECCR_FUSE_BIAS_GRAD', '1') != '0'      # bias 
 # The text towers (caption BERT forward, text BERT forward + backward: small-M GEMMs that leave CUs idle) run on a third stream
 # beside the image tower (150.8 -> 148.7 ms on the batch-256 step).  LECCR_TEXT_STREAM=0 keeps them on the main stream.
 text_overlap = os.environ.get('LECCR_TEXT_STREAM', '1') != '0'
+wgrad_lag = int(os.environ.get('LECCR_DW_LAG', '12'))      # host run-ahead over the weight-gradient stream, in launches (0: unbounded)
+wgrad_lag_pressure = float(os.environ.get('LECCR_DW_LAG_PRESSURE', '0.35'))  # .. applied when the backward pass starts with this share of the HBM allocated
+_wgrad_events = collections.deque()
+_wgrad_throttle = False
 _wgrad_stream = None
 _text_stream = None
 _wgrad_join_queued = False
@@ -197,6 +213,7 @@ def begin_step():
     global _wgrad_join_queued, _g8_slot
     _wgrad_join_queued = False
     _g8_slot = None
+    _wgrad_events.clear()
 
 
 def text_stream(device):
@@ -243,10 +260,13 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None):
     dy_bias: the tensor whose column sums are the bias gradient when it is not dy2 itself (an f32 head's incoming gradient,
     of which dy2 is the bf16 GEMM operand: the bias sum cancels heavily and is taken from the unrounded values).
     g8, x8 (fp8 mode): the e5m2 copy of dy2 and the e4m3 copy of x2 under w's gradient / activation sites - the product then runs on
-    the fp8 weight-gradient kernel (the bias sums still come from the bf16 dy2)."""
-    global _wgrad_stream, _wgrad_join_queued
+    the fp8 weight-gradient kernel (the bias sums still come from the bf16 dy2); x2 may then hold only the tail rows (dw_keep)."""
+    global _wgrad_stream, _wgrad_join_queued, _wgrad_throttle
     if not (fp8_dw and g8 is not None and x8 is not None and _fp8_dw_ok(g8, x8)):
         g8 = x8 = None
+        if x2.shape[0] != dy2.shape[0]:
+            raise RuntimeError('lin_dw: the forward kept only the fp8 copy of this input (dw_keep) but the fp8 weight-gradient product '
+                               'is not available for dY %s / X8 %s' % (tuple(dy2.shape), None if x8 is None else tuple(x8.shape)))
     if not (wgrad_overlap and dy2.is_cuda):
         return _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8)
     main = torch.cuda.current_stream()
@@ -261,9 +281,24 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None):
     if g8 is not None:
         g8.record_stream(side)
         x8.record_stream(side)
+    if wgrad_lag > 0 and _wgrad_throttle:
+        # the caching allocator hands a block touched by the side stream back only once that stream has passed the point of the free,
+        # and it looks at those events when the HOST allocates: a host that queues the whole backward pass ahead of the device therefore
+        # holds every block's temporaries at once (config E: 5 GB per ViT-L block, reserved memory 286 of 288 GB, allocation retries).
+        # Keeping the host at most `wgrad_lag` weight-gradient launches (3 blocks) ahead of the side stream bounds that overhang
+        # (config E: reserved 286 -> 163 GB).  Only under memory pressure (wgrad_lag_pressure): on the batch-256 ViT-B/16 step, where the
+        # overhang fits (reserved 107 of 288 GB), the host waits cost 2.4 ms of 130.6.
+        ev = torch.cuda.Event()
+        ev.record(side)
+        _wgrad_events.append(ev)
+        if len(_wgrad_events) > wgrad_lag:
+            _wgrad_events.popleft().synchronize()
     if dy_bias is not None:
         dy_bias.record_stream(side)
     if not _wgrad_join_queued:
+        # (first weight-gradient launch of a backward pass: every saved activation is still held - the moment to look at the pressure)
+        _wgrad_throttle = wgrad_lag > 0 and (torch.cuda.memory_allocated(dy2.device)
+                                             > wgrad_lag_pressure * torch.cuda.get_device_properties(dy2.device).total_memory)
         # once per backward pass: when the autograd engine has run every node, the main stream waits for the side stream,
         # so whatever follows backward() (optimizer, gradient all-reduce, a test reading .grad) sees complete gradients
         def _join():                            # (final callbacks run on the stream that called backward())
@@ -296,7 +331,9 @@ def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None):
         K.gemm(g8[:rows], x8[:rows], trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale,
                alpha_dev=(w._gsite.inv_scale, w._xsite.inv_scale))
         if rows < g8.shape[0]:
-            K.gemm(dy2[rows:], x2[rows:], trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale)
+            xt = x2[rows:] if x2.shape[0] == g8.shape[0] else x2          # full tensor, or the tail rows dw_keep kept
+            assert xt.shape[0] == g8.shape[0] - rows
+            K.gemm(dy2[rows:], xt, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale)
         fused = False
     else:
         K.gemm(dy2, x2, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale,
@@ -469,21 +506,22 @@ class ViTBlockFn(torch.autograd.Function):
                             c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True)
         act8 = x8_of(blk.fp8, act, blk.mlp.c_proj.weight, act8)
         x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
-        ctx.save_for_backward(x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act)
-        # fp8: the e4m3 copies the forward products multiplied are the weight-gradient products' X operands
-        ctx.x8 = (h1_8, o_8, h2_8, act8) if fp8_dw else (None,) * 4
+        # fp8: the e4m3 copies the forward products multiplied are the weight-gradient products' X operands, and the bf16 h1 / h2 / act
+        # are kept for nothing else (dw_keep)
+        ctx.save_for_backward(x, dw_keep(_rows(h1), h1_8, blk.attn.in_proj_weight), mean1, rstd1, qkv, o, lse, x1,
+                              dw_keep(_rows(h2), h2_8, blk.mlp.c_fc.weight), mean2, rstd2, pre, dw_keep(act, act8, blk.mlp.c_proj.weight),
+                              *((h1_8, o_8, h2_8, act8) if fp8_dw else (None,) * 4))
         ctx.blk = blk
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
-        x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act = ctx.saved_tensors
+        x, h1, mean1, rstd1, qkv, o, lse, x1, h2, mean2, rstd2, pre, act, h1_8, o_8, h2_8, act8 = ctx.saved_tensors
         blk = ctx.blk
         _fire(blk.ln_1.weight, 'on_vit_block_backward', blk)
         b, N, d = x.shape
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
-        h1_8, o_8, h2_8, act8 = ctx.x8
         g2_8 = _g8_take(g2) if blk.fp8 else None          # written by the next block's LayerNorm-1 backward (fp8 mode)
         g2_8 = g8_of(blk.fp8, g2, blk.mlp.c_proj.weight, g2_8)
         dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, g8=g2_8, epilogue=EPI_DQUICKGELU, aux=pre,
@@ -496,7 +534,7 @@ class ViTBlockFn(torch.autograd.Function):
         dh2 = lin_dx(dpre, blk.mlp.c_fc.weight, fp8=blk.fp8, g8=dpre8)
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
-        lin_dw(dpre, _rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, g8=dpre8, x8=h2_8)
+        lin_dw(dpre, h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, g8=dpre8, x8=h2_8)
         dx1, _, g1_8 = _ln_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g, blk.ln_2.bias._g,
                                site=_q8_site(blk.fp8, b * N, blk.attn.out_proj.weight, '_gsite'), dres=dx2)
         g1 = _rows(dx1)
@@ -508,7 +546,7 @@ class ViTBlockFn(torch.autograd.Function):
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
         dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight)
         dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)
-        lin_dw(_rows(dqkv), _rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
+        lin_dw(_rows(dqkv), h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
         # (fp8: dx is the gradient the previous block's c_proj dX product consumes: its e5m2 copy goes with it)
         prev = getattr(blk, '_dx_consumer', (None,))[0]
         dx, _, dx_8 = _ln_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g, blk.ln_1.bias._g,
@@ -618,18 +656,19 @@ class BertLayerFn(torch.autograd.Function):
         else:
             s2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8, residual=_rows(x1)).view(b, L, d)
             x2, mean2, rstd2, _ = K.layernorm_fwd(s2, out.LayerNorm.weight.data, out.LayerNorm.bias.data, layer.eps)
-        ctx.save_for_backward(x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2)
+        ctx.save_for_backward(dw_keep(_rows(x), x_8, layer._qkv_w), kmask, qkv, o, lse, s1, mean1, rstd1,
+                              dw_keep(_rows(x1), x1_8, layer.intermediate.dense.weight), pre, dw_keep(h, h8, out.dense.weight), s2, mean2, rstd2,
+                              *((x_8, o_8, x1_8, h8) if fp8_dw else (None,) * 4))          # fp8: the weight-gradient products' X operands
         ctx.layer, ctx.drop = layer, (ph, pa, seeds)
-        ctx.x8 = (x_8, o_8, x1_8, h8) if fp8_dw else (None,) * 4          # fp8: the weight-gradient products' X operands
         return x2
 
     @staticmethod
     def backward(ctx, dx2):
-        x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2 = ctx.saved_tensors
+        x, kmask, qkv, o, lse, s1, mean1, rstd1, x1, pre, h, s2, mean2, rstd2, x_8, o_8, x1_8, h8 = ctx.saved_tensors
         layer = ctx.layer
         ph, pa, seeds = ctx.drop
         ao, out = layer.attention.output, layer.output
-        b, L, d = x.shape
+        b, L, d = s1.shape
         # gradient of the sum: the residual path takes it as is (g2), the dense path through the dropout mask (gd2) - both
         # written by the LayerNorm backward pass
         # written by the LayerNorm backward pass (fp8: with gd2's e5m2 copy)
@@ -637,14 +676,13 @@ class BertLayerFn(torch.autograd.Function):
                                  out.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, out.dense.weight, '_gsite'),
                                  drop=(ph, seeds[2]) if ph > 0 else None)
         g2, gd2 = _rows(g2), _rows(gd2)
-        x_8, o_8, x1_8, h8 = ctx.x8
         gd2_8 = g8_of(layer.fp8, gd2, out.dense.weight, gd2_8)
         dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, g8=gd2_8, epilogue=EPI_DGELU, aux=pre,
                              c8_site=_site(layer.intermediate.dense.weight, '_gsite'), want8=True)
         lin_dw(gd2, h, out.dense.weight, out.dense.bias, g8=gd2_8, x8=h8)
         dpre8 = g8_of(layer.fp8, dpre, layer.intermediate.dense.weight, dpre8)
         dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
-        lin_dw(dpre, _rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, g8=dpre8, x8=x1_8)
+        lin_dw(dpre, x1, layer.intermediate.dense.weight, layer.intermediate.dense.bias, g8=dpre8, x8=x1_8)
         g1, gd1, gd1_8 = _ln_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                                  ao.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, ao.dense.weight, '_gsite'),
                                  drop=(ph, seeds[1]) if ph > 0 else None)
@@ -657,7 +695,7 @@ class BertLayerFn(torch.autograd.Function):
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], drop_p=pa, seed=seeds[0])
         dqkv8 = g8_of(layer.fp8, _rows(dqkv), layer._qkv_w)
         dx = lin_dx(_rows(dqkv), layer._qkv_w, fp8=layer.fp8, g8=dqkv8, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
-        lin_dw(_rows(dqkv), _rows(x), layer._qkv_w, layer._qkv_b, g8=dqkv8, x8=x_8)
+        lin_dw(_rows(dqkv), x, layer._qkv_w, layer._qkv_b, g8=dqkv8, x8=x_8)
         for p in (out.LayerNorm.weight, out.LayerNorm.bias, ao.LayerNorm.weight, ao.LayerNorm.bias):
             _mark(p)
         return (dx, None, None) + (None,) * len(ctx.needs_input_grad[3:])
