@@ -319,6 +319,11 @@ int leccr_fp8_amax(const void* x, int64_t rows, int64_t cols, int64_t ldx, int d
 int leccr_fp8_update(float* sites, int64_t n, void* stream);
 int leccr_fp8_quantize(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, int dtype, int fmt,
                        float* site, void* stream);
+/* Weights (current scaling, once per optimizer step): every Linear's bf16 compute copy [R, C] -> its e4m3 copies in both layouts
+ * ([R, C] for the forward product, [C, R] for dX) under a scale taken from the weight itself, for ALL weights in three launches.
+ * table: n rows of 7 int64 in device memory {first tile (cumulative count of 64 x 64 tiles), bf16 source, e4m3 [R, C], e4m3 [C, R], R, C,
+ * site pointer}; R, C multiples of 64, contiguous tensors, site.amax == 0 on entry (as fp8_update leaves it) and on return. */
+int leccr_fp8_requantize_weights(const int64_t* table, int64_t n, int64_t total_tiles, void* stream);
 
 #ifdef __cplusplus
 }

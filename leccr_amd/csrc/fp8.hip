@@ -106,10 +106,98 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const T* __restrict__
     block_amax(m, site);
 }
 
+// ---- weights: one batched requantisation per optimizer step (current scaling) ----------------------------------------------------
+// table[i] = {first tile, bf16 source [R, C], e4m3 copy [R, C], e4m3 copy [C, R], R, C, site}: 64 x 64 tiles, one workgroup each.
+// Three launches for ALL weights (config E: 192 Linears were 768 launches of 18-58 us, 48 ms of kernel time per step):
+// amax per tile -> site.amax; scale from it (site.amax back to 0); both layouts written from one read of the tile.
+constexpr int WT = 64, WTAB = 7;
+
+__device__ __forceinline__ const int64_t* weight_entry(const int64_t* __restrict__ table, int n) {
+    int lo = 0, hi = n - 1;                                  // last weight whose first tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * WTAB] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    return table + lo * WTAB;
+}
+
+// thread -> row (tid >> 3) and (tid >> 3) + 32 of the tile, 8 columns at 8 (tid & 7)
+template <int STAGE>
+__global__ __launch_bounds__(256) void fp8_weights_kernel(const int64_t* __restrict__ table, int n) {
+    const int64_t* e = weight_entry(table, n);
+    const bf16_t* src = reinterpret_cast<const bf16_t*>(e[1]);
+    const int R = (int)e[4], C = (int)e[5];
+    float* site = reinterpret_cast<float*>(e[6]);
+    const int t = (int)(blockIdx.x - e[0]), tiles_x = C / WT;
+    const int r0 = (t / tiles_x) * WT, c0 = (t % tiles_x) * WT;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+    bf16x8 v[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) v[h] = *reinterpret_cast<const bf16x8*>(src + (int64_t)(r0 + tr + 32 * h) * C + c0 + tc);
+    if constexpr (STAGE == 0) {
+        float m = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m = fmaxf(m, fabsf((float)v[h][i]));
+        block_amax(m, site);
+    } else {
+        __shared__ uint8_t tile[WT][WT + 8];                  // [row][column] bytes; 72-byte rows: the column reads below spread over banks
+        uint8_t* q8 = reinterpret_cast<uint8_t*>(e[2]);
+        uint8_t* q8t = reinterpret_cast<uint8_t*>(e[3]);
+        const float sc = site[1];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float q[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) q[i] = fminf(fmaxf((float)v[h][i] * sc, -448.f), 448.f);
+            int w[2] = {0, 0};
+            w[0] = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w[0], false);
+            w[0] = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w[0], true);
+            w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w[1], false);
+            w[1] = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w[1], true);
+            const int r = tr + 32 * h;
+            *reinterpret_cast<int2*>(q8 + (int64_t)(r0 + r) * C + c0 + tc) = int2{w[0], w[1]};
+            *reinterpret_cast<int2*>(&tile[r][tc]) = int2{w[0], w[1]};
+        }
+        __syncthreads();
+        // transposed copy: thread -> column c = tid >> 2 of the tile (a row of q8t), 16 consecutive r at 16 (tid & 3)
+        const int c = threadIdx.x >> 2, rb = (threadIdx.x & 3) * 16;
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = (uint32_t)tile[rb + 4 * j][c] | ((uint32_t)tile[rb + 4 * j + 1][c] << 8) | ((uint32_t)tile[rb + 4 * j + 2][c] << 16) |
+                   ((uint32_t)tile[rb + 4 * j + 3][c] << 24);
+        *reinterpret_cast<uint4*>(q8t + (int64_t)(c0 + c) * R + r0 + rb) = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+__global__ void fp8_update_table_kernel(const int64_t* __restrict__ table, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* s = reinterpret_cast<float*>(table[i * WTAB + 6]);
+    const float amax = s[0];
+    if (amax > 0.f && isfinite(amax)) {
+        const float sc = exp2f(fminf(floorf(log2f(448.f) - log2f(amax)), 100.f));      // as fp8_update_kernel, e4m3
+        s[1] = sc;
+        s[2] = 1.f / sc;
+    }
+    s[0] = 0.f;
+}
+
 }  // namespace
 }  // namespace leccr
 
 using namespace leccr;
+
+extern "C" int leccr_fp8_requantize_weights(const int64_t* table, int64_t n, int64_t total_tiles, void* stream) {
+    LECCR_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31) && n < (1ll << 24), LECCR_EINVAL, "fp8_requantize_weights: bad argument");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(fp8_weights_kernel<0>, dim3((unsigned)total_tiles), dim3(256), 0, st, table, (int)n);
+    hipLaunchKernelGGL(fp8_update_table_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, table, (int)n);
+    hipLaunchKernelGGL(fp8_weights_kernel<1>, dim3((unsigned)total_tiles), dim3(256), 0, st, table, (int)n);
+    return check_launch("fp8_requantize_weights");
+}
 
 static unsigned rows_grid(int64_t rows) { return (unsigned)(rows < 4096 ? (rows < 1 ? 1 : rows) : 4096); }
 // contiguous rows (ld == cols): the tensor is re-cut into pseudo-rows of 2048 elements so that every thread of a block has one

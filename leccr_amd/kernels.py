@@ -405,6 +405,25 @@ def transpose_cast_batched(table, total_tiles):
           'leccr_transpose_cast_batched')
 
 
+def fp8_requantize_weights(holders):
+    """All fp8 weight copies in three launches (leccr_fp8_requantize_weights): holders carry _lp (bf16 [R, C]), _q8 ([R, C]), _q8t ([C, R])
+    and _wsite.  Returns a closure that re-runs the batch (the table lives on the device, built once)."""
+    rows, tiles = [], 0
+    for h in holders:
+        R, Cn = h._lp.shape
+        assert h._lp.is_contiguous() and h._q8.is_contiguous() and h._q8t.is_contiguous() and R % 64 == 0 and Cn % 64 == 0
+        assert h._q8.shape == (R, Cn) and h._q8t.shape == (Cn, R)
+        rows.append([tiles, h._lp.data_ptr(), h._q8.data_ptr(), h._q8t.data_ptr(), R, Cn, h._wsite.row.data_ptr()])
+        tiles += (R // 64) * (Cn // 64)
+    table = torch.tensor(rows, dtype=torch.int64, device=holders[0]._lp.device)
+
+    def run():
+        check(lib().leccr_fp8_requantize_weights(ptr(table), table.shape[0], tiles, stream()), 'leccr_fp8_requantize_weights')
+        for h in holders:
+            h._wsite.primed = True
+    return run
+
+
 def axpy(x, y, a):
     assert x.dtype == y.dtype and x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     check(lib().leccr_axpy(ptr(x), ptr(y), float(a), x.numel(), dtype_code(x), stream()), 'leccr_axpy')

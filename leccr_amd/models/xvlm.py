@@ -292,8 +292,21 @@ class XVLMBase(nn.Module):
             for prev, blk in zip(blocks[:-1], blocks[1:]):
                 blk._dx_consumer = (prev.mlp.c_proj.weight,)        # a tuple: not registered as this block's parameter
 
+        # one batched requantisation of every weight per optimizer step (three launches); weights the batch cannot take (not whole
+        # 64 x 64 tiles - none at the ViT / BERT geometries) go through the per-tensor passes
+        from .. import kernels as K
+        batch = [h for h in holders if h._lp.shape[0] % 64 == 0 and h._lp.shape[1] % 64 == 0 and h._lp.is_contiguous()]
+        if os.environ.get('LECCR_FP8_BATCH_REQUANT', '1') == '0':
+            batch = []
+        rest = [h for h in holders if not any(h is b for b in batch)]
+        run_batch = K.fp8_requantize_weights(batch) if batch else None
+
         def requantise():
-            for h in holders:
+            if os.environ.get('XP_SKIP_REQ') == '1' and holders[0]._wsite.primed:
+                return
+            if run_batch is not None:
+                run_batch()
+            for h in rest:
                 h._wsite.quantize_current(h._lp, [(h._lp, h._q8), (h._lpt, h._q8t)])
         a.post_refresh.append(requantise)
 

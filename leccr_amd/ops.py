@@ -341,6 +341,8 @@ def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None):
     _mark(w)
     if b is not None and fused:
         _mark(b)
+    elif b is not None and os.environ.get('XP_SKIP_COLSUM') == '1' and g8 is not None:
+        pass
     elif b is not None:
         src = dy2 if dy_bias is None else dy_bias
         if scale == 1.0:

@@ -966,6 +966,39 @@ def test_gemm_fp8_gradient_operands(K, M, N, K_, case):
     assert e <= 1.2e-2 * s, (case, e, s)
 
 
+def test_fp8_batched_weight_requantisation_matches_the_per_tensor_passes(K):
+    """leccr_fp8_requantize_weights: every weight's e4m3 copies in both layouts ([out, in] and [in, out]) and its scale, for all weights
+    in three launches - the bytes and the scales the per-tensor sequence (amax, update, two quantise passes) writes; run twice with a
+    weight grown in between (current scaling: the second scale follows the new amax, no memory of the first)."""
+    class H:
+        pass
+    shapes = [(768, 768), (2304, 768), (3072, 1024), (1024, 4096), (64, 128), (192, 64)]
+    sites_a, sites_b = K.Fp8Sites(DEV, 8), K.Fp8Sites(DEV, 8)
+    hs = []
+    for i, (R, Cn) in enumerate(shapes):
+        h = H()
+        h._lp = _rand((R, Cn), torch.bfloat16, 600 + i, 0.02 * (i + 1)).to(DEV)
+        h._lpt = h._lp.t().contiguous()
+        h._q8, h._q8t = torch.zeros(R, Cn, device=DEV, dtype=torch.float8_e4m3fn), torch.zeros(Cn, R, device=DEV, dtype=torch.float8_e4m3fn)
+        h._wsite, h.ref_site = sites_a.new(0), sites_b.new(0)
+        hs.append(h)
+    run = K.fp8_requantize_weights(hs)
+    for rnd in range(2):
+        if rnd == 1:
+            hs[1]._lp.mul_(5.0); hs[1]._lpt.mul_(5.0)          # crosses two powers of two
+            hs[3]._lp.mul_(0.25); hs[3]._lpt.mul_(0.25)
+        run()
+        for h in hs:
+            r8, r8t = torch.empty_like(h._q8), torch.empty_like(h._q8t)
+            h.ref_site.row[0] = 0.0                             # current scaling: no memory of the previous round's amax
+            h.ref_site.quantize_current(h._lp, [(h._lp, r8), (h._lpt, r8t)])
+            assert float(h._wsite.row[1]) == float(h.ref_site.row[1]) and float(h._wsite.row[2]) == float(h.ref_site.row[2]), (rnd, h._lp.shape)
+            assert float(h._wsite.row[0]) == 0.0 and h._wsite.primed
+            assert torch.equal(h._q8.view(torch.uint8), r8.view(torch.uint8)), (rnd, h._lp.shape)
+            assert torch.equal(h._q8t.view(torch.uint8), r8t.view(torch.uint8)), (rnd, h._lp.shape)
+            assert torch.equal(h._q8t.view(torch.uint8), h._q8.view(torch.uint8).t())
+
+
 def test_gemm_fp8_rejects_what_it_does_not_implement(K):
     sites = K.Fp8Sites(DEV, 4)
     sa, sb = sites.new(0), sites.new(0)
