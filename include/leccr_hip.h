@@ -116,7 +116,11 @@ typedef struct leccr_gemm_params {
     void* c8;                    /* optional fp8 copy of the C written, for the NEXT product that consumes it (fp8 operand kernels
                                     with an activation / d-activation epilogue only): c8[m,n] = fp8(clamp(C[m,n] * c8_site.scale)),
                                     row stride ldc8 bytes, format c8_fmt (0 e4m3, 1 e5m2); c8_site.amax accumulates max |C| - the
-                                    same contract as leccr_fp8_quantize, without its pass over C */
+                                    same contract as leccr_fp8_quantize, without its pass over C.  With c8, C itself may be NULL: a
+                                    consumer chain that is fp8 end to end reads only the copy, and the bf16 C stays unwritten (2 of the
+                                    epilogue's 5 bytes per element).  With c8 on the dX form (LECCR_FP8_BF8A, derivative epilogue),
+                                    `colsum` is fused: colsum[n] += sum_m of the f32 epilogue values (the bias gradient of the Linear
+                                    that produced the pre-activation), so nothing needs the bf16 C */
     int64_t ldc8;
     float* c8_site;
     int32_t c8_fmt;
@@ -192,6 +196,18 @@ int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, int64_t b, int64_t heads,
                    int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                    int dtype, float drop_p, uint64_t seed, void* stream);
+/* _q8 (compute_dtype 'fp8'): the same calls plus per-tensor scaled fp8 copies of the outputs for the scaled-MFMA products that consume
+ * them, under `site` = {amax, scale, 1/scale, fmt} with the contract of leccr_fp8_quantize (quantised from the f32 values, site.amax
+ * accumulates max |value|): o8 [b*Lq, heads*hd] e4m3 (the out_proj input), dq8 / dk8 / dv8 e5m2 under ONE site (the three column
+ * blocks of the packed in_proj gradient; row stride ld8 bytes).  Written by the attention kernels' own epilogues where the variant that
+ * runs has them (MFMA head-64 kernels: the 32-query forward kernels, every backward), by quantise passes otherwise. */
+int leccr_attn_fwd_q8(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, int64_t b,
+                      int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                      int dtype, float drop_p, uint64_t seed, void* o8, int64_t ldo8, float* site, void* stream);
+int leccr_attn_bwd_q8(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                      const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, int64_t b, int64_t heads,
+                      int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                      int dtype, float drop_p, uint64_t seed, void* dq8, void* dk8, void* dv8, int64_t ld8, float* site, void* stream);
 
 /* ---- ViT input stage --------------------------------------------------------------------------------------
  * patchify: image [b,3,R,R] f32 NCHW -> patches [b*g*g, Kp] (T), g = floor(R/p) (the R % p edge pixels are dropped, as

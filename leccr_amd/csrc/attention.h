@@ -18,12 +18,21 @@ int attn_generic_bwd(const void* q, const void* k, const void* v, const void* o,
                      const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D,
                      hipStream_t st);
 
+// optional fp8 copies of the outputs (leccr_attn_fwd_q8 / leccr_attn_bwd_q8): forward o8 (e4m3), backward dq8 / dk8 / dv8 (e5m2), row
+// stride ld8 bytes, under `site`.  *fused is set when the kernel that ran wrote them itself; otherwise the caller runs quantise passes.
+struct AttnQ8 {
+    void *o8 = nullptr, *dq8 = nullptr, *dk8 = nullptr, *dv8 = nullptr;
+    int64_t ld8 = 0;
+    float* site = nullptr;
+};
+
 // bf16, head size 64, MFMA flash kernels (attention_mfma.hip)
 bool attn_mfma_supported(const AttnDims& D, int dtype);
 int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
-                  const AttnDims& D, hipStream_t st);
+                  const AttnDims& D, hipStream_t st, const AttnQ8* q8 = nullptr, bool* fused = nullptr);
 int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                  const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st);
+                  const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st,
+                  const AttnQ8* q8 = nullptr, bool* fused = nullptr);
 
 extern bool g_force_generic_attn;
 int attn_set_variant(int v);      // 0 = default (environment), 16 / 32 = queries per wave of the MFMA forward kernel; returns the one in effect

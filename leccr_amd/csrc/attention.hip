@@ -17,9 +17,9 @@ static int check_dims(const char* what, const AttnDims& D, int dtype) {
 
 using namespace leccr;
 
-extern "C" int leccr_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
-                              int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
-                              int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream) {
+static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+                         int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
+                         int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream, const AttnQ8* q8, bool* fused) {
     LECCR_REQUIRE(q && k && v && o && lse, LECCR_EINVAL, "attn_fwd: null pointer");
     LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_fwd: drop_p must be in [0,1)");
     LECCR_REQUIRE(b * heads * Lq * Lk < (1ll << 32) || drop_p == 0.f, LECCR_EINVAL, "attn_fwd: dropout index space exceeds 2^32");
@@ -28,17 +28,38 @@ extern "C" int leccr_attn_fwd(const void* q, const void* k, const void* v, void*
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * (double)b * heads * Lq * Lk * hd, st);
-    if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) return attn_mfma_fwd(q, k, v, o, lse, kmask, D, st);
+    if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) return attn_mfma_fwd(q, k, v, o, lse, kmask, D, st, q8, fused);
     return dtype == LECCR_F32 ? attn_generic_fwd<float>(q, k, v, o, lse, kmask, D, st)
                               : attn_generic_fwd<bf16_t>(q, k, v, o, lse, kmask, D, st);
 }
 
-extern "C" int leccr_set_attn_variant(int v) { return attn_set_variant(v); }
-
-extern "C" int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
-                              const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
+extern "C" int leccr_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                               int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
                               int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream) {
+    return attn_fwd_impl(q, k, v, o, lse, kmask, b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, dtype, drop_p, seed, stream, nullptr, nullptr);
+}
+
+// .. and the e4m3 copy of o for the product that consumes it (out_proj in fp8 mode): written by the attention kernel where the variant
+// that runs has the epilogue (the long unmasked sequences of the ViT), by a leccr_fp8_quantize pass over o otherwise - same bytes contract
+extern "C" int leccr_attn_fwd_q8(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+                                 int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
+                                 int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* o8, int64_t ldo8, float* site,
+                                 void* stream) {
+    LECCR_REQUIRE(o8 && site && ldo8 >= heads * hd && dtype == LECCR_BF16, LECCR_EINVAL, "attn_fwd_q8: needs o8, its site, ldo8 >= heads * hd, bf16");
+    AttnQ8 q8;
+    q8.o8 = o8; q8.ld8 = ldo8; q8.site = site;
+    bool fused = false;
+    int rc = attn_fwd_impl(q, k, v, o, lse, kmask, b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, dtype, drop_p, seed, stream, &q8, &fused);
+    if (rc == LECCR_OK && !fused && b * Lq > 0) rc = leccr_fp8_quantize(o, o8, b * Lq, heads * hd, ldo, ldo8, dtype, 0, site, stream);
+    return rc;
+}
+
+extern "C" int leccr_set_attn_variant(int v) { return attn_set_variant(v); }
+
+static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                         const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
+                         int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
+                         int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream, const AttnQ8* q8, bool* fused) {
     LECCR_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && delta, LECCR_EINVAL, "attn_bwd: null pointer");
     LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_bwd: drop_p must be in [0,1)");
     const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
@@ -47,7 +68,37 @@ extern "C" int leccr_attn_bwd(const void* q, const void* k, const void* v, const
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_BWD, 10.0 * (double)b * heads * Lq * Lk * hd, st);
     if (!g_force_generic_attn && attn_mfma_supported(D, dtype))
-        return attn_mfma_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
+        return attn_mfma_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st, q8, fused);
     return dtype == LECCR_F32 ? attn_generic_bwd<float>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st)
                               : attn_generic_bwd<bf16_t>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
+}
+
+extern "C" int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                              const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
+                              int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
+                              int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream) {
+    return attn_bwd_impl(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, dtype, drop_p, seed,
+                         stream, nullptr, nullptr);
+}
+
+// .. and the e5m2 copies of dq / dk / dv (row stride ld8: the three column blocks of one packed [rows, 3 d] gradient, or separate
+// tensors) under ONE site, for the in_proj dX and weight-gradient products in fp8 mode
+extern "C" int leccr_attn_bwd_q8(const void* q, const void* k, const void* v, const void* o, const void* dout,
+                                 const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
+                                 int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
+                                 int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* dq8, void* dk8, void* dv8,
+                                 int64_t ld8, float* site, void* stream) {
+    LECCR_REQUIRE(dq8 && dk8 && dv8 && site && ld8 >= heads * hd && dtype == LECCR_BF16, LECCR_EINVAL,
+                  "attn_bwd_q8: needs dq8 / dk8 / dv8, their site, ld8 >= heads * hd, bf16");
+    AttnQ8 q8;
+    q8.dq8 = dq8; q8.dk8 = dk8; q8.dv8 = dv8; q8.ld8 = ld8; q8.site = site;
+    bool fused = false;
+    int rc = attn_bwd_impl(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, dtype, drop_p, seed,
+                           stream, &q8, &fused);
+    if (rc == LECCR_OK && !fused) {
+        if (b * Lq > 0) rc = leccr_fp8_quantize(dq, dq8, b * Lq, heads * hd, ldq, ld8, dtype, 1, site, stream);
+        if (rc == LECCR_OK && b * Lk > 0) rc = leccr_fp8_quantize(dk, dk8, b * Lk, heads * hd, ldk, ld8, dtype, 1, site, stream);
+        if (rc == LECCR_OK && b * Lk > 0) rc = leccr_fp8_quantize(dv, dv8, b * Lk, heads * hd, ldv, ld8, dtype, 1, site, stream);
+    }
+    return rc;
 }

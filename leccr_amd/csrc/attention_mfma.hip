@@ -42,7 +42,35 @@ struct FP {
     float scale;
     DropCfg drop;
     int xcd;             // 1: XCD-aware block order (xcd_block)
+    // optional fp8 copies of the outputs for the scaled-MFMA products that consume them (compute_dtype 'fp8'): out8 (e4m3, the out_proj
+    // input) / dq8, dk8, dv8 (e5m2, the in_proj gradient), row stride ld8 bytes, quantised from the f32 values under site8 =
+    // {amax, scale, 1/scale, fmt} with site8.amax accumulating max |value| - the contract of leccr_fp8_quantize without its pass
+    uint8_t *out8, *dq8, *dk8, *dv8;
+    int64_t ld8;
+    float* site8;
 };
+
+// 4 f32 -> 4 fp8 bytes under scale sc (BF8: e5m2, else e4m3), amax tracking
+template <bool BF8>
+__device__ __forceinline__ uint32_t q8_pack4(const f32x4& v, float sc, float& amax) {
+    constexpr float FMAX = BF8 ? 57344.f : 448.f;
+    float q[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        amax = fmaxf(amax, fabsf(v[e]));
+        q[e] = fminf(fmaxf(v[e] * sc, -FMAX), FMAX);
+    }
+    int w = 0;
+    if constexpr (BF8) { w = __builtin_amdgcn_cvt_pk_bf8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_bf8_f32(q[2], q[3], w, true); }
+    else { w = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w, false); w = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w, true); }
+    return (uint32_t)w;
+}
+// one conditional atomic per wave (fp8.hip: block_amax)
+__device__ __forceinline__ void q8_wave_amax(float m, float* site) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(site)) atomicMax(reinterpret_cast<unsigned int*>(site), __float_as_uint(m));
+}
 
 // Workgroups are dealt to the 8 XCDs round-robin (block id % 8), each XCD with its own 4 MiB L2.  The blocks of one (batch, head)
 // - 5 query blocks that each stream the head's whole K / V in the forward, 5 key blocks that each stream its Q / dO in dK/dV -
@@ -824,21 +852,33 @@ __global__ __launch_bounds__(NW * 64, WPS) void flash_fwd32_kernel(FP p) {
     const int64_t qi = q0 + r;
     const float inv = l > 0.f ? 1.f / l : 0.f;
     bf16_t* op = p.out + (b * p.Lq + (qi < p.Lq ? qi : p.Lq - 1)) * p.ldo + head * HD;
+    const bool q8 = p.out8 != nullptr;                      // uniform
+    uint8_t* op8 = p.out8 + (b * p.Lq + (qi < p.Lq ? qi : p.Lq - 1)) * p.ld8 + head * HD;
+    const float sc8 = q8 ? p.site8[1] : 1.f;
+    float amax8 = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
             bf16x8 w;
+            f32x4 lo, hi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a0 = o[dt][8 * gg + e] * inv, a1 = o[dt][8 * gg + 4 + e] * inv;
                 auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
-                w[e] = (bf16_t)__uint_as_float(sw[0]);
-                w[4 + e] = (bf16_t)__uint_as_float(sw[1]);
+                lo[e] = __uint_as_float(sw[0]);
+                hi[e] = __uint_as_float(sw[1]);
+                w[e] = (bf16_t)lo[e];
+                w[4 + e] = (bf16_t)hi[e];
             }
             if (qi < p.Lq) *reinterpret_cast<bf16x8*>(op + 32 * dt + 16 * gg + 8 * h) = w;
+            if (q8 && qi < p.Lq) {
+                const uint32_t w0 = q8_pack4<false>(lo, sc8, amax8), w1 = q8_pack4<false>(hi, sc8, amax8);
+                *reinterpret_cast<uint2*>(op8 + 32 * dt + 16 * gg + 8 * h) = uint2{w0, w1};
+            }
         }
     if (qi < p.Lq && h == 0) p.lse[(b * p.heads + head) * p.Lq + qi] = l > 0.f ? (m * c + __log2f(l)) * kLn2 : INFINITY;
+    if (q8) q8_wave_amax(amax8, p.site8);
 }
 
 // --------------------------------------------------------------------------------------------------- forward, software-pipelined
@@ -1204,21 +1244,33 @@ __global__ __launch_bounds__(NW * 64, 2) void flash_fwd32p_kernel(FP p) {
     const int64_t qi = q0 + r;
     const float inv = l > 0.f ? 1.f / l : 0.f;
     bf16_t* op = p.out + (b * p.Lq + (qi < p.Lq ? qi : p.Lq - 1)) * p.ldo + head * HD;
+    const bool q8 = p.out8 != nullptr;                      // uniform
+    uint8_t* op8 = p.out8 + (b * p.Lq + (qi < p.Lq ? qi : p.Lq - 1)) * p.ld8 + head * HD;
+    const float sc8 = q8 ? p.site8[1] : 1.f;
+    float amax8 = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
             bf16x8 w;
+            f32x4 lo, hi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float a0 = o[dt][8 * gg + e] * inv, a1 = o[dt][8 * gg + 4 + e] * inv;
                 auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
-                w[e] = (bf16_t)__uint_as_float(sw[0]);
-                w[4 + e] = (bf16_t)__uint_as_float(sw[1]);
+                lo[e] = __uint_as_float(sw[0]);
+                hi[e] = __uint_as_float(sw[1]);
+                w[e] = (bf16_t)lo[e];
+                w[4 + e] = (bf16_t)hi[e];
             }
             if (qi < p.Lq) *reinterpret_cast<bf16x8*>(op + 32 * dt + 16 * gg + 8 * h) = w;
+            if (q8 && qi < p.Lq) {
+                const uint32_t w0 = q8_pack4<false>(lo, sc8, amax8), w1 = q8_pack4<false>(hi, sc8, amax8);
+                *reinterpret_cast<uint2*>(op8 + 32 * dt + 16 * gg + 8 * h) = uint2{w0, w1};
+            }
         }
     if (qi < p.Lq && h == 0) p.lse[(b * p.heads + head) * p.Lq + qi] = l > 0.f ? (m * c + __log2f(l)) * kLn2 : INFINITY;
+    if (q8) q8_wave_amax(amax8, p.site8);
 }
 
 // --------------------------------------------------------------------------------------------------- backward
@@ -1492,6 +1544,9 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
             }
         }
     }
+    const bool q8 = p.dk8 != nullptr;                       // uniform
+    const float sc8 = q8 ? p.site8[1] : 1.f;
+    float amax8 = 0.f;
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
         if (key[g] < p.Lk) {
@@ -1502,8 +1557,18 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
                 store4(dkp + nd * 16 + 4 * h4, dk[g][nd] * p.scale);
                 store4(dvp + nd * 16 + 4 * h4, dv[g][nd]);
             }
+            if (q8) {
+                uint8_t* dk8 = p.dk8 + (b * p.Lk + key[g]) * p.ld8 + head * HD;
+                uint8_t* dv8 = p.dv8 + (b * p.Lk + key[g]) * p.ld8 + head * HD;
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) {
+                    *reinterpret_cast<uint32_t*>(dk8 + nd * 16 + 4 * h4) = q8_pack4<true>(dk[g][nd] * p.scale, sc8, amax8);
+                    *reinterpret_cast<uint32_t*>(dv8 + nd * 16 + 4 * h4) = q8_pack4<true>(dv[g][nd], sc8, amax8);
+                }
+            }
         }
     }
+    if (q8) q8_wave_amax(amax8, p.site8);
 }
 
 // ---- dQ.  Block = NW waves x KG x 16 queries; sweeps 64-key tiles.  LDS per stage: K tile | V tile.
@@ -1708,14 +1773,23 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
             }
         }
     }
+    const bool q8 = p.dq8 != nullptr;                       // uniform
+    const float sc8 = q8 ? p.site8[1] : 1.f;
+    float amax8 = 0.f;
 #pragma unroll
     for (int g = 0; g < KG; ++g) {
         if (qi[g] < p.Lq) {
             bf16_t* dqp = p.dq + (b * p.Lq + qi[g]) * p.ldq + head * HD;
 #pragma unroll
             for (int nd = 0; nd < 4; ++nd) store4(dqp + nd * 16 + 4 * h4, dq[g][nd] * p.scale);
+            if (q8) {
+                uint8_t* dq8 = p.dq8 + (b * p.Lq + qi[g]) * p.ld8 + head * HD;
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) *reinterpret_cast<uint32_t*>(dq8 + nd * 16 + 4 * h4) = q8_pack4<true>(dq[g][nd] * p.scale, sc8, amax8);
+            }
         }
     }
+    if (q8) q8_wave_amax(amax8, p.site8);
 }
 
 template <typename KFn>
@@ -1750,7 +1824,7 @@ bool attn_mfma_supported(const AttnDims& D, int dtype) {
 }
 
 int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
-                  const AttnDims& D, hipStream_t st) {
+                  const AttnDims& D, hipStream_t st, const AttnQ8* q8, bool* fused) {
     if (!(al16(q) && al16(k) && al16(v) && al16(o))) {
         set_error("attn_fwd(mfma): q/k/v/o must be 16-byte aligned");
         return LECCR_EALIGN;
@@ -1761,6 +1835,10 @@ int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* l
     p.ldo = D.ldo; p.scale = 1.f / sqrtf((float)HD); p.drop = D.drop;
     p.xcd = attn_xcd_aware();
     if (attn_fwd_variant() == 32) {
+        if (q8 && q8->o8 && (q8->ld8 & 7) == 0 && ((uintptr_t)q8->o8 & 7) == 0) {      // the 32-query kernels write the fp8 copy themselves
+            p.out8 = (uint8_t*)q8->o8; p.ld8 = q8->ld8; p.site8 = q8->site;
+            if (fused) *fused = true;
+        }
         // 32-query waves (v_mfma_f32_32x32x16_bf16): 4 waves = 128 queries per block; short query sets take fewer waves per block
         // so that a block does not carry waves without rows (BERT: L = 32 / 64; the caption-query side of the interaction: 4)
 #define LAUNCH_F32(NW)                                                                                                   \
@@ -1799,7 +1877,8 @@ int attn_mfma_fwd(const void* q, const void* k, const void* v, void* o, float* l
 }
 
 int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
-                  const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st) {
+                  const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st,
+                  const AttnQ8* q8, bool* fused) {
     if (!(al16(q) && al16(k) && al16(v) && al16(o) && al16(dout) && al16(dq) && al16(dk) && al16(dv))) {
         set_error("attn_bwd(mfma): tensors must be 16-byte aligned");
         return LECCR_EALIGN;
@@ -1812,6 +1891,10 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
     p.Lqp = cdiv(D.Lq, BT) * BT;
     p.xcd = attn_xcd_aware();
     p.nbh = D.b * D.heads;
+    if (q8 && q8->dq8 && q8->dk8 && q8->dv8 && (q8->ld8 & 3) == 0 && (((uintptr_t)q8->dq8 | (uintptr_t)q8->dk8 | (uintptr_t)q8->dv8) & 3) == 0) {
+        p.dq8 = (uint8_t*)q8->dq8; p.dk8 = (uint8_t*)q8->dk8; p.dv8 = (uint8_t*)q8->dv8; p.ld8 = q8->ld8; p.site8 = q8->site;
+        if (fused) *fused = true;
+    }
     // dQ first: it computes the row constants (-delta, -lse/scale) and leaves them in `delta` for the dK/dV kernel
 #define LAUNCH_BWD(DR, KG)                                                                                              \
     do {                                                                                                            \

@@ -441,7 +441,7 @@ static int gemm_dispatch(const leccr_gemm_params& p, hipStream_t st, bool* colsu
 extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     LECCR_REQUIRE(pp != nullptr, LECCR_EINVAL, "gemm: null params");
     const leccr_gemm_params& p = *pp;
-    LECCR_REQUIRE(p.A && p.B && p.C, LECCR_EINVAL, "gemm: null operand");
+    LECCR_REQUIRE(p.A && p.B && (p.C || (p.c8 && (p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A))), LECCR_EINVAL, "gemm: null operand");
     LECCR_REQUIRE(p.M >= 0 && p.N >= 0 && p.K >= 0, LECCR_EINVAL, "gemm: negative size");
     // checks every operand format shares (they used to sit below the fp8 branch, which returned before reaching them)
     LECCR_REQUIRE(p.lda >= (p.trans_a ? p.M : p.K) && p.ldb >= (p.trans_b ? p.N : p.K) && p.ldc >= p.N, LECCR_EINVAL,
@@ -466,8 +466,9 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
         // fp8 MFMA GEMM inputs: only the 4-wave 256x256 kernel has them (no generic / small-shape fp8 path: callers keep those in bf16)
         LECCR_REQUIRE(gemm256w4_fp8_legal(p), LECCR_EINVAL, "gemm: fp8 operands need trans_a = trans_b = 0, a bf16 C, M, N >= 256, K %% 128 == 0, "
                       "16-byte aligned rows and a compiled epilogue");
-        LECCR_REQUIRE(!p.colsum && !p.asum, LECCR_EINVAL, "gemm: fp8 operands with colsum / asum");
-        LECCR_REQUIRE(gemm256w4_c8_legal(p), LECCR_EINVAL, "gemm: c8 needs a site, 8-byte aligned rows and an (d-)activation epilogue of matching format");
+        LECCR_REQUIRE(!p.asum, LECCR_EINVAL, "gemm: fp8 NT operands with asum");
+        LECCR_REQUIRE(gemm256w4_c8_legal(p), LECCR_EINVAL, "gemm: c8 needs a site, 8-byte aligned rows and an (d-)activation epilogue of matching format; "
+                      "colsum / a null C exist beside c8 only (colsum: the dX form)");
         if (p.M == 0 || p.N == 0) return LECCR_OK;
         hipStream_t st8 = as_stream(stream);
         ProfScope prof(PROF_GEMM_NT, 2.0 * (double)p.M * (double)p.N * (double)p.K, st8);

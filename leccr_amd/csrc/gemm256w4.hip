@@ -57,7 +57,8 @@ struct Args {
     uint8_t* c8;                         // F_Q8: fp8 copy of C (row stride ldc8), quantised under c8_site = {amax, scale, 1/scale, fmt}
     int64_t ldc8;
     float* c8_site;
-};
+    float* colsum;                       // F_Q8_BF8 (the dX product with a derivative epilogue): [N] += column sums of the f32 epilogue values
+};                                       // F_Q8 with C == nullptr: only the fp8 copy (and aux_out) is written
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) int int4_t;
@@ -352,13 +353,36 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             const int rr = lane_e >> 2, rc = (lane_e & 3) * 32;
             const int64_t ncol = n0 + wc * 128 + rc;
             const float* bias = a.bias;
+            // F_Q8: the bf16 C is optional - a consumer chain that is fp8 end to end (next product AND the weight-gradient product) reads
+            // only the fp8 copy, and 2 of the epilogue's 5 bytes per element stay unwritten (config E: the 4d-wide activation / its gradient)
+            const bool store_c = (FLAGS & F_Q8) == 0 || a.C != nullptr;
+            // F_Q8_BF8: the bias gradient colsum(C) from the f32 values, per lane the 32 columns at ncol over the rows of all 8 passes
+            [[maybe_unused]] float cs[32];
+            if constexpr ((FLAGS & F_Q8_BF8) != 0) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) cs[i] = 0.f;
+            }
             auto tiles = [&](auto check_tag) {
                 constexpr bool CHECK = decltype(check_tag)::value;
                 const bool col_ok = !CHECK || ncol < a.N;                      // N % 32 == 0 on this path (dispatcher)
+                // derivative epilogues read the saved pre-activation (32 columns of one row per lane and pass = 4 x 16 bytes): loaded one
+                // pass AHEAD, so the latency sits under the previous pass's LDS transpose and stores instead of in front of every use
+                // (config E, the 4d-wide dX product: 2.53 ms per launch against 1.53 for the forward twin that only stores)
+                [[maybe_unused]] bf16x8 xpre[2][4];
+                auto load_pre = [&](int pass, bf16x8* dst) {
+                    const int64_t mm = m0 + wr * 128 + (pass >> 1) * 32 + (pass & 1) * 16 + rr;
+                    const bool okp = !CHECK || (col_ok && mm < a.M);
+#pragma unroll
+                    for (int h8 = 0; h8 < 4; ++h8) dst[h8] = *reinterpret_cast<const bf16x8*>(a.aux + (okp ? mm * a.ldaux + ncol + 8 * h8 : 0));
+                };
+                if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) load_pre(0, xpre[0]);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
+                        if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) {
+                            if (2 * mi + hh + 1 < 8) load_pre(2 * mi + hh + 1, xpre[(2 * mi + hh + 1) & 1]);
+                        }
                         if (whalf == hh) {
 #pragma unroll
                             for (int ni = 0; ni < 4; ++ni)
@@ -397,7 +421,7 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                             if constexpr (EPI != LECCR_EPI_NONE) {
                                 f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
                                 if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) {
-                                    const bf16x8 xv = *reinterpret_cast<const bf16x8*>(a.aux + (ok ? m * a.ldaux + ncol + 8 * h8 : 0));
+                                    const bf16x8 xv = xpre[(2 * mi + hh) & 1][h8];
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) { x0[e] = (float)xv[e]; x1[e] = (float)xv[4 + e]; }
                                 }
@@ -412,7 +436,13 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                             bf16x8 ov;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { ov[e] = (bf16_t)v0[e]; ov[4 + e] = (bf16_t)v1[e]; }
-                            if (ok) *reinterpret_cast<bf16x8*>(a.C + off) = ov;
+                            if (ok && store_c) *reinterpret_cast<bf16x8*>(a.C + off) = ov;
+                            if constexpr ((FLAGS & F_Q8_BF8) != 0) {
+                                if (ok) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) { cs[8 * h8 + e] += v0[e]; cs[8 * h8 + 4 + e] += v1[e]; }
+                                }
+                            }
                             if constexpr ((FLAGS & F_Q8) != 0) {
                                 constexpr float FMAX = (FLAGS & F_Q8_BF8) != 0 ? 57344.f : 448.f;
                                 float q[8];
@@ -438,6 +468,20 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             };
             if (interior) tiles(std::false_type{});
             else tiles(std::true_type{});
+            if constexpr ((FLAGS & F_Q8_BF8) != 0) {
+                if (a.colsum != nullptr) {          // lanes with equal lane & 3 hold the same 32 columns: fold the 16 of them, lanes 0..3 add
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) {
+                        float v = cs[i];
+                        v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                        cs[i] = v;
+                    }
+                    if (lane_e < 4 && ncol < a.N) {
+#pragma unroll
+                        for (int i = 0; i < 32; ++i) atomicAdd(a.colsum + ncol + i, cs[i]);
+                    }
+                }
+            }
             // every ordinary load of the epilogue retired, visibly to hipcc's waitcnt pass (no vmcnt(0) sneaks into the K loop)
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_sched_barrier(0);
@@ -490,6 +534,8 @@ bool gemm256w4_fp8_legal(const leccr_gemm_params& p) {
 
 // the fused fp8 copy of C: activation epilogues of a forward product (e4m3 copy) or derivative epilogues of a dX product (e5m2)
 bool gemm256w4_c8_legal(const leccr_gemm_params& p) {
+    if (p.colsum && !(p.c8 && p.ab_dtype == LECCR_FP8_BF8A)) return false;       // fused column sums: the dX + derivative + c8 form only
+    if (!p.C && !p.c8) return false;                                              // C may be omitted only beside its fp8 copy
     if (!p.c8) return true;
     if (!p.c8_site || (p.ldc8 & 7) || ((uintptr_t)p.c8 & 7) || p.ldc8 < p.N) return false;
     if (p.ab_dtype == LECCR_FP8) return (p.epilogue == LECCR_EPI_QUICKGELU || p.epilogue == LECCR_EPI_GELU) && p.c8_fmt == 0;
@@ -529,7 +575,7 @@ int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st) {
         // the bf16 problem with half the columns: byte-identical staging (see F_FP8)
         a.K = p.K / 2; a.lda = p.lda / 2; a.ldb = p.ldb / 2;
         a.nkt = (int)(a.K / BK);
-        a.c8 = (uint8_t*)p.c8; a.ldc8 = p.ldc8; a.c8_site = p.c8_site;
+        a.c8 = (uint8_t*)p.c8; a.ldc8 = p.ldc8; a.c8_site = p.c8_site; a.colsum = p.colsum;
         if (p.c8) {     // the C written is also the next product's fp8 operand: activation output (e4m3) / its gradient (e5m2)
             if (p.ab_dtype == LECCR_FP8 && p.epilogue == LECCR_EPI_QUICKGELU) launch_inst<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st);
             else if (p.ab_dtype == LECCR_FP8) launch_inst<LECCR_EPI_GELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st);

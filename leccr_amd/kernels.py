@@ -21,24 +21,27 @@ def _rows2d(t):
 
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
-         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None, c8=None):
-    """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major."""
+         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None, c8=None, write_c=True):
+    """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major.
+    write_c=False (fp8 operands with c8 only): the bf16 C is not written - only its fp8 copy c8 (and aux_out / colsum); returns None."""
     assert a.dim() == 2 and b.dim() == 2 and (a.dtype == b.dtype or a.dtype == torch.float8_e5m2)
     assert a.stride(1) == 1 and b.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     N, Kb = (b.shape[1], b.shape[0]) if trans_b else b.shape
     assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
     fp8 = a.dtype in (torch.float8_e4m3fn, torch.float8_e5m2)
-    if out is None:
+    if not write_c:
+        assert fp8 and c8 is not None and out is None and not trans_a
+    elif out is None:
         out = torch.empty(M, N, device=a.device, dtype=out_dtype or (torch.bfloat16 if fp8 else a.dtype))
-    assert out.shape == (M, N) and out.stride(1) == 1
+    assert out is None or (out.shape == (M, N) and out.stride(1) == 1)
     p = L.GemmParams()
     p.A, p.B, p.C = ptr(a), ptr(b), ptr(out)
     p.M, p.N, p.K = M, N, K
-    p.lda, p.ldb, p.ldc = a.stride(0), b.stride(0), out.stride(0)
+    p.lda, p.ldb, p.ldc = a.stride(0), b.stride(0), (out.stride(0) if out is not None else N)
     if fp8:     # fp8 operands (quantize_fp8): b e4m3, a e4m3 (forward) or e5m2 (gradients); alpha_dev = their two inverse scales
         assert b.dtype == torch.float8_e4m3fn and trans_a == trans_b      # NT (forward / dX) or the weight-gradient form dY^T X
-        p.ab_dtype, p.c_dtype = (FP8 if a.dtype == torch.float8_e4m3fn else FP8_BF8A), dtype_code(out)
+        p.ab_dtype, p.c_dtype = (FP8 if a.dtype == torch.float8_e4m3fn else FP8_BF8A), (dtype_code(out) if out is not None else BF16)
     else:
         p.ab_dtype, p.c_dtype = dtype_code(a), dtype_code(out)
     if alpha_dev is not None:
@@ -50,12 +53,13 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     p.bias = ptr(bias)
     p.epilogue, p.accumulate = epilogue, int(accumulate)
+    odt = out.dtype if out is not None else torch.bfloat16
     for t in (aux, aux_out, residual):
         if t is not None:
-            assert t.dtype == out.dtype and t.shape == (M, N) and t.stride(1) == 1
+            assert t.dtype == odt and t.shape == (M, N) and t.stride(1) == 1
     p.aux, p.ldaux = ptr(aux), (aux.stride(0) if aux is not None else 0)
     if aux_out is not None:
-        assert aux_out.stride(0) == out.stride(0)
+        assert aux_out.stride(0) == p.ldc
     p.aux_out = ptr(aux_out)
     p.residual, p.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
     p.alpha = alpha
@@ -150,7 +154,8 @@ def _attn_args(q, k, v):
     return q.shape[0], q.shape[1], k.shape[1]
 
 
-def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0):
+def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0, q8_site=None):
+    """q8_site (a primed Fp8Site, bf16 only): returns (o, lse, o8) with o8 [b * Lq, d] the e4m3 copy of o under that site."""
     b, Lq, Lk = _attn_args(q, k, v)
     d = q.shape[2]
     hd = d // heads
@@ -158,13 +163,21 @@ def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0):
     lse = torch.empty(b, heads, Lq, device=q.device, dtype=torch.float32)
     if kmask is not None:
         assert kmask.dtype == torch.uint8 and kmask.shape == (b, Lk) and kmask.is_contiguous()
+    if q8_site is not None:
+        assert q8_site.primed and q8_site.fmt == 0 and d % 8 == 0
+        o8 = torch.empty(b * Lq, d, device=q.device, dtype=q8_site.torch_dtype)
+        check(lib().leccr_attn_fwd_q8(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), b, heads, Lq, Lk, hd,
+                                      q.stride(1), k.stride(1), v.stride(1), o.stride(1), dtype_code(q), float(drop_p),
+                                      int(seed), ptr(o8), d, ptr(q8_site.row), stream()), 'leccr_attn_fwd_q8')
+        return o, lse, o8
     check(lib().leccr_attn_fwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), b, heads, Lq, Lk, hd,
                                q.stride(1), k.stride(1), v.stride(1), o.stride(1), dtype_code(q), float(drop_p),
                                int(seed), stream()), 'leccr_attn_fwd')
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None, drop_p=0.0, seed=0):
+def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None, drop_p=0.0, seed=0, q8=None):
+    """q8 = (dq8, dk8, dv8, site): e5m2 copies of the three gradients (views of one packed [b, L, 3 d] byte tensor) under one primed site."""
     b, Lq, Lk = _attn_args(q, k, v)
     d = q.shape[2]
     hd = d // heads
@@ -176,6 +189,15 @@ def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None
     assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
     # workspace: two rows of constants per (b, head, query), queries padded to a multiple of 64 (see leccr_hip.h)
     delta = torch.empty(2 * b * heads * ((Lq + 63) // 64 * 64), dtype=torch.float32, device=q.device)
+    if q8 is not None:
+        dq8, dk8, dv8, site = q8
+        assert site.primed and site.fmt == 1 and dq8.stride(1) == dk8.stride(1) == dv8.stride(1) and dq8.stride(2) == 1
+        assert dq8.shape == q.shape and dk8.shape == k.shape and dv8.shape == v.shape and dq8.element_size() == 1
+        check(lib().leccr_attn_bwd_q8(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(kmask), ptr(dq), ptr(dk),
+                                      ptr(dv), ptr(delta), b, heads, Lq, Lk, hd, q.stride(1), k.stride(1), v.stride(1),
+                                      o.stride(1), dtype_code(q), float(drop_p), int(seed), ptr(dq8), ptr(dk8), ptr(dv8),
+                                      dq8.stride(1), ptr(site.row), stream()), 'leccr_attn_bwd_q8')
+        return dq, dk, dv
     check(lib().leccr_attn_bwd(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(kmask), ptr(dq), ptr(dk),
                                ptr(dv), ptr(delta), b, heads, Lq, Lk, hd, q.stride(1), k.stride(1), v.stride(1),
                                o.stride(1), dtype_code(q), float(drop_p), int(seed), stream()), 'leccr_attn_bwd')

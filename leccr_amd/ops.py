@@ -155,26 +155,43 @@ def dw_keep(x2, x8, w):
     return x2
 
 
-def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, **kw):
+def fp8_only_ok(rows, w, grad):
+    """True when a tensor [rows, n] that Linear `w` consumes - as its activation (grad False) or as its incoming gradient (grad True) -
+    is read ONLY through its fp8 copy: the product (forward / dX) and the weight-gradient product both run on the fp8 kernels and no
+    bf16 tail is left (rows a whole number of 128-row K-tiles).  The producing GEMM then writes just the fp8 copy (write_c=False):
+    2 of the 5 bytes per element of the 4d-wide activation / activation-gradient epilogues (config E: those two launches were half of
+    the fp8 GEMM time, HBM-bound)."""
+    if not (fp8_dw and fp8_c8_only and getattr(w, '_q8', None) is not None and rows >= 2048 and rows % 128 == 0):
+        return False
+    out_f, in_f = w._q8.shape
+    site = w._gsite if grad else w._xsite
+    return out_f % 256 == 0 and in_f % 256 == 0 and site.primed
+
+
+fp8_c8_only = os.environ.get('LECCR_FP8_C8_ONLY', '1') != '0'
+
+
+def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_only=False, **kw):
     """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free).
     fp8 (compute_dtype 'fp8', the encoder blocks' Linears): x2 is quantised to e4m3 under the Linear's activation site and
     multiplied with the weight's e4m3 copy on the scaled-MFMA kernel; the saved-for-backward tensors stay bf16.
     x8: x2's fp8 copy when the producer already wrote it (c8_site).  c8_site: the activation site of the Linear that CONSUMES this
     output: once that site has a scale, the epilogue also writes the output's fp8 copy under it (no separate quantise pass over
-    it).  want8: return (y, y8 or None) instead of y."""
+    it).  want8: return (y, y8 or None) instead of y.  c8_only (fp8_only_ok): y itself is not written, (None, y8) comes back."""
     if fp8 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8):
         if x8 is None:
             x8 = w._xsite.quantize(x2)
         c8 = None
         if c8_site is not None and c8_site.primed:
             c8 = (torch.empty(x2.shape[0], w._q8.shape[0], device=x2.device, dtype=c8_site.torch_dtype), c8_site)
-        y = K.gemm(x8, w._q8, bias=_bias(b), alpha_dev=(w._xsite.inv_scale, w._wsite.inv_scale), c8=c8, **kw)
+        y = K.gemm(x8, w._q8, bias=_bias(b), alpha_dev=(w._xsite.inv_scale, w._wsite.inv_scale), c8=c8, write_c=not (c8_only and c8 is not None), **kw)
         return (y, c8[0] if c8 is not None else None) if want8 else y
+    assert not c8_only
     y = K.gemm(x2, w._lp, bias=_bias(b), **kw)
     return (y, None) if want8 else y
 
 
-def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, **kw):
+def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False, **kw):
     """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N].
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
     if fp8 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t):
@@ -183,8 +200,9 @@ def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, **kw):
         c8 = None
         if c8_site is not None and c8_site.primed:
             c8 = (torch.empty(dy2.shape[0], w._q8t.shape[0], device=dy2.device, dtype=c8_site.torch_dtype), c8_site)
-        y = K.gemm(g8, w._q8t, alpha_dev=(w._gsite.inv_scale, w._wsite.inv_scale), c8=c8, **kw)
+        y = K.gemm(g8, w._q8t, alpha_dev=(w._gsite.inv_scale, w._wsite.inv_scale), c8=c8, write_c=not (c8_only and c8 is not None), **kw)
         return (y, c8[0] if c8 is not None else None) if want8 else y
+    assert not c8_only
     y = K.gemm(dy2, w._lpt, **kw) if w._lpt is not None else K.gemm(dy2, w._lp, trans_b=True, **kw)
     return (y, None) if want8 else y
 
@@ -255,28 +273,34 @@ def join_wgrad_stream(stream=None):
         cur.wait_stream(s)
 
 
-def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None):
+def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_done=False):
     """dW += scale * dY^T X (f32, into the gradient arena) and db += scale * colsum(dY).
     dy_bias: the tensor whose column sums are the bias gradient when it is not dy2 itself (an f32 head's incoming gradient,
     of which dy2 is the bf16 GEMM operand: the bias sum cancels heavily and is taken from the unrounded values).
     g8, x8 (fp8 mode): the e5m2 copy of dy2 and the e4m3 copy of x2 under w's gradient / activation sites - the product then runs on
-    the fp8 weight-gradient kernel (the bias sums still come from the bf16 dy2); x2 may then hold only the tail rows (dw_keep)."""
+    the fp8 weight-gradient kernel (the bias sums still come from the bf16 dy2); x2 may then hold only the tail rows (dw_keep).
+    dy2 None (fp8_only_ok): only the fp8 copy of the gradient exists - no tail rows, and the bias gradient was summed by the
+    producing GEMM's epilogue (bias_done)."""
     global _wgrad_stream, _wgrad_join_queued, _wgrad_throttle
     if not (fp8_dw and g8 is not None and x8 is not None and _fp8_dw_ok(g8, x8)):
+        if dy2 is None or x2.shape[0] != dy2.shape[0]:
+            raise RuntimeError('lin_dw: only the fp8 copy of an operand was kept (dw_keep / fp8_only_ok) but the fp8 weight-gradient product '
+                               'is not available for dY8 %s / X8 %s' % (None if g8 is None else tuple(g8.shape), None if x8 is None else tuple(x8.shape)))
         g8 = x8 = None
-        if x2.shape[0] != dy2.shape[0]:
-            raise RuntimeError('lin_dw: the forward kept only the fp8 copy of this input (dw_keep) but the fp8 weight-gradient product '
-                               'is not available for dY %s / X8 %s' % (tuple(dy2.shape), None if x8 is None else tuple(x8.shape)))
-    if not (wgrad_overlap and dy2.is_cuda):
-        return _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8)
+    if dy2 is None:
+        assert g8.shape[0] % 128 == 0 and (b is None or bias_done)
+    ref = dy2 if dy2 is not None else g8
+    if not (wgrad_overlap and ref.is_cuda):
+        return _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8, bias_done)
     main = torch.cuda.current_stream()
     if _wgrad_stream is None:
-        _wgrad_stream = torch.cuda.Stream(device=dy2.device)
+        _wgrad_stream = torch.cuda.Stream(device=ref.device)
     side = _wgrad_stream
     side.wait_stream(main)                      # dY and X were produced on the main stream
     with torch.cuda.stream(side):
-        _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8)
-    dy2.record_stream(side)                     # the caching allocator must not recycle them under the side stream
+        _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8, bias_done)
+    if dy2 is not None:
+        dy2.record_stream(side)                 # the caching allocator must not recycle them under the side stream
     x2.record_stream(side)
     if g8 is not None:
         g8.record_stream(side)
@@ -297,8 +321,8 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None):
         dy_bias.record_stream(side)
     if not _wgrad_join_queued:
         # (first weight-gradient launch of a backward pass: every saved activation is still held - the moment to look at the pressure)
-        _wgrad_throttle = wgrad_lag > 0 and (torch.cuda.memory_allocated(dy2.device)
-                                             > wgrad_lag_pressure * torch.cuda.get_device_properties(dy2.device).total_memory)
+        _wgrad_throttle = wgrad_lag > 0 and (torch.cuda.memory_allocated(ref.device)
+                                             > wgrad_lag_pressure * torch.cuda.get_device_properties(ref.device).total_memory)
         # once per backward pass: when the autograd engine has run every node, the main stream waits for the side stream,
         # so whatever follows backward() (optimizer, gradient all-reduce, a test reading .grad) sees complete gradients
         def _join():                            # (final callbacks run on the stream that called backward())
@@ -319,9 +343,12 @@ def _fp8_dw_ok(g8, x8):
             and g8.data_ptr() % 16 == 0 and x8.data_ptr() % 16 == 0)
 
 
-def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None):
+def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None, bias_done=False):
     # the bias gradient colsum(dY) rides in the dW GEMM (leccr_gemm_params.asum: on the matrix cores beside the product in the
     # 256x256 kernel, a colsum pass inside leccr_gemm otherwise) unless it comes from another tensor or carries a scale
+    if bias_done:           # summed by the GEMM epilogue that produced the gradient (fp8_only_ok)
+        _mark(b)
+        b = None
     fused = b is not None and dy_bias is None and scale == 1.0 and fuse_bias_grad
     if g8 is not None:
         # fp8 operands: whole 128-row K-tiles on the scaled-MFMA kernel, the (< 128-row) tail and the bias sums from the bf16 tensors
@@ -341,8 +368,6 @@ def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None):
     _mark(w)
     if b is not None and fused:
         _mark(b)
-    elif b is not None and os.environ.get('XP_SKIP_COLSUM') == '1' and g8 is not None:
-        pass
     elif b is not None:
         src = dy2 if dy_bias is None else dy_bias
         if scale == 1.0:
@@ -496,22 +521,34 @@ class ViTBlockFn(torch.autograd.Function):
                                             site=_q8_site(blk.fp8, M, blk.attn.in_proj_weight, '_xsite'))
         h1_8 = x8_of(blk.fp8, _rows(h1), blk.attn.in_proj_weight, h1_8)
         qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8, x8=h1_8).view(b, N, 3 * d)
-        o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
-        o_8 = x8_of(blk.fp8, _rows(o), blk.attn.out_proj.weight)
+        # (fp8: the attention kernel writes the e4m3 copy of o that out_proj multiplies, the backward the e5m2 copy of dqkv for in_proj)
+        o_site = _q8_site(blk.fp8, M, blk.attn.out_proj.weight, '_xsite')
+        if o_site is not None and o_site.primed:
+            o, lse, o_8 = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads, q8_site=o_site)
+        else:
+            o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
+            o_8 = x8_of(blk.fp8, _rows(o), blk.attn.out_proj.weight)
         x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, x8=o_8, residual=_rows(x)).view(b, N, d)
         h2, mean2, rstd2, _, h2_8 = _ln_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5,
                                             site=_q8_site(blk.fp8, M, blk.mlp.c_fc.weight, '_xsite'))
         pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
         h2_8 = x8_of(blk.fp8, _rows(h2), blk.mlp.c_fc.weight, h2_8)
         # (fp8: the activation's e4m3 copy for c_proj comes out of c_fc's epilogue - no quantise pass over the 4d-wide tensor)
+        # (.. and when c_proj's forward and weight-gradient products both read that copy, the bf16 activation is not written at all)
+        act_8only = blk.fp8 and h2_8 is not None and fp8_only_ok(M, blk.mlp.c_proj.weight, False)
         act, act8 = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, x8=h2_8, epilogue=EPI_QUICKGELU, aux_out=pre,
-                            c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True)
-        act8 = x8_of(blk.fp8, act, blk.mlp.c_proj.weight, act8)
-        x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
+                            c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True, c8_only=act_8only)
+        if act is None:
+            act = pre[:0]                                   # (the tail rows dw_keep would keep: none)
+            x2 = lin_fwd(act8, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=True, x8=act8, residual=_rows(x1)).view(b, N, d)
+        else:
+            act8 = x8_of(blk.fp8, act, blk.mlp.c_proj.weight, act8)
+            x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
         # fp8: the e4m3 copies the forward products multiplied are the weight-gradient products' X operands, and the bf16 h1 / h2 / act
         # are kept for nothing else (dw_keep)
         ctx.save_for_backward(x, dw_keep(_rows(h1), h1_8, blk.attn.in_proj_weight), mean1, rstd1, qkv, o, lse, x1,
-                              dw_keep(_rows(h2), h2_8, blk.mlp.c_fc.weight), mean2, rstd2, pre, dw_keep(act, act8, blk.mlp.c_proj.weight),
+                              dw_keep(_rows(h2), h2_8, blk.mlp.c_fc.weight), mean2, rstd2, pre,
+                              act if act.shape[0] == 0 else dw_keep(act, act8, blk.mlp.c_proj.weight),
                               *((h1_8, o_8, h2_8, act8) if fp8_dw else (None,) * 4))
         ctx.blk = blk
         return x2
@@ -526,17 +563,22 @@ class ViTBlockFn(torch.autograd.Function):
         g2 = _rows(dx2)
         g2_8 = _g8_take(g2) if blk.fp8 else None          # written by the next block's LayerNorm-1 backward (fp8 mode)
         g2_8 = g8_of(blk.fp8, g2, blk.mlp.c_proj.weight, g2_8)
+        # (fp8: when c_fc's dX and weight-gradient products both read dpre's e5m2 copy, the bf16 dpre is not written; its column sums -
+        #  c_fc's bias gradient - then come out of the same epilogue)
+        dpre_8only = blk.fp8 and g2_8 is not None and h2_8 is not None and fp8_only_ok(g2.shape[0], blk.mlp.c_fc.weight, True)
         dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, g8=g2_8, epilogue=EPI_DQUICKGELU, aux=pre,
-                             c8_site=_site(blk.mlp.c_fc.weight, '_gsite'), want8=True)
+                             c8_site=_site(blk.mlp.c_fc.weight, '_gsite'), want8=True, c8_only=dpre_8only,
+                             **(dict(colsum=blk.mlp.c_fc.bias._g.reshape(-1)) if dpre_8only else {}))
         # bias gradients of c_proj / out_proj = column sums of dx2 / dx1.  They ride the weight-gradient stream as 40 us HBM-bound
         # passes beside the dX chain: folded into the LayerNorm backward launches (whose `dres` operands those tensors are) they
         # cost that kernel a fifth of its occupancy - 253 us against 201 us per launch on the main chain
         lin_dw(g2, act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, g8=g2_8, x8=act8)
-        dpre8 = g8_of(blk.fp8, dpre, blk.mlp.c_fc.weight, dpre8)
-        dh2 = lin_dx(dpre, blk.mlp.c_fc.weight, fp8=blk.fp8, g8=dpre8)
+        if dpre is not None:
+            dpre8 = g8_of(blk.fp8, dpre, blk.mlp.c_fc.weight, dpre8)
+        dh2 = lin_dx(dpre if dpre is not None else dpre8, blk.mlp.c_fc.weight, fp8=blk.fp8, g8=dpre8)
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
-        lin_dw(dpre, h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, g8=dpre8, x8=h2_8)
+        lin_dw(dpre, h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, g8=dpre8, x8=h2_8, bias_done=dpre is None)
         dx1, _, g1_8 = _ln_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g, blk.ln_2.bias._g,
                                site=_q8_site(blk.fp8, b * N, blk.attn.out_proj.weight, '_gsite'), dres=dx2)
         g1 = _rows(dx1)
@@ -544,9 +586,14 @@ class ViTBlockFn(torch.autograd.Function):
         do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8, g8=g1_8).view(b, N, d)
         lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, g8=g1_8, x8=o_8)
         dqkv = torch.empty_like(qkv)
+        g_site = _q8_site(blk.fp8, b * N, blk.attn.in_proj_weight, '_gsite')
+        dqkv8 = None
+        if g_site is not None and g_site.primed:
+            dqkv8 = torch.empty(qkv.shape, device=qkv.device, dtype=g_site.torch_dtype)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
-                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
-        dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight)
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:],
+                   q8=None if dqkv8 is None else (dqkv8[..., :d], dqkv8[..., d:2 * d], dqkv8[..., 2 * d:], g_site))
+        dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight, None if dqkv8 is None else _rows(dqkv8))
         dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)
         lin_dw(_rows(dqkv), h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
         # (fp8: dx is the gradient the previous block's c_proj dX product consumes: its e5m2 copy goes with it)
@@ -647,10 +694,14 @@ class BertLayerFn(torch.autograd.Function):
             x1, mean1, rstd1, _, x1_8 = _ln_fwd(s1, ao.LayerNorm.weight.data, ao.LayerNorm.bias.data, layer.eps, site=x1_site)
         pre = torch.empty(b * L, layer.intermediate.dense.weight.shape[0], device=x.device, dtype=x.dtype)
         x1_8 = x8_of(layer.fp8, _rows(x1), layer.intermediate.dense.weight, x1_8)
-        h, h8 = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, x8=x1_8, epilogue=EPI_GELU,
-                        aux_out=pre, c8_site=_site(layer.output.dense.weight, '_xsite'), want8=True)
         out = layer.output
-        h8 = x8_of(layer.fp8, h, out.dense.weight, h8)
+        h_8only = layer.fp8 and x1_8 is not None and fp8_only_ok(b * L, out.dense.weight, False)       # as the ViT block's activation
+        h, h8 = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, x8=x1_8, epilogue=EPI_GELU,
+                        aux_out=pre, c8_site=_site(out.dense.weight, '_xsite'), want8=True, c8_only=h_8only)
+        if h is None:
+            h = h8                                          # the products below take the fp8 copy; no bf16 rows are kept
+        else:
+            h8 = x8_of(layer.fp8, h, out.dense.weight, h8)
         if ph > 0:
             a2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8)
             x2, mean2, rstd2, s2 = K.layernorm_fwd(a2.view(b, L, d), out.LayerNorm.weight.data, out.LayerNorm.bias.data,
@@ -659,7 +710,8 @@ class BertLayerFn(torch.autograd.Function):
             s2 = lin_fwd(h, out.dense.weight, out.dense.bias, fp8=layer.fp8, x8=h8, residual=_rows(x1)).view(b, L, d)
             x2, mean2, rstd2, _ = K.layernorm_fwd(s2, out.LayerNorm.weight.data, out.LayerNorm.bias.data, layer.eps)
         ctx.save_for_backward(dw_keep(_rows(x), x_8, layer._qkv_w), kmask, qkv, o, lse, s1, mean1, rstd1,
-                              dw_keep(_rows(x1), x1_8, layer.intermediate.dense.weight), pre, dw_keep(h, h8, out.dense.weight), s2, mean2, rstd2,
+                              dw_keep(_rows(x1), x1_8, layer.intermediate.dense.weight), pre,
+                              pre[:0] if h is h8 else dw_keep(h, h8, out.dense.weight), s2, mean2, rstd2,
                               *((x_8, o_8, x1_8, h8) if fp8_dw else (None,) * 4))          # fp8: the weight-gradient products' X operands
         ctx.layer, ctx.drop = layer, (ph, pa, seeds)
         return x2
@@ -679,12 +731,16 @@ class BertLayerFn(torch.autograd.Function):
                                  drop=(ph, seeds[2]) if ph > 0 else None)
         g2, gd2 = _rows(g2), _rows(gd2)
         gd2_8 = g8_of(layer.fp8, gd2, out.dense.weight, gd2_8)
+        inter = layer.intermediate.dense
+        dpre_8only = layer.fp8 and gd2_8 is not None and x1_8 is not None and fp8_only_ok(gd2.shape[0], inter.weight, True)
         dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, g8=gd2_8, epilogue=EPI_DGELU, aux=pre,
-                             c8_site=_site(layer.intermediate.dense.weight, '_gsite'), want8=True)
+                             c8_site=_site(inter.weight, '_gsite'), want8=True, c8_only=dpre_8only,
+                             **(dict(colsum=inter.bias._g.reshape(-1)) if dpre_8only else {}))
         lin_dw(gd2, h, out.dense.weight, out.dense.bias, g8=gd2_8, x8=h8)
-        dpre8 = g8_of(layer.fp8, dpre, layer.intermediate.dense.weight, dpre8)
-        dx1 = lin_dx(dpre, layer.intermediate.dense.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
-        lin_dw(dpre, x1, layer.intermediate.dense.weight, layer.intermediate.dense.bias, g8=dpre8, x8=x1_8)
+        if dpre is not None:
+            dpre8 = g8_of(layer.fp8, dpre, inter.weight, dpre8)
+        dx1 = lin_dx(dpre if dpre is not None else dpre8, inter.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
+        lin_dw(dpre, x1, inter.weight, inter.bias, g8=dpre8, x8=x1_8, bias_done=dpre is None)
         g1, gd1, gd1_8 = _ln_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                                  ao.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, ao.dense.weight, '_gsite'),
                                  drop=(ph, seeds[1]) if ph > 0 else None)

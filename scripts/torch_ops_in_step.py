@@ -1,11 +1,11 @@
-"""Which torch device ops (copies, fills, elementwise adds) still run inside one train step, and from where.
+"""Which torch (aten) device ops still run inside one train step, and from where.
     python scripts/torch_ops_in_step.py [--batch 32]
-Runs two warm-up steps and one step under torch.profiler (with Python stacks), then prints every at::native / copy kernel's op,
-count, input shapes and the innermost leccr_amd / bench frame that issued it."""
-import argparse, collections, os, sys
+Runs two warm-up steps, then one step under a TorchDispatchMode that records every aten op touching a CUDA tensor with the innermost
+leccr_amd / bench.py frame that issued it (views and metadata ops are left out)."""
+import argparse, collections, os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from torch.profiler import ProfilerActivity, profile
+from torch.utils._python_dispatch import TorchDispatchMode
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=32)
@@ -21,23 +21,26 @@ sched = create_scheduler(dict(cfg['schedular'], step_per_epoch=1000), opt)
 for _ in range(2):
     bench.train_step(model, batch, fwd, opt, sched)
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+
+SKIP = ('view', 'reshape', 'expand', 'permute', 'transpose', 'slice', 'select', 'as_strided', 'alias', 'detach', 'unsqueeze', 'squeeze',
+        't.default', 'empty', 'size', 'stride', 'is_', 'unbind', 'split', 'record_stream', '_unsafe_view', 'lift_fresh', 'numel', 'sym_')
+rows = collections.Counter()
+
+
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        flat = [x for x in list(args) + list((kwargs or {}).values()) if isinstance(x, torch.Tensor)]
+        if flat and any(t.is_cuda for t in flat) and not any(s in name for s in SKIP):
+            fr = [f for f in traceback.extract_stack() if ('leccr_amd' in f.filename or f.filename.endswith('bench.py')) and 'scripts' not in f.filename]
+            where = f'{os.path.relpath(fr[-1].filename)}:{fr[-1].lineno} {fr[-1].name}' if fr else '(autograd engine / torch internals)'
+            rows[(name, str([tuple(t.shape) for t in flat])[:70], where)] += 1
+        return func(*args, **(kwargs or {}))
+
+
+with Log():
     bench.train_step(model, batch, fwd, opt, sched)
     torch.cuda.synchronize()
-rows = collections.Counter()
-for e in prof.events():
-    if e.device_type.name != 'CPU' or not e.name.startswith('aten::'):
-        continue
-    if not e.kernels:
-        continue
-    frame = next((s for s in e.stack if ('leccr_amd' in s or 'bench.py' in s) and 'torch/' not in s), e.stack[0] if e.stack else '?')
-    rows[(e.name, str(e.input_shapes)[:80], frame.strip()[-110:])] += 1
-for (name, shapes, frame), n in sorted(rows.items(), key=lambda kv: -kv[1]):
-    print(f'{n:4d}  {name:28s} {shapes:80s} {frame}')
-print('kernels by name:')
-kc = collections.Counter()
-for e in prof.events():
-    if e.device_type.name == 'CUDA':
-        kc[e.name[:90]] += 1
-for k, n in kc.most_common(40):
-    print(f'{n:5d}  {k}')
+for (name, shapes, where), n in sorted(rows.items(), key=lambda kv: -kv[1]):
+    print(f'{n:4d}  {name:34s} {shapes:70s} {where}')
+print('total aten device ops in the step:', sum(rows.values()))

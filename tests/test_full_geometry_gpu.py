@@ -297,6 +297,29 @@ def test_config_e_geometry_vit_l14_xlmr_large_vs_oracle(dtype):
 
 @pytest.mark.parametrize('fuse_ln,dw8', [(False, True), (True, True), (False, False)])
 def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, dw8, monkeypatch):
+    _fp8_model_vs_noise_model(fuse_ln, dw8, monkeypatch, L14_GEOMETRY, 8, 2 * 4)
+
+
+def test_fp8_end_to_end_copies_without_the_bf16_activation(monkeypatch):
+    """The same rule where EVERY operand chain is fp8 end to end (round 3): 98 x 98 images (50 tokens) at b = 64 give 3200 token rows = 25
+    whole K-tiles of 128 for the ViT blocks and 2048 for the text layers, so from the second step on c_fc / intermediate.dense write
+    only the fp8 copy of their activation (no bf16 C), the dX products with the derivative epilogue write only the e5m2 copy of the
+    activation gradient and sum c_fc's bias gradient in that epilogue, and all 16 weight-gradient products run from fp8 copies."""
+    from leccr_amd import kernels as K
+    calls = []
+    real = K.gemm
+
+    def spy(*a, **kw):
+        calls.append(bool(kw.get('write_c', True)))
+        return real(*a, **kw)
+    monkeypatch.setattr(K, 'gemm', spy)
+    _fp8_model_vs_noise_model(True, True, monkeypatch, dict(L14_GEOMETRY, image_resolution=98), 64, 2 * 4 + 2 * 4)
+    # step 2: activation + its gradient in two ViT blocks and two text layers (8) + the activations of the caption encoder's two layers
+    # (forward only; it IS the text encoder, so in step 1 its pass already finds the sites the text pass primed: 2 + 2)
+    assert calls.count(False) == 2 * (2 + 2) + 2 + 2
+
+
+def _fp8_model_vs_noise_model(fuse_ln, dw8, monkeypatch, geometry, nb, dw_launches):
     """compute_dtype 'fp8' (BASELINE configs[4]: "fp8 MFMA"): the ViT-L/14 + XLM-R-large shaped model (two layers each, b = 8 so
     that every encoder Linear has >= 256 rows and takes the fp8 kernel) with e4m3 activations / weights in the forward products and
     e5m2 gradients in the dX products - and (dw8, round 3) the SAME copies in the weight-gradient products dY^T X of the ViT blocks
@@ -310,12 +333,12 @@ def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, dw8, monkeypatch):
     monkeypatch.setattr(ops, 'fp8_dw', dw8)                   # LECCR_FP8_DW
     monkeypatch.setattr(ops, 'fp8_dw_launches', 0)
     torch.manual_seed(17)
-    model = RetrievalModel(dict(MULTI30K_CFG, clip_geometry=L14_GEOMETRY, text_config=dict(XLMR_LARGE_2L, vocab_size=30000),
+    model = RetrievalModel(dict(MULTI30K_CFG, clip_geometry=geometry, text_config=dict(XLMR_LARGE_2L, vocab_size=30000),
                                 compute_dtype='fp8', clip_text_tower=False))
     model.init_caption_encoder()
     seeded_fill_(model.named_parameters(), 93)
     model = model.to(DEV).eval()
-    m = make_batch(8, vocab=30000)
+    m = make_batch(nb, vocab=30000, res=geometry['image_resolution'])
     batch = dict(image=m['image'], ids_s=m['text'][0].input_ids, mask_s=m['text'][0].attention_mask, ids_t=m['text'][1].input_ids,
                  mask_t=m['text'][1].attention_mask, ids_c=m['captions'].input_ids, mask_c=m['captions'].attention_mask, idx=m['idx'])
     torch.set_num_threads(16)
@@ -333,7 +356,7 @@ def test_fp8_operand_path_vs_oracle_noise_model(fuse_ln, dw8, monkeypatch):
     model.arena.zero_grad()
     sum(losses).backward()
     assert all(h._gsite.primed for h in (blk.attn.in_proj_weight, blk.mlp.c_proj.weight, lay._qkv_w, lay.intermediate.dense.weight))
-    assert ops.fp8_dw_launches == (2 * 4 if dw8 else 0)       # the four Linears of both ViT blocks
+    assert ops.fp8_dw_launches == (dw_launches if dw8 else 0)       # the four Linears of both ViT blocks (+ of both text layers at 2048 rows)
     rows = grad_rows(model, sd, sd_noise)
     bad = outside_noise_model(rows)
     assert len(rows) > 150 and not bad, (len(bad), bad[:8])

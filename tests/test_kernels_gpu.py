@@ -999,6 +999,50 @@ def test_fp8_batched_weight_requantisation_matches_the_per_tensor_passes(K):
             assert torch.equal(h._q8t.view(torch.uint8), h._q8.view(torch.uint8).t())
 
 
+@pytest.mark.parametrize('b,L,heads,kmask', [(3, 577, 12, False), (2, 730, 16, False), (4, 64, 12, True), (2, 145, 8, False)])
+def test_attention_writes_the_fp8_copies_its_consumers_need(K, b, L, heads, kmask):
+    """leccr_attn_fwd_q8 / leccr_attn_bwd_q8: o's e4m3 copy (the out_proj input) and the e5m2 copy of the packed dqkv (the in_proj
+    gradient, one site for its three column blocks) out of the attention kernels' epilogues (long unmasked sequences forward, every
+    MFMA backward) or out of quantise passes (masked / short forward): the bf16 results are untouched, the copies are within one fp8 step
+    of quantising the bf16 tensors (they are quantised from the f32 values) and the recorded amax is the tensors' own."""
+    d = heads * 64
+    qkv = _rand((b, L, 3 * d), torch.bfloat16, 700).to(DEV)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    km = None
+    if kmask:
+        km = torch.zeros(b, L, dtype=torch.uint8)
+        km[:, L - 7:] = 1
+        km = km.to(DEV)
+    sites = K.Fp8Sites(DEV, 4)
+    so, sg = sites.new(0), sites.new(1)
+    o, lse = K.attn_fwd(q, k, v, heads, km)
+    keep = [so.quantize(o.view(b * L, d))]                    # primes the site from the tensor (kept: its block must not be recycled as o8)
+    sites.update()
+    o2, lse2, o8 = K.attn_fwd(q, k, v, heads, km, q8_site=so)
+    assert torch.equal(o2, o) and torch.equal(lse2, lse)
+    want = (o.view(b * L, d).float() * float(so.row[1])).to(torch.float8_e4m3fn).float()
+    got = o8.float()
+    assert bool(((got - want).abs() <= torch.maximum(want.abs(), got.abs()) * 0.13 + 2.0 ** -9).all())
+    assert float((got - want).abs().gt(0).float().mean()) < 0.2
+    amax = float(o.float().abs().max())
+    assert abs(float(so.row[0]) - amax) <= 8e-3 * amax
+    do = _rand((b, L, d), torch.bfloat16, 701, 1e-2).to(DEV)
+    dqkv = torch.empty_like(qkv)
+    K.attn_bwd(q, k, v, o, do, lse, heads, km, dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:])
+    keep.append(sg.quantize(dqkv.view(b * L, 3 * d)))
+    sites.update()
+    dqkv2, dqkv8 = torch.empty_like(qkv), torch.zeros(b, L, 3 * d, device=DEV, dtype=torch.float8_e5m2)
+    K.attn_bwd(q, k, v, o, do, lse, heads, km, dq=dqkv2[..., :d], dk=dqkv2[..., d:2 * d], dv=dqkv2[..., 2 * d:],
+               q8=(dqkv8[..., :d], dqkv8[..., d:2 * d], dqkv8[..., 2 * d:], sg))
+    assert torch.equal(dqkv2, dqkv)
+    want = (dqkv.float() * float(sg.row[1])).to(torch.float8_e5m2).float()
+    got = dqkv8.float()
+    assert bool(((got - want).abs() <= torch.maximum(want.abs(), got.abs()) * 0.26 + 2.0 ** -16).all())
+    assert float((got - want).abs().gt(0).float().mean()) < 0.2
+    amax = float(dqkv.float().abs().max())
+    assert abs(float(sg.row[0]) - amax) <= 8e-3 * amax
+
+
 def test_gemm_fp8_rejects_what_it_does_not_implement(K):
     sites = K.Fp8Sites(DEV, 4)
     sa, sb = sites.new(0), sites.new(0)
@@ -1083,3 +1127,26 @@ def test_gemm_fp8_fused_copy_of_the_output(K, grad):
     assert float((got - want).abs().gt(0).float().mean()) < 0.2       # and mostly identical
     amax = float(out.float().abs().max())
     assert abs(float(sc.row[0]) - amax) <= 8e-3 * amax                 # max |C| of the f32 values, recorded for the next scale
+    # round 3: C itself is optional beside c8 (write_c=False) - the same copy bytes, the pre-activation still written, and on the
+    # dX form the column sums of the f32 epilogue values (the bias gradient) fused into the epilogue, ragged last row tile included
+    sites.update()
+    y8b = torch.zeros(M, N, device=DEV, dtype=sc.torch_dtype)
+    y8c = torch.zeros(M, N, device=DEV, dtype=sc.torch_dtype)
+    K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), c8=(y8c, sc), **kw)
+    sites.update()
+    kw2 = dict(kw)
+    if not grad:
+        kw2['aux_out'] = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    cs = torch.full((N,), 2.0, device=DEV) if grad else None
+    assert K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), c8=(y8b, sc), write_c=False, colsum=cs, **kw2) is None
+    assert torch.equal(y8b.view(torch.uint8), y8c.view(torch.uint8))
+    if grad:
+        want_cs = 2.0 + out.double().sum(0)
+        tol = 4e-3 * float(out.double().abs().sum(0).max())              # `out` is the bf16-rounded C; the sums are of the f32 values
+        assert float((cs.double() - want_cs).abs().max()) <= tol
+        with pytest.raises(RuntimeError):                                 # no column sums without the fp8 copy
+            K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), colsum=cs, **kw)
+    else:
+        assert torch.equal(kw2['aux_out'], kw['aux_out'])
+        with pytest.raises((RuntimeError, AssertionError)):               # forward form: no fused column sums
+            K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), c8=(y8b, sc), colsum=torch.zeros(N, device=DEV), **kw2)
