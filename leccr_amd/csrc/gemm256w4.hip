@@ -250,6 +250,30 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
 
     [[maybe_unused]] float q8_scale = 1.f, q8_amax = 0.f;
     if constexpr ((FLAGS & F_Q8) != 0) q8_scale = a.c8_site[1];
+    // F_Q8_BF8: the bias gradient colsum(C) from the f32 epilogue values, per lane its 32 columns, carried ACROSS the items of this
+    // workgroup while they stay in the same tile column (they do whenever tiles_n divides the item stride: 4096 / 256 = 16 | 32) and
+    // added to memory once per change of column: one atomic per column and workgroup instead of one per column and 128-row wave tile
+    // (11 680 tiles x 2 waves on 4096 addresses serialised at the memory side: +1.0 ms on a 1.3 ms launch)
+    [[maybe_unused]] float cs[32];
+    [[maybe_unused]] int64_t cs_n0 = -1;
+    if constexpr ((FLAGS & F_Q8_BF8) != 0) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) cs[i] = 0.f;
+    }
+    [[maybe_unused]] auto cs_flush = [&]() {
+        if (cs_n0 >= 0 && a.colsum != nullptr) {     // lanes with equal lane & 3 hold the same 32 columns: fold the 16 of them, lanes 0..3 add
+            int lane_f = lane;
+            asm volatile("" : "+v"(lane_f));
+            const int64_t ncol = cs_n0 + wc * 128 + (lane_f & 3) * 32;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                float v = cs[i];
+                v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                if (lane_f < 4 && ncol < a.N) atomicAdd(a.colsum + ncol + i, v);
+                cs[i] = 0.f;
+            }
+        }
+    };
     int t = 0;
     for (int j = 0; j < n_mine; ++j) {
         f32x16 acc[16];                      // [ni * 4 + mi]
@@ -356,11 +380,11 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             // F_Q8: the bf16 C is optional - a consumer chain that is fp8 end to end (next product AND the weight-gradient product) reads
             // only the fp8 copy, and 2 of the epilogue's 5 bytes per element stay unwritten (config E: the 4d-wide activation / its gradient)
             const bool store_c = (FLAGS & F_Q8) == 0 || a.C != nullptr;
-            // F_Q8_BF8: the bias gradient colsum(C) from the f32 values, per lane the 32 columns at ncol over the rows of all 8 passes
-            [[maybe_unused]] float cs[32];
             if constexpr ((FLAGS & F_Q8_BF8) != 0) {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) cs[i] = 0.f;
+                if (n0 != cs_n0) {
+                    cs_flush();
+                    cs_n0 = n0;
+                }
             }
             auto tiles = [&](auto check_tag) {
                 constexpr bool CHECK = decltype(check_tag)::value;
@@ -368,19 +392,24 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                 // derivative epilogues read the saved pre-activation (32 columns of one row per lane and pass = 4 x 16 bytes): loaded one
                 // pass AHEAD, so the latency sits under the previous pass's LDS transpose and stores instead of in front of every use
                 // (config E, the 4d-wide dX product: 2.53 ms per launch against 1.53 for the forward twin that only stores)
+                // (the residual of the plain epilogues likewise)
+                constexpr bool NEED_AUX = EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU;
+                constexpr bool PRE = NEED_AUX || (FLAGS & F_RES) != 0;
                 [[maybe_unused]] bf16x8 xpre[2][4];
                 auto load_pre = [&](int pass, bf16x8* dst) {
                     const int64_t mm = m0 + wr * 128 + (pass >> 1) * 32 + (pass & 1) * 16 + rr;
                     const bool okp = !CHECK || (col_ok && mm < a.M);
+                    const bf16_t* pb = NEED_AUX ? a.aux : a.residual;
+                    const int64_t pld = NEED_AUX ? a.ldaux : a.ldr;
 #pragma unroll
-                    for (int h8 = 0; h8 < 4; ++h8) dst[h8] = *reinterpret_cast<const bf16x8*>(a.aux + (okp ? mm * a.ldaux + ncol + 8 * h8 : 0));
+                    for (int h8 = 0; h8 < 4; ++h8) dst[h8] = *reinterpret_cast<const bf16x8*>(pb + (okp ? mm * pld + ncol + 8 * h8 : 0));
                 };
-                if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) load_pre(0, xpre[0]);
+                if constexpr (PRE) load_pre(0, xpre[0]);
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
                     for (int hh = 0; hh < 2; ++hh) {
-                        if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) {
+                        if constexpr (PRE) {
                             if (2 * mi + hh + 1 < 8) load_pre(2 * mi + hh + 1, xpre[(2 * mi + hh + 1) & 1]);
                         }
                         if (whalf == hh) {
@@ -429,7 +458,9 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                                 for (int e = 0; e < 4; ++e) { v0[e] = apply_epi<EPI>(v0[e], x0[e]); v1[e] = apply_epi<EPI>(v1[e], x1[e]); }
                             }
                             if constexpr ((FLAGS & F_RES) != 0) {
-                                const bf16x8 rv = *reinterpret_cast<const bf16x8*>(a.residual + (ok ? m * a.ldr + ncol + 8 * h8 : 0));
+                                bf16x8 rv;
+                                if constexpr (!NEED_AUX) rv = xpre[(2 * mi + hh) & 1][h8];
+                                else rv = *reinterpret_cast<const bf16x8*>(a.residual + (ok ? m * a.ldr + ncol + 8 * h8 : 0));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { v0[e] += (float)rv[e]; v1[e] += (float)rv[4 + e]; }
                             }
@@ -468,20 +499,6 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             };
             if (interior) tiles(std::false_type{});
             else tiles(std::true_type{});
-            if constexpr ((FLAGS & F_Q8_BF8) != 0) {
-                if (a.colsum != nullptr) {          // lanes with equal lane & 3 hold the same 32 columns: fold the 16 of them, lanes 0..3 add
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) {
-                        float v = cs[i];
-                        v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-                        cs[i] = v;
-                    }
-                    if (lane_e < 4 && ncol < a.N) {
-#pragma unroll
-                        for (int i = 0; i < 32; ++i) atomicAdd(a.colsum + ncol + i, cs[i]);
-                    }
-                }
-            }
             // every ordinary load of the epilogue retired, visibly to hipcc's waitcnt pass (no vmcnt(0) sneaks into the K loop)
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_sched_barrier(0);
@@ -492,6 +509,7 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             decode(a, first_item, stride, cur);
         }
     }
+    if constexpr ((FLAGS & F_Q8_BF8) != 0) cs_flush();
     if constexpr ((FLAGS & F_Q8) != 0) {               // one conditional atomic per wave and launch (see fp8.hip: block_amax)
         float m = q8_amax;
 #pragma unroll
