@@ -18,6 +18,13 @@ int attn_generic_bwd(const void* q, const void* k, const void* v, const void* o,
                      const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D,
                      hipStream_t st);
 
+// bf16 attention with a thin side (<= 8 keys or <= 8 queries per batch element), any head size (attention_thin.hip)
+int attn_thin_kind(const AttnDims& D, int dtype);          // 0: not taken, 1: thin-K, 2: thin-Q
+int attn_thin_fwd(int kind, const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+                  const AttnDims& D, hipStream_t st);
+int attn_thin_bwd(int kind, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                  const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st);
+
 // optional fp8 copies of the outputs (leccr_attn_fwd_q8 / leccr_attn_bwd_q8): forward o8 (e4m3), backward dq8 / dk8 / dv8 (e5m2), row
 // stride ld8 bytes, under `site`.  *fused is set when the kernel that ran wrote them itself; otherwise the caller runs quantise passes.
 struct AttnQ8 {

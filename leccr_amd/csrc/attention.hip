@@ -4,6 +4,7 @@
 
 namespace leccr {
 bool g_force_generic_attn = false;
+static int g_last_attn_kernel = -1;      // 0 generic, 1 MFMA flash (head 64), 2 thin-K, 3 thin-Q
 
 static int check_dims(const char* what, const AttnDims& D, int dtype) {
     LECCR_REQUIRE(dtype == LECCR_F32 || dtype == LECCR_BF16, LECCR_EINVAL, "%s: bad dtype", what);
@@ -28,7 +29,17 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * (double)b * heads * Lq * Lk * hd, st);
-    if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) return attn_mfma_fwd(q, k, v, o, lse, kmask, D, st, q8, fused);
+    if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) {
+        g_last_attn_kernel = 1;
+        return attn_mfma_fwd(q, k, v, o, lse, kmask, D, st, q8, fused);
+    }
+    if (!g_force_generic_attn) {         // head sizes the MFMA kernels do not cover, one side thin (the caption interaction at d = 768)
+        if (const int kind = attn_thin_kind(D, dtype)) {
+            g_last_attn_kernel = 1 + kind;
+            return attn_thin_fwd(kind, q, k, v, o, lse, kmask, D, st);
+        }
+    }
+    g_last_attn_kernel = 0;
     return dtype == LECCR_F32 ? attn_generic_fwd<float>(q, k, v, o, lse, kmask, D, st)
                               : attn_generic_fwd<bf16_t>(q, k, v, o, lse, kmask, D, st);
 }
@@ -55,6 +66,7 @@ extern "C" int leccr_attn_fwd_q8(const void* q, const void* k, const void* v, vo
 }
 
 extern "C" int leccr_set_attn_variant(int v) { return attn_set_variant(v); }
+extern "C" int leccr_last_attn_kernel(void) { return g_last_attn_kernel; }
 
 static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dout,
                          const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
@@ -67,8 +79,17 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_BWD, 10.0 * (double)b * heads * Lq * Lk * hd, st);
-    if (!g_force_generic_attn && attn_mfma_supported(D, dtype))
+    if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) {
+        g_last_attn_kernel = 1;
         return attn_mfma_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st, q8, fused);
+    }
+    if (!g_force_generic_attn) {
+        if (const int kind = attn_thin_kind(D, dtype)) {
+            g_last_attn_kernel = 1 + kind;
+            return attn_thin_bwd(kind, q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
+        }
+    }
+    g_last_attn_kernel = 0;
     return dtype == LECCR_F32 ? attn_generic_bwd<float>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st)
                               : attn_generic_bwd<bf16_t>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
 }

@@ -797,6 +797,55 @@ def test_dropout_mask_is_counter_based(K):
     assert torch.equal(K.dropout(xv.contiguous(), 0.1, 99) != 0, K.dropout(torch.ones(xv.numel(), device=DEV), 0.1, 99) != 0)
 
 
+@pytest.mark.parametrize('b,heads,Lq,Lk,hd,masked', [(3, 8, 300, 4, 96, False), (3, 8, 4, 730, 96, False), (2, 8, 4, 64, 96, True),
+                                                     (2, 8, 577, 3, 64, False), (2, 8, 8, 8, 64, True), (2, 8, 130, 4, 128, True),
+                                                     (2, 8, 3, 200, 128, False), (5, 16, 257, 4, 48, False)])
+@pytest.mark.parametrize('drop', [0.0, 0.1])
+def test_attention_with_a_thin_side(K, b, heads, Lq, Lk, hd, masked, drop):
+    """attention_thin.hip (round 3): at most 8 keys or at most 8 queries per batch element at d = heads * hd in {512, 768, 1024} - the
+    caption interaction's shapes (models/attention.py:24-58 with nhead = 8: 96-wide heads at ViT-L/14's embedding width) - against
+    the f64 reference with the kernels' own dropout mask; the long query sets of thin-K run as 8 row chunks whose dK / dV partial sums
+    meet in the workspace; leccr_last_attn_kernel() confirms which family ran (hd = 64 shapes stay on the MFMA kernels)."""
+    d = heads * hd
+    q, kv = _rand((b, Lq, d), torch.bfloat16, 110, 0.5), _rand((b, Lk, 2 * d), torch.bfloat16, 111, 0.5)
+    k, v = kv[..., :d], kv[..., d:]
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    kmask = None
+    if masked:
+        lens = torch.randint(1, Lk + 1, (b,), generator=torch.Generator().manual_seed(112))
+        lens[0] = Lk
+        kmask = (torch.arange(Lk)[None, :] >= lens[:, None]).to(torch.uint8)
+    km = kmask.to(DEV) if masked else None
+    from leccr_amd import _lib
+    lib = _lib.lib()
+    o, lse = K.attn_fwd(qd, kvd[..., :d], kvd[..., d:], heads, km, drop, 77)
+    want_kernel = 1 if hd == 64 else (2 if Lk <= 4 else 3)
+    assert lib.leccr_last_attn_kernel() == want_kernel
+    mask = (K.dropout(torch.ones(b * heads * Lq * Lk, device=DEV), drop, 77).view(b, heads, Lq, Lk).cpu().double() if drop
+            else torch.ones(b, heads, Lq, Lk, dtype=torch.float64))
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh = qr.reshape(b, Lq, heads, hd).permute(0, 2, 1, 3)
+    kh = kr.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    vh = vr.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    sc = qh @ kh.transpose(-1, -2) / math.sqrt(hd)
+    if masked:
+        sc = sc.masked_fill(kmask.bool()[:, None, None, :], float('-inf'))
+    ref = ((torch.softmax(sc, -1) * mask) @ vh).permute(0, 2, 1, 3).reshape(b, Lq, d)
+    e, s_ = _err(o, ref)
+    assert e <= _tol(torch.bfloat16) * s_, ('o', e, s_)
+    e, s_ = _err(lse, torch.logsumexp(sc, -1).detach())
+    assert e <= (3e-3 if hd == 64 else 1e-4 * s_ + 1e-4), ('lse', e)          # (MFMA path: normaliser of bf16-rounded weights)
+    do = _rand((b, Lq, d), torch.bfloat16, 113)
+    (ref * do.double()).sum().backward()
+    dkv = torch.zeros_like(kvd)
+    dq, dk, dv = K.attn_bwd(qd, kvd[..., :d], kvd[..., d:], o, do.to(DEV), lse, heads, km, dk=dkv[..., :d], dv=dkv[..., d:],
+                            drop_p=drop, seed=77)
+    assert lib.leccr_last_attn_kernel() == want_kernel
+    for name, got, r in (('dq', dq, qr.grad), ('dk', dk, kr.grad), ('dv', dv, vr.grad)):
+        e, s_ = _err(got, r)
+        assert e <= (3e-2 if hd == 64 else 1.5e-2) * s_, (name, e, s_)
+
+
 @pytest.mark.parametrize('Lq,Lk', [(70, 50), (40, 72)])        # short (<= 16 rows) last query tile / last key tile
 @pytest.mark.parametrize('dtype,hd', [(torch.float32, 64), (torch.bfloat16, 64), (torch.float32, 8)])
 def test_attention_dropout_matches_masked_reference(K, dtype, hd, Lq, Lk):
