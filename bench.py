@@ -412,7 +412,7 @@ def _main(args, real_stdout):
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    NK = 11
+    NK = 13
     ms, work, n = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
     busy, gwork, gn = C.c_double(), C.c_double(), C.c_int64()
     prof_steps = args.roofline_steps if args.roofline_steps > 0 else 0
@@ -431,7 +431,7 @@ def _main(args, real_stdout):
         lib.leccr_prof_enable(0)
         dropped += int(lib.leccr_prof_dropped())
         lib.leccr_prof_read_n(NK, ms, work, n)
-        lib.leccr_prof_read_union(0b11, C.byref(busy), C.byref(gwork), C.byref(gn))
+        lib.leccr_prof_read_union(0b11 | (0b11 << 11), C.byref(busy), C.byref(gwork), C.byref(gn))
     # Roofline leg: the same steps with every launch on ONE stream, so that a launch's event interval is the kernel running
     # alone (in the timed region above a dW GEMM shares the chip with the dX chain, and its own interval is stretched by that).
     ms1, work1, n1 = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
@@ -463,10 +463,22 @@ def _main(args, real_stdout):
         G = args.batch * world
         value = G * args.steps / dt
         union_ms, union_fl = busy.value, gwork.value
-        gemm_ms, gemm_fl, gemm_n = leg_ms[0] + leg_ms[1], leg_work[0] + leg_work[1], leg_n[0] + leg_n[1]
+        # the GEMM family: bf16 launches (kinds 0, 1) and, with --dtype fp8, the fp8-operand launches (kinds 11, 12).  A mixed step is
+        # priced launch by launch: `peak` is the rate at which the SAME mix of flops would run with every launch at its own MFMA peak
+        # (fp8 flops at 5 PF, bf16 flops at 2.5 PF), so frac = (time at peak) / (time measured)
+        bf_ms, bf_fl, bf_n = leg_ms[0] + leg_ms[1], leg_work[0] + leg_work[1], leg_n[0] + leg_n[1]
+        f8_ms, f8_fl, f8_n = leg_ms[11] + leg_ms[12], leg_work[11] + leg_work[12], leg_n[11] + leg_n[12]
+        gemm_ms, gemm_fl, gemm_n = bf_ms + f8_ms, bf_fl + f8_fl, bf_n + f8_n
         achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        # --dtype fp8: the GEMM family mixes fp8 (forward, dX) and bf16 (dW, heads) launches; it is priced against the fp8 peak
-        peak = MFMA_FP8_PEAK_TFLOPS if args.dtype == 'fp8' else MFMA_BF16_PEAK_TFLOPS
+        t_peak = bf_fl / MFMA_BF16_PEAK_TFLOPS + f8_fl / MFMA_FP8_PEAK_TFLOPS
+        peak = gemm_fl / t_peak if t_peak > 0 else MFMA_BF16_PEAK_TFLOPS
+        mixed = None
+        if f8_n:
+            mixed = {'fp8': {'launches_per_step': f8_n // max(1, leg), 'ms_per_step': round(f8_ms / max(1, leg), 3),
+                             'tflops': round(f8_fl / (f8_ms * 1e-3) / 1e12, 1) if f8_ms > 0 else None, 'peak': MFMA_FP8_PEAK_TFLOPS,
+                             'weight_gradient_tflops': round(leg_work[12] / (leg_ms[12] * 1e-3) / 1e12, 1) if leg_ms[12] > 0 else None},
+                     'bf16': {'launches_per_step': bf_n // max(1, leg), 'ms_per_step': round(bf_ms / max(1, leg), 3),
+                              'tflops': round(bf_fl / (bf_ms * 1e-3) / 1e12, 1) if bf_ms > 0 else None, 'peak': MFMA_BF16_PEAK_TFLOPS}}
         traffic, traffic_src = None, None
         tj = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_gemm256_hbm_traffic.json') for r in (2, 1))
                    if os.path.exists(p)), '')
@@ -502,8 +514,9 @@ def _main(args, real_stdout):
                        'alloc_retries': int(torch.cuda.memory_stats().get('num_alloc_retries', 0)),
                        'world': world, 'backend': backend if world > 1 else None, 'rccl_version': rccl,
                        'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'LECCR_RCCL_CUS': rccl_cus()},
-            'roofline': {'bound': 'mfma', 'kernel': 'gemm256_kernel (bf16 256x256x64 MFMA GEMM: NT forward/dX + TN weight-gradient instantiations)',
-                         'achieved': round(achieved, 1), 'peak': peak, 'unit': 'TFLOP/s',
+            'roofline': {'bound': 'mfma', 'kernel': ('gemm256 family (256x256 MFMA GEMMs: 8-wave NT forward / dX, 4-wave TN weight gradient'
+                                                     + (', fp8-operand 4-wave NT / TN' if args.dtype == 'fp8' else '') + ')'),
+                         'achieved': round(achieved, 1), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'by_operand_type': mixed,
                          'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': traffic_src,
                          'launches_per_step': gemm_n // max(1, leg),

@@ -52,8 +52,10 @@ int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_ge
                                                 * 5 the 4-wave TN weight-gradient kernel, 6 its fp8 form; tests use it */
 int leccr_prof_enable(int on);
 int leccr_prof_read(double* ms, double* work, int64_t* launches);
-/* The first n <= 11 kinds: the five above, then {layernorm_fwd, layernorm_bwd, colsum, embedding stages, adamw, dropout} -
- * the HBM-bound launches, whose work[] entry is ALGORITHMIC BYTES (every operand read once, every result written once). */
+/* The first n <= 13 kinds: the five above, then {layernorm_fwd, layernorm_bwd, colsum, embedding stages, adamw, dropout} -
+ * the HBM-bound launches, whose work[] entry is ALGORITHMIC BYTES (every operand read once, every result written once) - then
+ * {fp8-operand NT GEMMs (forward / dX), fp8-operand weight-gradient GEMMs}: flops, kept apart from the bf16 launches of kinds 0 / 1
+ * so that a mixed-precision step can be priced launch by launch (fp8 against the fp8 MFMA peak, bf16 against the bf16 one). */
 int leccr_prof_read_n(int n, double* ms, double* work, int64_t* launches);
 /* The launches of the kinds in kind_mask (bit k = index k above) as one busy time: the union of their [start, stop]
  * intervals (launches that overlap on two streams are not counted twice), their total work and count. */

@@ -5,6 +5,11 @@
 namespace leccr {
 bool g_force_generic_attn = false;
 static int g_last_attn_kernel = -1;      // 0 generic, 1 MFMA flash (head 64), 2 thin-K, 3 thin-Q
+// LECCR_ATTN_THIN=2: the thin kernels also take the head-64 problems with a thin side (default: those stay on the MFMA kernels)
+static bool thin_first() {
+    static const bool v = [] { const char* e = getenv("LECCR_ATTN_THIN"); return e && e[0] == '2'; }();
+    return v;
+}
 
 static int check_dims(const char* what, const AttnDims& D, int dtype) {
     LECCR_REQUIRE(dtype == LECCR_F32 || dtype == LECCR_BF16, LECCR_EINVAL, "%s: bad dtype", what);
@@ -29,7 +34,7 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * (double)b * heads * Lq * Lk * hd, st);
-    if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) {
+    if (!g_force_generic_attn && attn_mfma_supported(D, dtype) && !(thin_first() && attn_thin_kind(D, dtype))) {
         g_last_attn_kernel = 1;
         return attn_mfma_fwd(q, k, v, o, lse, kmask, D, st, q8, fused);
     }
@@ -79,7 +84,7 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_BWD, 10.0 * (double)b * heads * Lq * Lk * hd, st);
-    if (!g_force_generic_attn && attn_mfma_supported(D, dtype)) {
+    if (!g_force_generic_attn && attn_mfma_supported(D, dtype) && !(thin_first() && attn_thin_kind(D, dtype))) {
         g_last_attn_kernel = 1;
         return attn_mfma_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st, q8, fused);
     }

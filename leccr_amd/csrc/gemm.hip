@@ -458,7 +458,7 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
         LECCR_REQUIRE(gemm256t4_fp8_legal(p), LECCR_EINVAL, "gemm: fp8 TN operands need ab_dtype LECCR_FP8_BF8A, an accumulated f32 C, no epilogue, "
                       "M, N %% 256 == 0, K %% 128 == 0, K >= 2048 and 16-byte aligned rows");
         hipStream_t st8 = as_stream(stream);
-        ProfScope prof(PROF_GEMM_TN, 2.0 * (double)p.M * (double)p.N * (double)p.K, st8);
+        ProfScope prof(PROF_GEMM_FP8_TN, 2.0 * (double)p.M * (double)p.N * (double)p.K, st8);
         g_last_kernel = 6;
         return gemm256t4_fp8_launch(p, gemm256_max_blocks(), st8);
     }
@@ -471,7 +471,7 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
                       "colsum / a null C exist beside c8 only (colsum: the dX form)");
         if (p.M == 0 || p.N == 0) return LECCR_OK;
         hipStream_t st8 = as_stream(stream);
-        ProfScope prof(PROF_GEMM_NT, 2.0 * (double)p.M * (double)p.N * (double)p.K, st8);
+        ProfScope prof(PROF_GEMM_FP8_NT, 2.0 * (double)p.M * (double)p.N * (double)p.K, st8);
         g_last_kernel = 4;
         return gemm256w4_launch(p, st8);
     }
