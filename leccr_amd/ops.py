@@ -218,8 +218,10 @@ fuse_bias_grad = os.environ.get('LECCR_FUSE_BIAS_GRAD', '1') != '0'      # bias 
 text_overlap = os.environ.get('LECCR_TEXT_STREAM', '1') != '0'
 wgrad_lag = int(os.environ.get('LECCR_DW_LAG', '12'))      # host run-ahead over the weight-gradient stream, in launches (0: unbounded)
 wgrad_lag_pressure = float(os.environ.get('LECCR_DW_LAG_PRESSURE', '0.35'))  # .. applied when the backward pass starts with this share of the HBM allocated
+wgrad_lag_reserved = float(os.environ.get('LECCR_DW_LAG_RESERVED', '0.75'))   # .. or with this share of the HBM held by the allocator's pool
 _wgrad_events = collections.deque()
 _wgrad_throttle = False
+_bwd_done = None             # recorded when a backward pass (side stream included) has been queued completely
 _wgrad_stream = None
 _text_stream = None
 _wgrad_join_queued = False
@@ -312,23 +314,40 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_d
         # Keeping the host at most `wgrad_lag` weight-gradient launches (3 blocks) ahead of the side stream bounds that overhang
         # (config E: reserved 286 -> 163 GB).  Only under memory pressure (wgrad_lag_pressure): on the batch-256 ViT-B/16 step, where the
         # overhang fits (reserved 107 of 288 GB), the host waits cost 2.4 ms of 130.6.
+        # Hysteresis: the host waits only once 2 x wgrad_lag launches are outstanding, then until wgrad_lag are left - one blocking
+        # wait (and one wake-up latency) per wgrad_lag launches instead of one per launch.
         ev = torch.cuda.Event()
         ev.record(side)
         _wgrad_events.append(ev)
-        if len(_wgrad_events) > wgrad_lag:
+        if len(_wgrad_events) >= 2 * wgrad_lag:
+            while len(_wgrad_events) > wgrad_lag + 1:
+                _wgrad_events.popleft()
             _wgrad_events.popleft().synchronize()
     if dy_bias is not None:
         dy_bias.record_stream(side)
     if not _wgrad_join_queued:
-        # (first weight-gradient launch of a backward pass: every saved activation is still held - the moment to look at the pressure)
-        _wgrad_throttle = wgrad_lag > 0 and (torch.cuda.memory_allocated(ref.device)
-                                             > wgrad_lag_pressure * torch.cuda.get_device_properties(ref.device).total_memory)
+        # First weight-gradient launch of a backward pass.  The host does not start queuing this pass before the device has finished the
+        # PREVIOUS one (it still has this step's whole forward queued, so nothing idles): a loop that never reads a loss (bench.py's
+        # timed region; the reference's loop reads loss.item() every step) lets the host run steps ahead, the blocks the side stream
+        # touched come back to the allocator only when the device gets there, and every step ahead allocates its temporaries anew -
+        # the pool grew from 60 to 150-217 GB over 8-16 steps of the batch-256 step (and into allocation retries beyond).
+        global _bwd_done
+        if _bwd_done is not None:
+            _bwd_done.synchronize()
+            _bwd_done = None
+        # (.. also the moment to look at the memory pressure: every saved activation is still held)
+        # .. or the allocator's pool has grown past three quarters of the HBM (it never shrinks by itself)
+        total = torch.cuda.get_device_properties(ref.device).total_memory
+        _wgrad_throttle = wgrad_lag > 0 and (torch.cuda.memory_allocated(ref.device) > wgrad_lag_pressure * total
+                                             or torch.cuda.memory_reserved(ref.device) > wgrad_lag_reserved * total)
         # once per backward pass: when the autograd engine has run every node, the main stream waits for the side stream,
         # so whatever follows backward() (optimizer, gradient all-reduce, a test reading .grad) sees complete gradients
         def _join():                            # (final callbacks run on the stream that called backward())
-            global _wgrad_join_queued
+            global _wgrad_join_queued, _bwd_done
             _wgrad_join_queued = False
             join_wgrad_stream()
+            _bwd_done = torch.cuda.Event()
+            _bwd_done.record()
         try:
             torch.autograd.Variable._execution_engine.queue_callback(_join)
             _wgrad_join_queued = True
