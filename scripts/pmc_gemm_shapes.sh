@@ -29,10 +29,6 @@ for k, v in acc.items():
 PY
   done
 done <<LIST
-qkv 0 $M 2304 768
-fc1 0 $M 3072 768
-fc2 0 $M 768 3072
-out 0 $M 768 768
-dW_fc1 1 3072 768 $M
+$( if [ "$SHAPES" = "dw" ]; then printf 'dW_qkv 1 2304 768 %s\ndW_fc1 1 3072 768 %s\ndW_fc2 1 768 3072 %s\n' $M $M $M; else printf 'qkv 0 %s 2304 768\nfc1 0 %s 3072 768\nfc2 0 %s 768 3072\nout 0 %s 768 768\ndW_fc1 1 3072 768 %s\n' $M $M $M $M $M; fi )
 LIST
 cat $OUT
