@@ -147,7 +147,8 @@ __device__ __forceinline__ void issue_piece(const Args& a, const Cursor& c, int 
 // k-step 3 (right after the barrier that frees the slot) belong to K-tile t+2, those in k-steps 0..2 of the NEXT iteration
 // are the rest of the same K-tile; front-loaded so that the last piece has two k-steps to land before vmcnt(0).
 #ifndef W4_EXP
-#define W4_EXP 0          // diagnostic builds: 1 no vmcnt wait, 2 no DMA in the loop, 4 no barrier, 8 no fragment reads (wrong results)
+#define W4_EXP 0          // diagnostic builds: 1 no vmcnt wait, 2 no DMA in the loop, 4 no barrier, 8 no fragment reads, 16 no epilogue at all,
+                          // 32 epilogue without its global stores, 64 one K-tile per item (wrong results)
 #endif
 constexpr int N3 = 8;     // pieces issued in k-step 3
 __host__ __device__ constexpr int piece_at(int ks, int i) {
@@ -250,26 +251,26 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
 
     [[maybe_unused]] float q8_scale = 1.f, q8_amax = 0.f;
     if constexpr ((FLAGS & F_Q8) != 0) q8_scale = a.c8_site[1];
-    // F_Q8_BF8: the bias gradient colsum(C) from the f32 epilogue values, per lane its 32 columns, carried ACROSS the items of this
+    // F_Q8_BF8: the bias gradient colsum(C) from the f32 epilogue values, per lane its 8 columns, carried ACROSS the items of this
     // workgroup while they stay in the same tile column (they do whenever tiles_n divides the item stride: 4096 / 256 = 16 | 32) and
     // added to memory once per change of column: one atomic per column and workgroup instead of one per column and 128-row wave tile
     // (11 680 tiles x 2 waves on 4096 addresses serialised at the memory side: +1.0 ms on a 1.3 ms launch)
-    [[maybe_unused]] float cs[32];
+    [[maybe_unused]] float cs[8];
     [[maybe_unused]] int64_t cs_n0 = -1;
     if constexpr ((FLAGS & F_Q8_BF8) != 0) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) cs[i] = 0.f;
+        for (int i = 0; i < 8; ++i) cs[i] = 0.f;
     }
     [[maybe_unused]] auto cs_flush = [&]() {
-        if (cs_n0 >= 0 && a.colsum != nullptr) {     // lanes with equal lane & 3 hold the same 32 columns: fold the 16 of them, lanes 0..3 add
+        if (cs_n0 >= 0 && a.colsum != nullptr) {     // lanes with equal lane & 15 hold the same 8 columns: fold the 4 of them, lanes 0..15 add
             int lane_f = lane;
             asm volatile("" : "+v"(lane_f));
-            const int64_t ncol = cs_n0 + wc * 128 + (lane_f & 3) * 32;
+            const int64_t ncol = cs_n0 + wc * 128 + (lane_f & 15) * 8;
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
+            for (int i = 0; i < 8; ++i) {
                 float v = cs[i];
-                v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-                if (lane_f < 4 && ncol < a.N) atomicAdd(a.colsum + ncol + i, v);
+                v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+                if (lane_f < 16 && ncol < a.N) atomicAdd(a.colsum + ncol + i, v);
                 cs[i] = 0.f;
             }
         }
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
 
-        for (int kt = 0; kt < a.nkt; ++kt, ++t) {
+        for (int kt = 0; kt < ((W4_EXP & 64) ? 1 : a.nkt); ++kt, ++t) {
             const uint32_t sc = (t & 1) * SLOT, sn = SLOT - sc;
             // per-lane address pieces go through an opaque asm each K-tile so that the derived addresses are formed at their use
             asm volatile("" : "+v"(la[0]), "+v"(la[1]), "+v"(la[2]), "+v"(la[3]));
@@ -373,10 +374,12 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             asm volatile("" : "+v"(lane_e));
             // write side: this lane's accumulator row m = 32 mi + (lane & 31); 16-row half hh = (lane & 31) >> 4
             const int wrow = lane_e & 15, whalf = (lane_e & 31) >> 4, wk = lane_e >> 5;
-            // read side: row rr = lane >> 2 (16 rows), the lane's 32 columns start at 32 * (lane & 3)
-            const int rr = lane_e >> 2, rc = (lane_e & 3) * 32;
-            const int64_t ncol = n0 + wc * 128 + rc;
-            const float* bias = a.bias;
+            // read side: every global access of a pass is 16 bytes per lane with 16 consecutive lanes on ONE row (256 contiguous bytes,
+            // 4 rows per instruction): lane -> row 4 i + (lane >> 4) of the pass's 16 (i = 0..3), columns 8 (lane & 15) .. + 7 - fixed for the
+            // lane.  (Until round 3 a lane owned 32 columns of one row and a store instruction wrote 64 separate 16-byte pieces 64 bytes
+            // apart: the stores alone were 8 us of a 28 us K = 1024 item, scripts/gemm_w4_items.py with the -DW4_EXP=32 build.)
+            const int rq = lane_e >> 4, rp = lane_e & 15;
+            const int64_t ncol = n0 + wc * 128 + rp * 8;
             // F_Q8: the bf16 C is optional - a consumer chain that is fp8 end to end (next product AND the weight-gradient product) reads
             // only the fp8 copy, and 2 of the epilogue's 5 bytes per element stay unwritten (config E: the 4d-wide activation / its gradient)
             const bool store_c = (FLAGS & F_Q8) == 0 || a.C != nullptr;
@@ -389,7 +392,9 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             auto tiles = [&](auto check_tag) {
                 constexpr bool CHECK = decltype(check_tag)::value;
                 const bool col_ok = !CHECK || ncol < a.N;                      // N % 32 == 0 on this path (dispatcher)
-                // derivative epilogues read the saved pre-activation (32 columns of one row per lane and pass = 4 x 16 bytes): loaded one
+                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+                if (a.bias) { b0 = load4(a.bias + (col_ok ? ncol : 0)); b1 = load4(a.bias + (col_ok ? ncol + 4 : 0)); }
+                // derivative epilogues read the saved pre-activation (8 columns of 4 rows per lane and pass = 4 x 16 bytes): loaded one
                 // pass AHEAD, so the latency sits under the previous pass's LDS transpose and stores instead of in front of every use
                 // (config E, the 4d-wide dX product: 2.53 ms per launch against 1.53 for the forward twin that only stores)
                 // (the residual of the plain epilogues likewise)
@@ -397,12 +402,14 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                 constexpr bool PRE = NEED_AUX || (FLAGS & F_RES) != 0;
                 [[maybe_unused]] bf16x8 xpre[2][4];
                 auto load_pre = [&](int pass, bf16x8* dst) {
-                    const int64_t mm = m0 + wr * 128 + (pass >> 1) * 32 + (pass & 1) * 16 + rr;
-                    const bool okp = !CHECK || (col_ok && mm < a.M);
                     const bf16_t* pb = NEED_AUX ? a.aux : a.residual;
                     const int64_t pld = NEED_AUX ? a.ldaux : a.ldr;
 #pragma unroll
-                    for (int h8 = 0; h8 < 4; ++h8) dst[h8] = *reinterpret_cast<const bf16x8*>(pb + (okp ? mm * pld + ncol + 8 * h8 : 0));
+                    for (int h8 = 0; h8 < 4; ++h8) {
+                        const int64_t mm = m0 + wr * 128 + (pass >> 1) * 32 + (pass & 1) * 16 + 4 * h8 + rq;
+                        const bool okp = !CHECK || (col_ok && mm < a.M);
+                        dst[h8] = *reinterpret_cast<const bf16x8*>(pb + (okp ? mm * pld + ncol : 0));
+                    }
                 };
                 if constexpr (PRE) load_pre(0, xpre[0]);
 #pragma unroll
@@ -426,21 +433,23 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                         WAVE_LDS_FENCE();
                         f32x4 v[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q)
-                            v[q] = *reinterpret_cast<const f32x4*>(stg + rr * 128 + ((((rc >> 2) + q) ^ rr) << 2));
+                        for (int q = 0; q < 4; ++q) {                                  // row 4 q + rq, chunks 2 rp and 2 rp + 1
+                            const int row = 4 * q + rq;
+                            v[2 * q] = *reinterpret_cast<const f32x4*>(stg + row * 128 + (((2 * rp) ^ row) << 2));
+                            v[2 * q + 1] = *reinterpret_cast<const f32x4*>(stg + row * 128 + (((2 * rp + 1) ^ row) << 2));
+                        }
                         WAVE_LDS_FENCE();
-                        const int64_t m = m0 + wr * 128 + mi * 32 + hh * 16 + rr;
-                        const bool ok = !CHECK || (col_ok && m < a.M);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-                            if (bias) bq = load4(bias + (ok ? ncol + 4 * q : 0));
-                            v[q] = v[q] * a.alpha + bq;
+                        for (int q = 0; q < 4; ++q) {
+                            v[2 * q] = v[2 * q] * a.alpha + b0;
+                            v[2 * q + 1] = v[2 * q + 1] * a.alpha + b1;
                         }
 #pragma unroll
-                        for (int h8 = 0; h8 < 4; ++h8) {                              // 4 x (8 columns = 16 bytes of bf16)
+                        for (int h8 = 0; h8 < 4; ++h8) {                              // 4 rows x (8 columns = 16 bytes of bf16)
                             f32x4 v0 = v[2 * h8], v1 = v[2 * h8 + 1];
-                            const int64_t off = ok ? m * a.ldc + ncol + 8 * h8 : 0;
+                            const int64_t m = m0 + wr * 128 + mi * 32 + hh * 16 + 4 * h8 + rq;
+                            const bool ok = !CHECK || (col_ok && m < a.M);
+                            const int64_t off = ok ? m * a.ldc + ncol : 0;
                             if constexpr ((FLAGS & F_AUXOUT) != 0) {
                                 bf16x8 pv;
 #pragma unroll
@@ -449,7 +458,7 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                             }
                             if constexpr (EPI != LECCR_EPI_NONE) {
                                 f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
-                                if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) {
+                                if constexpr (NEED_AUX) {
                                     const bf16x8 xv = xpre[(2 * mi + hh) & 1][h8];
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) { x0[e] = (float)xv[e]; x1[e] = (float)xv[4 + e]; }
@@ -460,18 +469,19 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                             if constexpr ((FLAGS & F_RES) != 0) {
                                 bf16x8 rv;
                                 if constexpr (!NEED_AUX) rv = xpre[(2 * mi + hh) & 1][h8];
-                                else rv = *reinterpret_cast<const bf16x8*>(a.residual + (ok ? m * a.ldr + ncol + 8 * h8 : 0));
+                                else rv = *reinterpret_cast<const bf16x8*>(a.residual + (ok ? m * a.ldr + ncol : 0));
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { v0[e] += (float)rv[e]; v1[e] += (float)rv[4 + e]; }
                             }
                             bf16x8 ov;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { ov[e] = (bf16_t)v0[e]; ov[4 + e] = (bf16_t)v1[e]; }
+                            if constexpr ((W4_EXP & 32) != 0) { asm volatile("" ::"v"(ov)); } else
                             if (ok && store_c) *reinterpret_cast<bf16x8*>(a.C + off) = ov;
                             if constexpr ((FLAGS & F_Q8_BF8) != 0) {
                                 if (ok) {
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) { cs[8 * h8 + e] += v0[e]; cs[8 * h8 + 4 + e] += v1[e]; }
+                                    for (int e = 0; e < 4; ++e) { cs[e] += v0[e]; cs[4 + e] += v1[e]; }
                                 }
                             }
                             if constexpr ((FLAGS & F_Q8) != 0) {
@@ -491,14 +501,19 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                                     w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
                                     w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
                                 }
-                                if (ok) *reinterpret_cast<int2*>(a.c8 + m * a.ldc8 + ncol + 8 * h8) = int2{w0, w1};
+                                if (ok) *reinterpret_cast<int2*>(a.c8 + m * a.ldc8 + ncol) = int2{w0, w1};
                             }
                         }
                     }
                 }
             };
-            if (interior) tiles(std::false_type{});
-            else tiles(std::true_type{});
+            if constexpr ((W4_EXP & 16) != 0) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(acc[i]));
+            } else {
+                if (interior) tiles(std::false_type{});
+                else tiles(std::true_type{});
+            }
             // every ordinary load of the epilogue retired, visibly to hipcc's waitcnt pass (no vmcnt(0) sneaks into the K loop)
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_sched_barrier(0);
