@@ -745,7 +745,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                             bf16x8 ov;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) { ov[r] = (bf16_t)v0[r]; ov[4 + r] = (bf16_t)v1[r]; }
+#ifdef G256_EXP_NOSTORE
+                            asm volatile("" ::"v"(ov));            // diagnostic build: the epilogue without its C stores (wrong results)
+#else
                             if (ok) *reinterpret_cast<bf16x8*>(cptr) = ov;
+#endif
                             cptr += step8;
                         }
                     }

@@ -148,7 +148,7 @@ __device__ __forceinline__ void issue_piece(const Args& a, const Cursor& c, int 
 // are the rest of the same K-tile; front-loaded so that the last piece has two k-steps to land before vmcnt(0).
 #ifndef W4_EXP
 #define W4_EXP 0          // diagnostic builds: 1 no vmcnt wait, 2 no DMA in the loop, 4 no barrier, 8 no fragment reads, 16 no epilogue at all,
-                          // 32 epilogue without its global stores, 64 one K-tile per item (wrong results)
+                          // 32 epilogue without its global stores, 64 one K-tile per item, 128 no drain behind the epilogue (wrong results)
 #endif
 constexpr int N3 = 8;     // pieces issued in k-step 3
 __host__ __device__ constexpr int piece_at(int ks, int i) {
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                 else tiles(std::true_type{});
             }
             // every ordinary load of the epilogue retired, visibly to hipcc's waitcnt pass (no vmcnt(0) sneaks into the K loop)
-            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if constexpr (!(W4_EXP & 128)) __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (j + 1 < n_mine) {
