@@ -12,15 +12,15 @@ def total(c):
     f = glob.glob('$R/gpurun_out/pmc_traffic_%s/**/*counter_collection.csv' % c, recursive=True)[0]
     s, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if 'gemm256_kernel' in r['Kernel_Name'] and r['Counter_Name'] == c:
+        if 'gemm256' in r['Kernel_Name'] and r['Counter_Name'] == c:        # gemm256_kernel (8-wave NT / TN), gemm256t4_kernel (4-wave TN)
             s += float(r['Counter_Value']); n += 1
     return s, n
 fs, nf = total('FETCH_SIZE'); ws, nw = total('WRITE_SIZE')
 assert nf == nw and nf > 0, (nf, nw)
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --roofline-steps 0 (scripts/pmc_traffic.sh)",
-       "kernel_family": "gemm256_kernel (all instantiations)", "launches": nf, "fetch_size_kb_sum": fs, "write_size_kb_sum": ws,
+       "kernel_family": "gemm256 family (gemm256_kernel: 8-wave NT / TN instantiations; gemm256t4_kernel: 4-wave TN weight gradient)", "launches": nf, "fetch_size_kb_sum": fs, "write_size_kb_sum": ws,
        "correction": "FETCH_SIZE x2 on gfx950 for 16 B/lane streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE as reported",
        "hbm_bytes_per_launch": (2 * fs + ws) * 1024 / nf}
-json.dump(out, open('$R/gpurun_out/r02_gemm256_hbm_traffic.json', 'w'), indent=1)
+json.dump(out, open('$R/gpurun_out/r03_gemm256_hbm_traffic.json', 'w'), indent=1)
 print(json.dumps(out)[:400])
 PY
