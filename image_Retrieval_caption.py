@@ -37,6 +37,13 @@ class _PassThroughTokenizer:
         return text
 
 
+def clip_tokenize(texts):
+    """caption_encoder_name 'clip': the reference tokenises generated captions with its own `clip` package (clip.tokenize,
+    image_Retrieval_caption.py:26, 56, 129) - like the `dataset` package it must be importable (the BPE vocabulary ships with it)."""
+    from clip import tokenize
+    return tokenize(texts, truncate=True)
+
+
 def train(model, data_loader, optimizer, tokenizer, epoch, device, scheduler, config):
     """image_Retrieval_caption.py:28-81."""
     model.train()
@@ -51,7 +58,10 @@ def train(model, data_loader, optimizer, tokenizer, epoch, device, scheduler, co
     for i, (image, text_ls, captions, idx, cap_idx) in enumerate(metric_logger.log_every(batches, 50, header)):
         # tokenised in the loader workers (--tokenize_in_workers: TokenizingCollate) or here, as the reference does
         text_inputs = [tokenize_or_pass(tokenizer, text, config['max_tokens'], device) for text in text_ls]
-        captions = tokenize_or_pass(tokenizer, captions, config['max_tokens'], device)
+        if config.get('caption_encoder_name', 'mbert') == 'clip':      # image_Retrieval_caption.py:55-56: CLIP token ids [b, 77]
+            captions = captions.to(device) if torch.is_tensor(captions) else clip_tokenize(captions).to(device)
+        else:
+            captions = tokenize_or_pass(tokenizer, captions, config['max_tokens'], device)
         losses = model(image, text_inputs, captions=captions, idx=idx, epoch=epoch, cap_idx=cap_idx)
         loss = losses[0] + losses[1] + losses[2] + losses[3] + losses[4]
         optimizer.zero_grad()

@@ -201,6 +201,14 @@ int leccr_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, int64_t b, int64_t heads,
                    int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                    int dtype, float drop_p, uint64_t seed, void* stream);
+/* _causal: self-attention in which query i sees keys j <= i only, no dropout - CLIP's text transformer (clip/model.py:328-334, 354),
+ * the caption encoder of caption_encoder_name = 'clip' (models/model_retrieval_caption.py:57-58).  Generic kernels (a 77-token problem). */
+int leccr_attn_fwd_causal(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, int64_t b,
+                          int64_t heads, int64_t L, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int dtype,
+                          void* stream);
+int leccr_attn_bwd_causal(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                          const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, int64_t b, int64_t heads, int64_t L,
+                          int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int dtype, void* stream);
 /* _q8 (compute_dtype 'fp8'): the same calls plus per-tensor scaled fp8 copies of the outputs for the scaled-MFMA products that consume
  * them, under `site` = {amax, scale, 1/scale, fmt} with the contract of leccr_fp8_quantize (quantised from the f32 values, site.amax
  * accumulates max |value|): o8 [b*Lq, heads*hd] e4m3 (the out_proj input), dq8 / dk8 / dv8 e5m2 under ONE site (the three column

@@ -51,6 +51,8 @@ _SIGS = {
     'leccr_attn_fwd': ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, f32, C.c_uint64, vp], C.c_int),
     'leccr_attn_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64,
                         C.c_int, f32, C.c_uint64, vp], C.c_int),
+    'leccr_attn_fwd_causal': ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, vp], C.c_int),
+    'leccr_attn_bwd_causal': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_attn_fwd_q8': ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, f32, C.c_uint64, vp, i64, vp, vp], C.c_int),
     'leccr_attn_bwd_q8': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64,
                            C.c_int, f32, C.c_uint64, vp, vp, vp, i64, vp, vp], C.c_int),

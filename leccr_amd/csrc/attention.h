@@ -8,6 +8,7 @@ struct AttnDims {
     int64_t b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo;
     DropCfg drop;       // attention-probability dropout (thr == 0: off)
     bool dropout;
+    bool causal = false;   // key j visible to query i only for j <= i (CLIP's text transformer, clip/model.py:328-334); generic kernels only
 };
 
 template <typename T>

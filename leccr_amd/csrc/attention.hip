@@ -25,15 +25,21 @@ using namespace leccr;
 
 static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
                          int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
-                         int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream, const AttnQ8* q8, bool* fused) {
+                         int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream, const AttnQ8* q8, bool* fused,
+                         bool causal = false) {
     LECCR_REQUIRE(q && k && v && o && lse, LECCR_EINVAL, "attn_fwd: null pointer");
     LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_fwd: drop_p must be in [0,1)");
     LECCR_REQUIRE(b * heads * Lq * Lk < (1ll << 32) || drop_p == 0.f, LECCR_EINVAL, "attn_fwd: dropout index space exceeds 2^32");
-    const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
+    AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
+    D.causal = causal;
     if (int rc = check_dims("attn_fwd", D, dtype)) return rc;
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_FWD, 4.0 * (double)b * heads * Lq * Lk * hd, st);
+    if (causal) {                        // the causal mask exists in the generic kernels only (77-token CLIP text tower: a small problem)
+        g_last_attn_kernel = 0;
+        return dtype == LECCR_F32 ? attn_generic_fwd<float>(q, k, v, o, lse, kmask, D, st) : attn_generic_fwd<bf16_t>(q, k, v, o, lse, kmask, D, st);
+    }
     if (!g_force_generic_attn && attn_mfma_supported(D, dtype) && !(thin_first() && attn_thin_kind(D, dtype))) {
         g_last_attn_kernel = 1;
         return attn_mfma_fwd(q, k, v, o, lse, kmask, D, st, q8, fused);
@@ -70,20 +76,35 @@ extern "C" int leccr_attn_fwd_q8(const void* q, const void* k, const void* v, vo
     return rc;
 }
 
+// Causal self-attention (key j visible to query i only for j <= i; no dropout): CLIP's text transformer (clip/model.py:328-334, 354), the
+// caption encoder of caption_encoder_name = 'clip' (models/model_retrieval_caption.py:57-58).  Generic kernels, Lq == Lk.
+extern "C" int leccr_attn_fwd_causal(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask,
+                                     int64_t b, int64_t heads, int64_t L, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                     int dtype, void* stream) {
+    return attn_fwd_impl(q, k, v, o, lse, kmask, b, heads, L, L, hd, ldq, ldk, ldv, ldo, dtype, 0.f, 0, stream, nullptr, nullptr, true);
+}
+
 extern "C" int leccr_set_attn_variant(int v) { return attn_set_variant(v); }
 extern "C" int leccr_last_attn_kernel(void) { return g_last_attn_kernel; }
 
 static int attn_bwd_impl(const void* q, const void* k, const void* v, const void* o, const void* dout,
                          const float* lse, const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta,
                          int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
-                         int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream, const AttnQ8* q8, bool* fused) {
+                         int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream, const AttnQ8* q8, bool* fused,
+                         bool causal = false) {
     LECCR_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && delta, LECCR_EINVAL, "attn_bwd: null pointer");
     LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_bwd: drop_p must be in [0,1)");
-    const AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
+    AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
+    D.causal = causal;
     if (int rc = check_dims("attn_bwd", D, dtype)) return rc;
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_BWD, 10.0 * (double)b * heads * Lq * Lk * hd, st);
+    if (causal) {
+        g_last_attn_kernel = 0;
+        return dtype == LECCR_F32 ? attn_generic_bwd<float>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st)
+                                  : attn_generic_bwd<bf16_t>(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
+    }
     if (!g_force_generic_attn && attn_mfma_supported(D, dtype) && !(thin_first() && attn_thin_kind(D, dtype))) {
         g_last_attn_kernel = 1;
         return attn_mfma_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st, q8, fused);
@@ -127,4 +148,11 @@ extern "C" int leccr_attn_bwd_q8(const void* q, const void* k, const void* v, co
         if (rc == LECCR_OK && b * Lk > 0) rc = leccr_fp8_quantize(dv, dv8, b * Lk, heads * hd, ldv, ld8, dtype, 1, site, stream);
     }
     return rc;
+}
+
+extern "C" int leccr_attn_bwd_causal(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                                     const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, int64_t b, int64_t heads, int64_t L,
+                                     int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int dtype, void* stream) {
+    return attn_bwd_impl(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, b, heads, L, L, hd, ldq, ldk, ldv, ldo, dtype, 0.f, 0, stream,
+                         nullptr, nullptr, true);
 }

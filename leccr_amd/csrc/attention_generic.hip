@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void attn_generic_fwd_kernel(const T* __restri
     float mx = -INFINITY;
     for (int64_t j = lane; j < D.Lk; j += 64) {
         float s = -INFINITY;
-        if (!kmask || !kmask[bb * D.Lk + j]) {
+        if ((!kmask || !kmask[bb * D.Lk + j]) && !(D.causal && j > i)) {
             const T* kp = k + (bb * D.Lk + j) * D.ldk + h * D.hd;
             float acc = 0.f;
             for (int d = 0; d < D.hd; ++d) acc = fmaf(qs[d], to_f32(kp[d]), acc);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_generic_dq_kernel(const T* __restric
     const float L = lse[row], dl = delta[row];
     for (int64_t j = lane; j < D.Lk; j += 64) {
         float dsv = 0.f;
-        if (!kmask || !kmask[bb * D.Lk + j]) {
+        if ((!kmask || !kmask[bb * D.Lk + j]) && !(D.causal && j > i)) {
             const T* kp = k + (bb * D.Lk + j) * D.ldk + h * D.hd;
             const T* vp = v + (bb * D.Lk + j) * D.ldv + h * D.hd;
             float s = 0.f, dp = 0.f;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void attn_generic_dkv_kernel(const T* __restri
     const bool masked = kmask && kmask[bb * D.Lk + j];
     for (int64_t i = lane; i < D.Lq; i += 64) {
         float p = 0.f, dsv = 0.f;
-        if (!masked) {
+        if (!masked && !(D.causal && j > i)) {
             const T* qp = q + (bb * D.Lq + i) * D.ldq + h * D.hd;
             const T* dop = dout + (bb * D.Lq + i) * D.ldo + h * D.hd;
             float s = 0.f, dp = 0.f;

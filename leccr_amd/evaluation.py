@@ -113,10 +113,19 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
             continue
         image = image.to(device)
         image_feat, _ = model.get_vision_embeds(image)
-        ci = tokenizer(generated_captions, padding='max_length', truncation=True, max_length=config['max_tokens'],
-                       return_tensors='pt').to(device)
-        caption_embed = model.get_caption_embeds(ci.input_ids, ci.attention_mask)
-        key_padding_mask = ~ci.attention_mask.bool()
+        if config.get('caption_encoder_name', 'mbert') == 'clip':       # image_Retrieval_caption.py:128-136: CLIP token ids, padding id 0
+            if torch.is_tensor(generated_captions):
+                cap_ids = generated_captions.to(device)
+            else:
+                from clip import tokenize as clip_tokenize                 # the reference's package (BPE vocabulary ships with it)
+                cap_ids = clip_tokenize(generated_captions, truncate=True).to(device)
+            caption_embed = model.get_caption_embeds(cap_ids, None)
+            key_padding_mask = cap_ids == 0
+        else:
+            ci = tokenizer(generated_captions, padding='max_length', truncation=True, max_length=config['max_tokens'],
+                           return_tensors='pt').to(device)
+            caption_embed = model.get_caption_embeds(ci.input_ids, ci.attention_mask)
+            key_padding_mask = ~ci.attention_mask.bool()
         image_feat, _, _ = model.interaction_with_caption(image_embeds=image_feat, caption_embeds=caption_embed,
                                                           key_padding_mask=key_padding_mask)
         image_embeds.append(model.get_features(image_embeds=image_feat.transpose(0, 1).contiguous()))

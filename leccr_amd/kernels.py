@@ -154,8 +154,9 @@ def _attn_args(q, k, v):
     return q.shape[0], q.shape[1], k.shape[1]
 
 
-def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0, q8_site=None):
-    """q8_site (a primed Fp8Site, bf16 only): returns (o, lse, o8) with o8 [b * Lq, d] the e4m3 copy of o under that site."""
+def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0, q8_site=None, causal=False):
+    """q8_site (a primed Fp8Site, bf16 only): returns (o, lse, o8) with o8 [b * Lq, d] the e4m3 copy of o under that site.
+    causal: query i sees keys j <= i only (self-attention, no dropout: CLIP's text transformer)."""
     b, Lq, Lk = _attn_args(q, k, v)
     d = q.shape[2]
     hd = d // heads
@@ -163,6 +164,11 @@ def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0, q8_site=None):
     lse = torch.empty(b, heads, Lq, device=q.device, dtype=torch.float32)
     if kmask is not None:
         assert kmask.dtype == torch.uint8 and kmask.shape == (b, Lk) and kmask.is_contiguous()
+    if causal:
+        assert Lq == Lk and drop_p == 0.0 and q8_site is None
+        check(lib().leccr_attn_fwd_causal(ptr(q), ptr(k), ptr(v), ptr(o), ptr(lse), ptr(kmask), b, heads, Lq, hd,
+                                          q.stride(1), k.stride(1), v.stride(1), o.stride(1), dtype_code(q), stream()), 'leccr_attn_fwd_causal')
+        return o, lse
     if q8_site is not None:
         assert q8_site.primed and q8_site.fmt == 0 and d % 8 == 0
         o8 = torch.empty(b * Lq, d, device=q.device, dtype=q8_site.torch_dtype)
@@ -176,7 +182,7 @@ def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0, q8_site=None):
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None, drop_p=0.0, seed=0, q8=None):
+def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None, drop_p=0.0, seed=0, q8=None, causal=False):
     """q8 = (dq8, dk8, dv8, site): e5m2 copies of the three gradients (views of one packed [b, L, 3 d] byte tensor) under one primed site."""
     b, Lq, Lk = _attn_args(q, k, v)
     d = q.shape[2]
@@ -189,6 +195,12 @@ def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None
     assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
     # workspace: two rows of constants per (b, head, query), queries padded to a multiple of 64 (see leccr_hip.h)
     delta = torch.empty(2 * b * heads * ((Lq + 63) // 64 * 64), dtype=torch.float32, device=q.device)
+    if causal:
+        assert Lq == Lk and drop_p == 0.0 and q8 is None
+        check(lib().leccr_attn_bwd_causal(ptr(q), ptr(k), ptr(v), ptr(o), ptr(dout), ptr(lse), ptr(kmask), ptr(dq), ptr(dk), ptr(dv),
+                                          ptr(delta), b, heads, Lq, hd, q.stride(1), k.stride(1), v.stride(1), o.stride(1),
+                                          dtype_code(q), stream()), 'leccr_attn_bwd_causal')
+        return dq, dk, dv
     if q8 is not None:
         dq8, dk8, dv8, site = q8
         assert site.primed and site.fmt == 1 and dq8.stride(1) == dk8.stride(1) == dv8.stride(1) and dq8.stride(2) == 1

@@ -1,7 +1,9 @@
 """CLIP vision tower with the reference's module tree (clip/model.py:171-240, 246-346) over the HIP ops.
 
-Only the ViT image path is live.  The CLIP text tower that the reference allocates and never uses
-(clip_encoder.transformer.*, token_embedding, ...) is kept as inert parameters so checkpoints load key for key.
+The ViT image path is live in every configuration.  The CLIP text tower (clip_encoder.transformer.*, token_embedding, ...) receives no
+gradient in any configuration of the reference and stays outside the parameter arena; with caption_encoder_name = 'clip'
+(models/model_retrieval_caption.py:57-58) it runs forward-only, under no_grad, as the caption encoder: encode_text below, on static compute
+copies made once (prepare_text_tower).
 """
 import numpy as np
 import torch
@@ -119,6 +121,35 @@ class CLIP(nn.Module):
 
     def float(self):
         return self
+
+    # ------------------------------------------------------------------ text tower (caption_encoder_name = 'clip')
+    def prepare_text_tower(self, dtype):
+        """Compute copies of the text tower's matrices in `dtype` (they are never trained - the reference encodes captions under
+        no_grad and nothing else reaches these parameters - so the copies are made once), causal blocks."""
+        for blk in self.transformer.resblocks:
+            blk.causal, blk.fp8 = True, False
+            for w in (blk.attn.in_proj_weight, blk.attn.out_proj.weight, blk.mlp.c_fc.weight, blk.mlp.c_proj.weight):
+                w._lp, w._lpt = w.data.to(dtype).contiguous(), None
+        tp = self.text_projection
+        tp._lp, tp._lpt = tp.data.to(dtype).contiguous(), tp.data.t().to(dtype).contiguous()
+        self._text_zero_type = torch.zeros(self.token_embedding.weight.shape[1], device=tp.device, dtype=torch.float32)
+        self._text_ready = True
+
+    @torch.no_grad()
+    def encode_text(self, text, return_hidden=False):
+        """clip/model.py:348-365: token + positional embedding -> causal transformer -> ln_final on ALL tokens @ text_projection;
+        x = the row of each sequence's highest token id (the EOT token).  Forward only."""
+        assert getattr(self, '_text_ready', False), 'the CLIP text tower is live for caption_encoder_name = "clip" only'
+        assert text.dim() == 2 and text.shape[1] == self.positional_embedding.shape[0], 'captions must be tokenised to context_length'
+        from .. import kernels as K
+        x = K.bert_embed_fwd(text.contiguous(), self.token_embedding.weight.data, self.positional_embedding.data, self._text_zero_type,
+                             self.compute_dtype)                                   # word[ids] + position (the type row is zero)
+        x = self.transformer(x)
+        hidden = ops.LnProjFn.apply(x, self.ln_final.weight, self.ln_final.bias, self.text_projection)
+        x = hidden[torch.arange(hidden.shape[0], device=hidden.device), text.argmax(dim=-1)]
+        if return_hidden:
+            return x, hidden
+        return x
 
     def encode_image(self, image, return_hidden=False):
         """clip/model.py:340-346: ln_post on ALL tokens then @ proj; returns (cls, hidden) when return_hidden."""

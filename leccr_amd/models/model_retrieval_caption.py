@@ -27,8 +27,8 @@ class RetrievalModel(XVLMBase):
         if self.caption_encoder_name == 'mbert':
             self.caption_encoder = self.text_encoder
             self.caption_width = self.text_width
-        elif self.caption_encoder_name == 'clip':
-            raise NotImplementedError("caption_encoder_name 'clip' is not used by any shipped config")
+        elif self.caption_encoder_name == 'clip':      # CLIP's text tower encodes the captions (forward only, never trained)
+            self.caption_width = self.vision_width
         else:
             print('caption_width error')
             exit()
@@ -47,6 +47,9 @@ class RetrievalModel(XVLMBase):
         if self.caption_encoder_name == 'mbert':
             self._ensure_runtime()
             return self.caption_encoder(text_ids, attention_mask=text_atts, return_dict=True).last_hidden_state
+        if self.caption_encoder_name == 'clip':
+            self._ensure_runtime()
+            return self.clip_encoder.encode_text(text_ids, return_hidden=True)[-1]
         print('caption_encoder_name error!')
         exit()
 
@@ -125,7 +128,11 @@ class RetrievalModel(XVLMBase):
 
         def pad(x):
             return x if x.shape[1] == L else torch.nn.functional.pad(x, (0, L - x.shape[1]))
-        cap_ids, cap_atts = captions.input_ids, captions.attention_mask
+        if self.caption_encoder_name == 'clip':     # captions = CLIP token ids [b, context_length], padding id 0 (model_retrieval_caption.py:158-167)
+            cap_ids = captions
+            cap_atts = (captions != 0).to(torch.int64)
+        else:
+            cap_ids, cap_atts = captions.input_ids, captions.attention_mask
 
         def caption_side():
             with torch.no_grad():

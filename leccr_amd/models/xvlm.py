@@ -259,6 +259,8 @@ class XVLMBase(nn.Module):
             a.need_transposed(layer._qkv_w)
         if self.fp8:
             self._enable_fp8(a, dev)
+        if getattr(self, 'caption_encoder_name', None) == 'clip' and self.clip_encoder is not None:
+            self.clip_encoder.prepare_text_tower(self.compute_dtype)        # forward-only caption encoder: static compute copies
         a.refresh()
         return a
 
@@ -318,6 +320,8 @@ class XVLMBase(nn.Module):
     def load_state_dict(self, *args, **kw):
         r = super().load_state_dict(*args, **kw)
         self.refresh_weights()
+        if self.arena is not None and getattr(self, 'caption_encoder_name', None) == 'clip' and self.clip_encoder is not None:
+            self.clip_encoder.prepare_text_tower(self.compute_dtype)        # (outside the arena: their copies are made here)
         return r
 
     # ------------------------------------------------------------------ reference API

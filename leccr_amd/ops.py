@@ -542,7 +542,10 @@ class ViTBlockFn(torch.autograd.Function):
         qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8, x8=h1_8).view(b, N, 3 * d)
         # (fp8: the attention kernel writes the e4m3 copy of o that out_proj multiplies, the backward the e5m2 copy of dqkv for in_proj)
         o_site = _q8_site(blk.fp8, M, blk.attn.out_proj.weight, '_xsite')
-        if o_site is not None and o_site.primed:
+        if getattr(blk, 'causal', False):              # CLIP's text transformer (clip/model.py:286, 328-334): key j <= query i
+            o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads, causal=True)
+            o_8 = None
+        elif o_site is not None and o_site.primed:
             o, lse, o_8 = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads, q8_site=o_site)
         else:
             o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
@@ -607,10 +610,10 @@ class ViTBlockFn(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         g_site = _q8_site(blk.fp8, b * N, blk.attn.in_proj_weight, '_gsite')
         dqkv8 = None
-        if g_site is not None and g_site.primed:
+        if g_site is not None and g_site.primed and not getattr(blk, 'causal', False):
             dqkv8 = torch.empty(qkv.shape, device=qkv.device, dtype=g_site.torch_dtype)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
-                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:],
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], causal=getattr(blk, 'causal', False),
                    q8=None if dqkv8 is None else (dqkv8[..., :d], dqkv8[..., d:2 * d], dqkv8[..., 2 * d:], g_site))
         dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight, None if dqkv8 is None else _rows(dqkv8))
         dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)

@@ -186,7 +186,7 @@ class _FlashBF16(torch.autograd.Function):
         return r((ds @ k) * ctx.scale), r((ds.transpose(-1, -2) @ q) * ctx.scale), r(p.bfloat16().float().transpose(-1, -2) @ do), None, None
 
 
-def attention_core(q, k, v, heads, key_padding_mask=None):
+def attention_core(q, k, v, heads, key_padding_mask=None, causal=False):
     """Scaled dot-product attention, batch-major.  q [b,Lq,d], k/v [b,Lk,d]; mask [b,Lk] True = ignore.
 
     Semantics of torch nn.MultiheadAttention / HF BertSelfAttention: scores/sqrt(head_dim), masked keys get
@@ -201,7 +201,9 @@ def attention_core(q, k, v, heads, key_padding_mask=None):
     s = (qh @ kh.transpose(-1, -2)) / math.sqrt(hd)
     if key_padding_mask is not None:
         s = s.masked_fill(key_padding_mask[:, None, None, :], float('-inf'))
-    if _LOWP:
+    if causal:              # CLIP.build_attention_mask (clip/model.py:328-334): -inf above the diagonal
+        s = s.masked_fill(torch.ones(Lq, Lk, dtype=torch.bool).triu(1), float('-inf'))
+    if _LOWP and not causal:
         o = _FlashBF16.apply(qh, kh, vh, key_padding_mask, 1.0 / math.sqrt(hd))
     else:
         p = torch.softmax(s, dim=-1)
@@ -209,7 +211,7 @@ def attention_core(q, k, v, heads, key_padding_mask=None):
     return o.permute(0, 2, 1, 3).reshape(b, Lq, d)
 
 
-def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None, keep_f32=False, fp8=False):
+def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None, keep_f32=False, fp8=False, causal=False):
     """nn.MultiheadAttention with packed in_proj ordered q,k,v (clip/model.py:175,187; attention.py:27,47).
     Batch-major in/out."""
     w, bias = sd[pre + 'in_proj_weight'], sd[pre + 'in_proj_bias']
@@ -221,7 +223,7 @@ def torch_mha(sd, pre, query, memory, heads, key_padding_mask=None, keep_f32=Fal
         q = linear(query, w[:d], bias[:d])
         k = linear(memory, w[d:2 * d], bias[d:2 * d])
         v = linear(memory, w[2 * d:], bias[2 * d:])
-    o = attention_core(q, k, v, heads, key_padding_mask)
+    o = attention_core(q, k, v, heads, key_padding_mask, causal=causal)
     return linear(o, sd[pre + 'out_proj.weight'], sd[pre + 'out_proj.bias'], keep_f32=keep_f32, fp8=fp8)
 
 
@@ -253,6 +255,25 @@ def vit_trunk(sd, pre, image):
         x = _r(x + linear(h, sd[bp + 'mlp.c_proj.weight'], sd[bp + 'mlp.c_proj.bias'], keep_f32=True, fp8=True))
         i += 1
     return x
+
+
+def encode_text_hidden(sd, pre, text):
+    """CLIP.encode_text(return_hidden=True)[-1] (clip/model.py:348-365): token + positional embedding -> transformer with the causal
+    mask -> ln_final on all tokens @ text_projection.  pre = 'clip_encoder.'; heads = width // 64 as CLIP.__init__ receives them from
+    build_model (clip/model.py:427-429)."""
+    x = _r(sd[pre + 'token_embedding.weight'][text] + sd[pre + 'positional_embedding'])
+    d = x.shape[-1]
+    heads = max(1, d // 64)
+    i = 0
+    while f'{pre}transformer.resblocks.{i}.ln_1.weight' in sd:
+        bp = f'{pre}transformer.resblocks.{i}.'
+        h = layer_norm(x, sd[bp + 'ln_1.weight'], sd[bp + 'ln_1.bias'], 1e-5)
+        x = _r(x + torch_mha(sd, bp + 'attn.', h, h, heads, keep_f32=True, causal=True))
+        h = layer_norm(x, sd[bp + 'ln_2.weight'], sd[bp + 'ln_2.bias'], 1e-5)
+        h = _r(quick_gelu(linear(h, sd[bp + 'mlp.c_fc.weight'], sd[bp + 'mlp.c_fc.bias'], keep_f32=True)))
+        x = _r(x + linear(h, sd[bp + 'mlp.c_proj.weight'], sd[bp + 'mlp.c_proj.bias'], keep_f32=True))
+        i += 1
+    return _r(layer_norm(x, sd[pre + 'ln_final.weight'], sd[pre + 'ln_final.bias'], 1e-5) @ _w(sd[pre + 'text_projection']))
 
 
 def encode_image(sd, pre, image):
@@ -430,7 +451,11 @@ def retrieval_forward(sd, cfg, image, ids_s, mask_s, ids_t, mask_t, ids_c, mask_
     """RetrievalModel.forward (models/model_retrieval_caption.py:154-199) -> the 5 weighted losses."""
     vis = encode_image(sd, 'clip_encoder.visual.', image)
     with torch.no_grad():
-        cap_hidden = bert_forward(sd, 'text_encoder.', ids_c, mask_c, text_heads)
+        if cfg.get('caption_encoder_name', 'mbert') == 'clip':      # ids_c = CLIP token ids, padding id 0 (:158-167); mask_c unused
+            cap_hidden = encode_text_hidden(sd, 'clip_encoder.', ids_c)
+            mask_c = ids_c != 0
+        else:
+            cap_hidden = bert_forward(sd, 'text_encoder.', ids_c, mask_c, text_heads)
     after_image, after_caption, ori_caption = interaction_with_caption(sd, vis, cap_hidden, ~mask_c.bool())
     loss_cv = caption_vision_loss(sd, ori_caption, vis, idx) * cfg['weight_cv_loss']
     loss_reg = caption_regularization(ori_caption)

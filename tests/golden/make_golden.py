@@ -151,7 +151,7 @@ def fixture_bert():
     print('bert_tiny', h.shape, float(h.abs().mean()))
 
 
-def build_model(clip_model, xvlm, seed=31):
+def build_model(clip_model, xvlm, seed=31, cfg=None):
     """Reference RetrievalModel at tiny geometry with seeded weights."""
     def _clip(config=None):
         return clip_model.CLIP(**MODEL_VIT).float(), MODEL_VIT['embed_dim']
@@ -164,7 +164,7 @@ def build_model(clip_model, xvlm, seed=31):
     xvlm.build_text_encoder = _bert
     from models.model_retrieval_caption import RetrievalModel
     torch.manual_seed(seed)
-    model = RetrievalModel(dict(TINY_CFG))
+    model = RetrievalModel(dict(cfg or TINY_CFG))
     model.init_caption_encoder()
     randomize_(model, seed)
     return model.eval()
@@ -210,6 +210,32 @@ def fixture_model_w1(clip_model, xvlm):
     out.update(grads_np(model))
     np.savez_compressed(os.path.join(OUT, 'model_tiny_w1.npz'), **out)
     print('model_tiny_w1 losses', out['losses'])
+
+
+def fixture_model_clipcap(clip_model, xvlm):
+    """caption_encoder_name = 'clip' (model_retrieval_caption.py:37-38, 57-58, 158-167): the captions are CLIP token ids
+    [b, context_length] encoded by clip_encoder.encode_text under no_grad; key padding = (ids == 0)."""
+    model = build_model(clip_model, xvlm, seed=37, cfg=dict(TINY_CFG, caption_encoder_name='clip'))
+    batch = make_batch(38, 8)
+    g = torch.Generator().manual_seed(39)
+    L, vocab = MODEL_VIT['context_length'], MODEL_VIT['vocab_size']
+    cap = torch.randint(1, vocab - 1, (8, L), generator=g)
+    lens = torch.randint(3, L + 1, (8,), generator=g)
+    lens[0] = L
+    for i in range(8):
+        cap[i, lens[i] - 1] = vocab - 1                 # the EOT token is the highest id (clip/model.py:358-359)
+        cap[i, lens[i]:] = 0
+    with torch.no_grad():
+        c = model.get_caption_embeds(cap, None)
+    losses = model(batch['image'], [Enc(batch['ids_s'], batch['mask_s']), Enc(batch['ids_t'], batch['mask_t'])],
+                   captions=cap, idx=batch['idx'])
+    sum(losses).backward()
+    out = {k: v_.numpy() for k, v_ in batch.items() if k not in ('ids_c', 'mask_c')}
+    out.update({'captions': cap.numpy(), 'caption_hidden': c.numpy(), 'losses': np.array([float(l) for l in losses], dtype=np.float64)})
+    out.update(sd_np(model))
+    out.update(grads_np(model))
+    np.savez_compressed(os.path.join(OUT, 'model_tiny_clipcap.npz'), **out)
+    print('model_tiny_clipcap losses', out['losses'])
 
 
 def _w2_worker(rank, world, port, ret):
@@ -596,7 +622,11 @@ def main():
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29610')
         dist.init_process_group('gloo', rank=0, world_size=1)
     if only:            # python tests/golden/make_golden.py full  -> only the full-geometry fixtures (minutes of CPU)
-        assert only <= {'full', 'captions', 'b32'}, only
+        assert only <= {'full', 'captions', 'b32', 'clipcap'}, only
+        if only == {'clipcap'}:
+            fixture_model_clipcap(clip_model, xvlm)
+            dist.destroy_process_group()
+            return
         if only == {'captions'}:
             fixture_caption_store()
             dist.destroy_process_group()
@@ -618,6 +648,7 @@ def main():
     fixture_vit(clip_model)
     fixture_bert()
     fixture_model_w1(clip_model, xvlm)
+    fixture_model_clipcap(clip_model, xvlm)
     fixture_losses(clip_model, xvlm)
     fixture_itm_eval()
     fixture_video_w1()

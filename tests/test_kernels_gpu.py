@@ -846,6 +846,43 @@ def test_attention_with_a_thin_side(K, b, heads, Lq, Lk, hd, masked, drop):
         assert e <= (3e-2 if hd == 64 else 1.5e-2) * s_, (name, e, s_)
 
 
+@pytest.mark.parametrize('dtype,b,heads,L,hd,masked', [(torch.float32, 3, 2, 77, 64, False), (torch.bfloat16, 3, 8, 77, 64, True),
+                                                      (torch.float32, 2, 1, 8, 64, True), (torch.float32, 2, 4, 20, 8, False)])
+def test_attention_causal(K, dtype, b, heads, L, hd, masked):
+    """leccr_attn_fwd_causal / _bwd_causal: query i sees keys j <= i (CLIP.build_attention_mask, clip/model.py:328-334) - against f64
+    with the additive upper-triangular -inf mask, with and without a key-padding mask on top."""
+    d = heads * hd
+    qkv = _rand((b, L, 3 * d), dtype, 130, 0.5)
+    q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+    qd = qkv.to(DEV)
+    kmask = None
+    if masked:
+        lens = torch.randint(2, L + 1, (b,), generator=torch.Generator().manual_seed(131))
+        kmask = (torch.arange(L)[None, :] >= lens[:, None]).to(torch.uint8)
+    km = kmask.to(DEV) if masked else None
+    o, lse = K.attn_fwd(qd[..., :d], qd[..., d:2 * d], qd[..., 2 * d:], heads, km, causal=True)
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    sp = lambda t: t.reshape(b, L, heads, hd).permute(0, 2, 1, 3)
+    sc = sp(qr) @ sp(kr).transpose(-1, -2) / math.sqrt(hd)
+    sc = sc.masked_fill(torch.ones(L, L, dtype=torch.bool).triu(1), float('-inf'))
+    if masked:
+        sc = sc.masked_fill(kmask.bool()[:, None, None, :], float('-inf'))
+    ref = (torch.softmax(sc, -1) @ sp(vr)).permute(0, 2, 1, 3).reshape(b, L, d)
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2
+    e, s_ = _err(o, ref)
+    assert e <= tol * s_, (e, s_)
+    e, s_ = _err(lse, torch.logsumexp(sc, -1).detach())
+    assert e <= 1e-4 * s_ + 1e-4
+    do = _rand((b, L, d), dtype, 132)
+    (ref * do.double()).sum().backward()
+    dqkv = torch.zeros_like(qd)
+    K.attn_bwd(qd[..., :d], qd[..., d:2 * d], qd[..., 2 * d:], o, do.to(DEV), lse, heads, km, dq=dqkv[..., :d], dk=dqkv[..., d:2 * d],
+               dv=dqkv[..., 2 * d:], causal=True)
+    for name, got, r in (('dq', dqkv[..., :d], qr.grad), ('dk', dqkv[..., d:2 * d], kr.grad), ('dv', dqkv[..., 2 * d:], vr.grad)):
+        e, s_ = _err(got, r)
+        assert e <= (1e-4 if dtype == torch.float32 else 3e-2) * s_, (name, e, s_)
+
+
 @pytest.mark.parametrize('Lq,Lk', [(70, 50), (40, 72)])        # short (<= 16 rows) last query tile / last key tile
 @pytest.mark.parametrize('dtype,hd', [(torch.float32, 64), (torch.bfloat16, 64), (torch.float32, 8)])
 def test_attention_dropout_matches_masked_reference(K, dtype, hd, Lq, Lk):

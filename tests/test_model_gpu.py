@@ -82,6 +82,39 @@ def test_reference_fixture_forward_backward_f32():
     assert n > 100 and not bad, bad[:8]
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_clip_caption_encoder_vs_reference_fixture(dtype):
+    """caption_encoder_name = 'clip': captions as CLIP token ids through clip_encoder.encode_text (causal generic attention,
+    leccr_attn_fwd_causal) under no_grad - caption hidden states, losses and all gradients against the reference's own run
+    (tests/golden/model_tiny_clipcap.npz); bf16 held loosely (tiny widths: the fixture is a wiring check there)."""
+    z = load_npz('model_tiny_clipcap.npz')
+    model = build(dict(clip_geometry=MODEL_VIT, text_config=TINY_BERT, compute_dtype=dtype, caption_encoder_name='clip'), weights(z))
+    cap = T(z['captions']).to(DEV)
+    with torch.no_grad():
+        c = model.get_caption_embeds(cap, None)
+    assert max_err(c, z['caption_hidden']) < (5e-5 if dtype == 'fp32' else 3e-2)
+    g = lambda k: T(z[k]).to(DEV)
+    losses = model(g('image'), [Enc(g('ids_s'), g('mask_s')), Enc(g('ids_t'), g('mask_t'))], captions=cap, idx=g('idx'))
+    got = np.array([float(l) for l in losses])
+    assert np.max(np.abs(got - z['losses'])) < (1e-4 if dtype == 'fp32' else 3e-2), (got, z['losses'])
+    model.arena.zero_grad()
+    sum(losses).backward()
+    if dtype == 'fp32':
+        named, bad, n = dict(model.named_parameters()), [], 0
+        for k, gr in z.items():
+            if k.startswith('g/'):
+                n += 1
+                if not grad_close(named[k[2:]].grad, gr, 2e-3, atol=2e-6):
+                    bad.append((k, max_err(named[k[2:]].grad, gr), float(np.abs(gr).max())))
+        assert n > 100 and not bad, bad[:8]
+    # the causal mask does what it says: changing a LATER token leaves the hidden states of earlier positions untouched
+    cap2 = cap.clone()
+    cap2[:, 5] = (cap2[:, 5] + 3) % 30 + 1
+    with torch.no_grad():
+        c2 = model.get_caption_embeds(cap2, None)
+    assert torch.equal(c2[:, :5], c[:, :5]) and not torch.equal(c2[:, 5:], c[:, 5:])
+
+
 def _with_lowp(lowp):
     """Context of the oracle's bf16-storage noise model (oracle.lowp) or a null context."""
     import contextlib

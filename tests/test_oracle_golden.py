@@ -92,6 +92,34 @@ def test_full_forward_backward_w1():
         assert sd[name].grad is None, name
 
 
+def test_clip_caption_encoder_full_forward_backward():
+    """caption_encoder_name = 'clip' (model_retrieval_caption.py:37-38, 57-58, 158-167): the captions go through CLIP's text tower
+    (clip/model.py:348-365, causal mask :328-334) under no_grad.  Caption hidden states, the five losses and every gradient of the
+    reference's own run; the text tower itself gets no gradient."""
+    z = load_npz('model_tiny_clipcap.npz')
+    sd = weights(z, requires_grad=True)
+    T_ = lambda k: torch.from_numpy(z[k])
+    cap = T_('captions')
+    with torch.no_grad():
+        hid = O.encode_text_hidden(sd, 'clip_encoder.', cap)
+    assert max_err(hid, z['caption_hidden']) < FWD_TOL
+    cfg = dict(TINY_CFG, caption_encoder_name='clip')
+    losses = O.retrieval_forward(sd, cfg, T_('image'), T_('ids_s'), T_('mask_s'), T_('ids_t'), T_('mask_t'), cap, None, T_('idx'),
+                                 text_heads=2)
+    got = np.array([float(l) for l in losses])
+    assert np.max(np.abs(got - z['losses'])) < 1e-5, (got, z['losses'])
+    sum(losses).backward()
+    checked = 0
+    for k, v in z.items():
+        if k.startswith('g/'):
+            assert grad_close(sd[k[2:]].grad, v, 5e-4), k
+            checked += 1
+    assert checked > 100
+    for name in ('clip_encoder.transformer.resblocks.0.attn.in_proj_weight', 'clip_encoder.token_embedding.weight',
+                 'clip_encoder.text_projection'):
+        assert sd[name].grad is None and ('g/' + name) not in z, name
+
+
 @pytest.mark.parametrize('name', ['itc_idx', 'itc_noidx', 'cap_itc', 'dstl', 'cv', 'reg'])
 def test_losses(name):
     z = load_npz('losses.npz')
