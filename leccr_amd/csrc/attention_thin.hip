@@ -51,7 +51,9 @@ struct TP {
     float* lse;
     float* ws;                 // thin-K backward with row splits: f32 [2][b][Lk][d] partial dK / dV (zeroed by the launcher)
     const uint8_t* kmask;
-    int64_t b, heads, Lq, Lk, ldq, ldk, ldv, ldo;
+    int64_t b, heads, Lq, Lk, ldq, ldk, ldv, ldo;      // heads: those of THIS column group (a launch covers d' = 64 EPL columns = whole heads)
+    int64_t heads_total;                               // .. of the problem; head0: first head of the group (lse rows, dropout indices)
+    int head0;
     int lph, nsplit;
     float scale;
     DropCfg drop;
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void thin_k_fwd_kernel(TP p) {
             l += s[j];
         }
         const float inv = l > 0.f ? 1.f / l : 0.f;
-        const int64_t row = (bb * p.heads + h) * p.Lq + i;
+        const int64_t row = (bb * p.heads_total + p.head0 + h) * p.Lq + i;
         if ((lane & (p.lph - 1)) == 0) p.lse[row] = l > 0.f ? mx + __logf(l) : INFINITY;
         float ov[EPL];
 #pragma unroll
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void thin_k_bwd_kernel(TP p) {
             l += s[j];
         }
         const float inv = l > 0.f ? 1.f / l : 0.f;
-        const int64_t row = (bb * p.heads + h) * p.Lq + i;
+        const int64_t row = (bb * p.heads_total + p.head0 + h) * p.Lq + i;
         float dm[KB], delta = 0.f;
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void thin_q_fwd_kernel(TP p) {
         if (lane == 0) {
             const int qi = r / heads, hh = r - qi * heads;
             invs[r] = l > 0.f ? 1.f / l : 0.f;
-            p.lse[(bb * p.heads + hh) * p.Lq + qi] = l > 0.f ? mx + __logf(l) : INFINITY;
+            p.lse[(bb * p.heads_total + p.head0 + hh) * p.Lq + qi] = l > 0.f ? mx + __logf(l) : INFINITY;
         }
     }
     __syncthreads();
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void thin_q_fwd_kernel(TP p) {
             for (int qi = 0; qi < QB; ++qi) {
                 if (qi < p.Lq) {
                     float pj = S[(qi * heads + h) * Lk + j] * invs[qi * heads + h];
-                    if (p.dropout) pj *= drop_mul(p.drop, (uint32_t)(((bb * p.heads + h) * p.Lq + qi) * p.Lk + j));
+                    if (p.dropout) pj *= drop_mul(p.drop, (uint32_t)(((bb * p.heads_total + p.head0 + h) * p.Lq + qi) * p.Lk + j));
 #pragma unroll
                     for (int e = 0; e < EPL; ++e) ov[qi][e] = fmaf(pj, vv[e], ov[qi][e]);
                 }
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void thin_q_bwd_kernel(TP p) {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) a = fmaf(gv[qi][e], ov[e], a);
             delta[qi] = head_sum(a, p.lph);
-            L[qi] = p.lse[(bb * p.heads + h) * p.Lq + qi];
+            L[qi] = p.lse[(bb * p.heads_total + p.head0 + h) * p.Lq + qi];
         } else {
 #pragma unroll
             for (int e = 0; e < EPL; ++e) { qv[qi][e] = 0.f; gv[qi][e] = 0.f; }
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(NW * 64) void thin_q_bwd_kernel(TP p) {
             a = head_sum(a, p.lph) * p.scale;
             g = head_sum(g, p.lph);
             const float pj = masked ? 0.f : __expf(a - L[qi]);
-            const float dm = p.dropout ? drop_mul(p.drop, (uint32_t)(((bb * p.heads + h) * p.Lq + qi) * p.Lk + j)) : 1.f;
+            const float dm = p.dropout ? drop_mul(p.drop, (uint32_t)(((bb * p.heads_total + p.head0 + h) * p.Lq + qi) * p.Lk + j)) : 1.f;
             const float ds = pj * (dm * g - delta[qi]), pt = pj * dm;
 #pragma unroll
             for (int e = 0; e < EPL; ++e) {
@@ -407,20 +409,41 @@ static bool al8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 
 
 }  // namespace thin
 
+// A problem of width d = heads * hd runs as d / d' column groups of d' in {1024, 768, 512} columns, each a whole number of heads (one launch
+// per group with shifted base pointers: the caption interaction at d = 768 is one group of 8 x 96, the MSR-VTT video model's d = 4096 with
+// 512-wide heads four groups of 2 heads).  thin side <= 4 rows: any d'; <= 8 rows: d' = 512 only (the backward's accumulators).
+static bool thin_plan(const AttnDims& D, int thin_rows, int* dprime, int* groups) {
+    const int64_t d = D.heads * D.hd;
+    static const int opts[3] = {1024, 768, 512};
+    for (int o = (thin_rows <= 4 ? 0 : 2); o < 3; ++o) {
+        const int dp = opts[o];
+        if (d % dp || dp % D.hd) continue;
+        const int hp = (int)(dp / D.hd);
+        if (hp > 64 || (64 % hp) != 0) continue;
+        // several groups = several launches: only worth it when the long side has rows to stream (the MSR-VTT video model's 8 frames x 4
+        // queries at d = 4096 run 7 % faster on the generic kernels: 33.7 against 36.1 ms per step)
+        if (d / dp > 1 && (D.Lq > D.Lk ? D.Lq : D.Lk) < 128) return false;
+        *dprime = dp;
+        *groups = (int)(d / dp);
+        return true;
+    }
+    return false;
+}
+
 // which thin form (if any) takes this problem: 1 = thin-K (Lk <= 8), 2 = thin-Q (Lq <= 8), 0 = neither
 int attn_thin_kind(const AttnDims& D, int dtype) {
     static const int enabled = [] { const char* e = getenv("LECCR_ATTN_THIN"); return (e && e[0] == '0') ? 0 : 1; }();
     if (!enabled || dtype != LECCR_BF16) return 0;
-    const int64_t d = D.heads * D.hd;
-    if (!(d == 512 || d == 768 || d == 1024) || D.heads > 64 || (64 % D.heads) != 0) return 0;
-    if ((D.ldq & 3) || (D.ldk & 3) || (D.ldv & 3) || (D.ldo & 3)) return 0;
-    if (D.Lk <= 4 || (D.Lk <= thin::MAXT && d == 512)) return 1;             // (8 keys at d >= 768: 192+ accumulators in the backward spill)
-    const int64_t qb = D.Lq <= 4 ? 4 : 8;
-    if ((D.Lq <= 4 || (D.Lq <= thin::MAXT && d == 512)) && (qb * D.heads * D.Lk + qb * d + qb * D.heads) * 4 <= 144 * 1024) return 2;
+    if ((D.ldq & 3) || (D.ldk & 3) || (D.ldv & 3) || (D.ldo & 3) || (D.hd & 3)) return 0;
+    int dp, groups;
+    if (D.Lk <= thin::MAXT && thin_plan(D, (int)D.Lk, &dp, &groups)) return 1;
+    if (D.Lq <= thin::MAXT && thin_plan(D, (int)D.Lq, &dp, &groups)) {
+        const int64_t qb = D.Lq <= 4 ? 4 : 8, hp = dp / D.hd;
+        if ((qb * hp * D.Lk + qb * dp + qb * hp) * 4 <= 144 * 1024) return 2;
+    }
     return 0;
 }
 
-// (EPL, thin rows) combinations that exist: (8,4) (8,8) (12,4) (16,4)
 #define THIN_DISPATCH(EPLV, TB, CALL, WITH_12_8)                                                           \
     do {                                                                                                   \
         if (EPLV == 8 && TB == 4) { CALL(8, 4); } else if (EPLV == 8) { CALL(8, 8); }                      \
@@ -430,10 +453,11 @@ int attn_thin_kind(const AttnDims& D, int dtype) {
 #define THIN_YES(CALL) CALL(12, 8)
 #define THIN_NO(CALL) return LECCR_EINVAL
 
-static thin::TP thin_params(const AttnDims& D) {
+static thin::TP thin_params(const AttnDims& D, int dprime) {
     thin::TP p{};
-    p.b = D.b; p.heads = D.heads; p.Lq = D.Lq; p.Lk = D.Lk; p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv; p.ldo = D.ldo;
-    p.lph = (int)(64 / D.heads); p.nsplit = 1; p.scale = 1.f / sqrtf((float)D.hd); p.drop = D.drop; p.dropout = D.dropout;
+    p.b = D.b; p.heads = dprime / D.hd; p.heads_total = D.heads; p.head0 = 0; p.Lq = D.Lq; p.Lk = D.Lk;
+    p.ldq = D.ldq; p.ldk = D.ldk; p.ldv = D.ldv; p.ldo = D.ldo;
+    p.lph = (int)(64 / p.heads); p.nsplit = 1; p.scale = 1.f / sqrtf((float)D.hd); p.drop = D.drop; p.dropout = D.dropout;
     return p;
 }
 
@@ -441,28 +465,34 @@ int attn_thin_fwd(int kind, const void* q, const void* k, const void* v, void* o
                   const AttnDims& D, hipStream_t st) {
     using namespace thin;
     if (!(al8(q) && al8(k) && al8(v) && al8(o))) { set_error("attn_fwd(thin): q/k/v/o must be 8-byte aligned"); return LECCR_EALIGN; }
-    TP p = thin_params(D);
-    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.out = (bf16_t*)o; p.lse = lse; p.kmask = kmask;
-    const int d = (int)(D.heads * D.hd), epl = d / 64;
-    if (kind == 1) {
-        const int kb = D.Lk <= 4 ? 4 : 8;
-        const size_t shm = (size_t)2 * kb * d * sizeof(float);
+    int d = 0, groups = 0;
+    if (!thin_plan(D, (int)(kind == 1 ? D.Lk : D.Lq), &d, &groups)) { set_error("attn_fwd(thin): no column-group plan"); return LECCR_EINVAL; }
+    const int epl = d / 64;
+    for (int g = 0; g < groups; ++g) {
+        TP p = thin_params(D, d);
+        const int64_t c0 = (int64_t)g * d;
+        p.head0 = g * (int)p.heads;
+        p.q = (const bf16_t*)q + c0; p.k = (const bf16_t*)k + c0; p.v = (const bf16_t*)v + c0; p.out = (bf16_t*)o + c0; p.lse = lse; p.kmask = kmask;
+        if (kind == 1) {
+            const int kb = D.Lk <= 4 ? 4 : 8;
+            const size_t shm = (size_t)2 * kb * d * sizeof(float);
 #define CALL(E, T)                                                                                                       \
-        do { set_smem(thin_k_fwd_kernel<E, T>, shm);                                                                     \
-             hipLaunchKernelGGL((thin_k_fwd_kernel<E, T>), dim3((unsigned)cdiv(D.Lq, 64), (unsigned)D.b), dim3(256), shm, st, p); } while (0)
-        THIN_DISPATCH(epl, kb, CALL, THIN_NO);
+            do { set_smem(thin_k_fwd_kernel<E, T>, shm);                                                                 \
+                 hipLaunchKernelGGL((thin_k_fwd_kernel<E, T>), dim3((unsigned)cdiv(D.Lq, 64), (unsigned)D.b), dim3(256), shm, st, p); } while (0)
+            THIN_DISPATCH(epl, kb, CALL, THIN_NO);
 #undef CALL
-        return check_launch("thin_k_fwd");
+        } else {
+            const int qb = D.Lq <= 4 ? 4 : 8;
+            const size_t shm = ((size_t)qb * p.heads * D.Lk + (size_t)qb * d + (size_t)qb * p.heads) * sizeof(float);
+#define CALL(E, T)                                                                                                       \
+            do { constexpr int NW = (T == 4 && E <= 12) ? 16 : 8;                                                        \
+                 set_smem(thin_q_fwd_kernel<E, T, NW>, shm);                                                             \
+                 hipLaunchKernelGGL((thin_q_fwd_kernel<E, T, NW>), dim3((unsigned)D.b), dim3(NW * 64), shm, st, p); } while (0)
+            THIN_DISPATCH(epl, qb, CALL, THIN_NO);
+#undef CALL
+        }
     }
-    const int qb = D.Lq <= 4 ? 4 : 8;
-    const size_t shm = ((size_t)qb * D.heads * D.Lk + (size_t)qb * d + (size_t)qb * D.heads) * sizeof(float);
-#define CALL(E, T)                                                                                                       \
-    do { constexpr int NW = (T == 4 && E <= 12) ? 16 : 8;                                                                \
-         set_smem(thin_q_fwd_kernel<E, T, NW>, shm);                                                                     \
-         hipLaunchKernelGGL((thin_q_fwd_kernel<E, T, NW>), dim3((unsigned)D.b), dim3(NW * 64), shm, st, p); } while (0)
-    THIN_DISPATCH(epl, qb, CALL, THIN_NO);
-#undef CALL
-    return check_launch("thin_q_fwd");
+    return check_launch(kind == 1 ? "thin_k_fwd" : "thin_q_fwd");
 }
 
 int attn_thin_bwd(int kind, const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
@@ -472,36 +502,44 @@ int attn_thin_bwd(int kind, const void* q, const void* k, const void* v, const v
         set_error("attn_bwd(thin): tensors must be 8-byte aligned");
         return LECCR_EALIGN;
     }
-    TP p = thin_params(D);
-    p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.v = (const bf16_t*)v; p.o = (const bf16_t*)o; p.dout = (const bf16_t*)dout;
-    p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.lse = const_cast<float*>(lse); p.kmask = kmask;
-    const int d = (int)(D.heads * D.hd), epl = d / 64;
-    if (kind == 1) {
-        const int kb = D.Lk <= 4 ? 4 : 8;
-        // long query sets are cut into row chunks (more workgroups than batch elements in flight); their dK / dV partial sums meet in
-        // the caller's f32 workspace (`delta`: 2 b heads roundup(Lq, 64) floats) when 2 b Lk d of them fit
-        const int64_t ws_have = 2 * D.b * D.heads * (cdiv(D.Lq, 64) * 64), ws_need = 2 * D.b * D.Lk * d;
-        p.nsplit = (D.Lq >= 256 && ws_need <= ws_have) ? 8 : 1;
-        p.ws = delta;
-        if (p.nsplit > 1 && hipMemsetAsync(delta, 0, sizeof(float) * ws_need, st) != hipSuccess) return check_launch("thin_k_bwd memset");
-        const size_t shm = (size_t)4 * kb * d * sizeof(float);
+    int d = 0, groups = 0;
+    if (!thin_plan(D, (int)(kind == 1 ? D.Lk : D.Lq), &d, &groups)) { set_error("attn_bwd(thin): no column-group plan"); return LECCR_EINVAL; }
+    const int epl = d / 64;
+    // thin-K: long query sets are cut into row chunks (more workgroups than batch elements in flight); their dK / dV partial sums meet in
+    // the caller's f32 workspace (`delta`: 2 b heads roundup(Lq, 64) floats) when 2 b Lk d_total of them fit (a slice per column group)
+    const int64_t ws_have = 2 * D.b * D.heads * (cdiv(D.Lq, 64) * 64), ws_group = 2 * D.b * D.Lk * d, ws_need = ws_group * groups;
+    const int nsplit = (kind == 1 && D.Lq >= 256 && ws_need <= ws_have) ? 8 : 1;
+    if (nsplit > 1 && hipMemsetAsync(delta, 0, sizeof(float) * ws_need, st) != hipSuccess) return check_launch("thin_k_bwd memset");
+    for (int g = 0; g < groups; ++g) {
+        TP p = thin_params(D, d);
+        const int64_t c0 = (int64_t)g * d;
+        p.head0 = g * (int)p.heads;
+        p.q = (const bf16_t*)q + c0; p.k = (const bf16_t*)k + c0; p.v = (const bf16_t*)v + c0; p.o = (const bf16_t*)o + c0;
+        p.dout = (const bf16_t*)dout + c0; p.dq = (bf16_t*)dq + c0; p.dk = (bf16_t*)dk + c0; p.dv = (bf16_t*)dv + c0;
+        p.lse = const_cast<float*>(lse); p.kmask = kmask;
+        if (kind == 1) {
+            const int kb = D.Lk <= 4 ? 4 : 8;
+            p.nsplit = nsplit;
+            p.ws = delta + g * ws_group;
+            const size_t shm = (size_t)4 * kb * d * sizeof(float);
 #define CALL(E, T)                                                                                                       \
-        do { set_smem(thin_k_bwd_kernel<E, T>, shm);                                                                     \
-             hipLaunchKernelGGL((thin_k_bwd_kernel<E, T>), dim3((unsigned)p.nsplit, (unsigned)D.b), dim3(256), shm, st, p); } while (0)
-        THIN_DISPATCH(epl, kb, CALL, THIN_NO);
+            do { set_smem(thin_k_bwd_kernel<E, T>, shm);                                                                 \
+                 hipLaunchKernelGGL((thin_k_bwd_kernel<E, T>), dim3((unsigned)p.nsplit, (unsigned)D.b), dim3(256), shm, st, p); } while (0)
+            THIN_DISPATCH(epl, kb, CALL, THIN_NO);
 #undef CALL
-        if (p.nsplit > 1)
-            hipLaunchKernelGGL(thin_k_finish_kernel, dim3((unsigned)cdiv(D.b * D.Lk * d, 256)), dim3(256), 0, st, p, d);
-        return check_launch("thin_k_bwd");
+            if (p.nsplit > 1)
+                hipLaunchKernelGGL(thin_k_finish_kernel, dim3((unsigned)cdiv(D.b * D.Lk * d, 256)), dim3(256), 0, st, p, d);
+        } else {
+            const int qb = D.Lq <= 4 ? 4 : 8;
+            const size_t shm = (size_t)qb * d * sizeof(float);
+#define CALL(E, T)                                                                                                       \
+            do { constexpr int NW = (E == 16 || T == 8) ? 4 : 8;       /* 128 q / dO registers: one wave per SIMD */             \
+                 hipLaunchKernelGGL((thin_q_bwd_kernel<E, T, NW>), dim3((unsigned)D.b), dim3(NW * 64), shm, st, p); } while (0)
+            THIN_DISPATCH(epl, qb, CALL, THIN_NO);
+#undef CALL
+        }
     }
-    const int qb = D.Lq <= 4 ? 4 : 8;
-    const size_t shm = (size_t)qb * d * sizeof(float);
-#define CALL(E, T)                                                                                                       \
-    do { constexpr int NW = (E == 16 || T == 8) ? 4 : 8;       /* 128 q / dO registers: one wave per SIMD */                     \
-         hipLaunchKernelGGL((thin_q_bwd_kernel<E, T, NW>), dim3((unsigned)D.b), dim3(NW * 64), shm, st, p); } while (0)
-    THIN_DISPATCH(epl, qb, CALL, THIN_NO);
-#undef CALL
-    return check_launch("thin_q_bwd");
+    return check_launch(kind == 1 ? "thin_k_bwd" : "thin_q_bwd");
 }
 
 }  // namespace leccr
