@@ -304,8 +304,6 @@ class XVLMBase(nn.Module):
         run_batch = K.fp8_requantize_weights(batch) if batch else None
 
         def requantise():
-            if os.environ.get('XP_SKIP_REQ') == '1' and holders[0]._wsite.primed:
-                return
             if run_batch is not None:
                 run_batch()
             for h in rest:
