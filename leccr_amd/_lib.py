@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libleccr_hip.so')
+LIB_PATH = os.environ.get('LECCR_LIB') or os.path.join(_HERE, 'libleccr_hip.so')      # LECCR_LIB: a diagnostic build (scripts/build_variant.sh)
 
 F32, BF16, FP8, FP8_BF8A = 0, 1, 2, 3      # FP8 / FP8_BF8A: leccr_gemm operand codes only (e4m3 x e4m3 / A e5m2 x B e4m3)
 EPI_NONE, EPI_QUICKGELU, EPI_GELU, EPI_DQUICKGELU, EPI_DGELU = 0, 1, 2, 3, 4

@@ -316,7 +316,11 @@ __global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
                 for (int ni = 0; ni < 4; ++ni) {
                     float* cp = a.C + (m0 + 32 * mi + 4 * h) * a.ldc + n0 + 32 * ni + r;
 #pragma unroll
+#ifdef T4_EXP_NOATOMIC
+                    for (int i = 0; i < 16; ++i) asm volatile("" ::"v"(acc[mi * 4 + ni][i]));       // diagnostic build: no epilogue atomics (wrong results)
+#else
                     for (int i = 0; i < 16; ++i) atomicAdd(cp + (int64_t)((i & 3) + 8 * (i >> 2)) * a.ldc, acc[mi * 4 + ni][i] * a.alpha);
+#endif
                 }
             if constexpr ((FLAGS & F_ASUM) != 0) {
                 // cs[u]: sum over this lane's k half (8 h ..) of column m = m0 + 32 (2 wc + u) + r: add the two halves, one atomic per column
