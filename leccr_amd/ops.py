@@ -703,9 +703,13 @@ class BertLayerFn(torch.autograd.Function):
         seeds = (_next_seed(), _next_seed(), _next_seed())
         x_8 = x8_of(layer.fp8, _rows(x), layer._qkv_w)
         qkv = lin_fwd(_rows(x), layer._qkv_w, layer._qkv_b, fp8=layer.fp8, x8=x_8).view(b, L, 3 * d)
-        o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask, pa, seeds[0])
         ao = layer.attention.output
-        o_8 = x8_of(layer.fp8, _rows(o), ao.dense.weight)
+        o_site = _q8_site(layer.fp8, b * L, ao.dense.weight, '_xsite')          # fp8: o's e4m3 copy out of the attention kernel
+        if o_site is not None and o_site.primed:
+            o, lse, o_8 = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask, pa, seeds[0], q8_site=o_site)
+        else:
+            o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], layer.heads, kmask, pa, seeds[0])
+            o_8 = x8_of(layer.fp8, _rows(o), ao.dense.weight)
         x1_site = _q8_site(layer.fp8, b * L, layer.intermediate.dense.weight, '_xsite')      # fp8: x1's e4m3 copy out of its LayerNorm pass
         if ph > 0:      # dense -> dropout -> + residual (inside the LayerNorm kernel)
             a1 = lin_fwd(_rows(o), ao.dense.weight, ao.dense.bias, fp8=layer.fp8, x8=o_8)
@@ -771,9 +775,12 @@ class BertLayerFn(torch.autograd.Function):
         do = lin_dx(gd1, ao.dense.weight, fp8=layer.fp8, g8=gd1_8).view(b, L, d)
         lin_dw(gd1, _rows(o), ao.dense.weight, ao.dense.bias, g8=gd1_8, x8=o_8)
         dqkv = torch.empty_like(qkv)
+        g_site = _q8_site(layer.fp8, b * L, layer._qkv_w, '_gsite')            # fp8: dqkv's e5m2 copy out of the attention backward
+        dqkv8 = torch.empty(qkv.shape, device=qkv.device, dtype=g_site.torch_dtype) if (g_site is not None and g_site.primed) else None
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, layer.heads, kmask,
-                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], drop_p=pa, seed=seeds[0])
-        dqkv8 = g8_of(layer.fp8, _rows(dqkv), layer._qkv_w)
+                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], drop_p=pa, seed=seeds[0],
+                   q8=None if dqkv8 is None else (dqkv8[..., :d], dqkv8[..., d:2 * d], dqkv8[..., 2 * d:], g_site))
+        dqkv8 = g8_of(layer.fp8, _rows(dqkv), layer._qkv_w, None if dqkv8 is None else _rows(dqkv8))
         dx = lin_dx(_rows(dqkv), layer._qkv_w, fp8=layer.fp8, g8=dqkv8, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
         lin_dw(_rows(dqkv), x, layer._qkv_w, layer._qkv_b, g8=dqkv8, x8=x_8)
         for p in (out.LayerNorm.weight, out.LayerNorm.bias, ao.LayerNorm.weight, ao.LayerNorm.bias):
