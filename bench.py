@@ -52,7 +52,7 @@ def parse():
     ap.add_argument('--text', default='mbert', choices=['mbert', 'xlmr-large'],
                     help="text tower geometry: mBERT (configs A-D) | XLM-R-large shaped BERT (BASELINE configs[4]: hidden 1024, 24 layers, 16 heads, FFN 4096, vocab 250002)")
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32', 'fp8'],
-                    help="bf16 = BASELINE configs[1] (the headline); fp8 = BASELINE configs[4]'s fp8 GEMM operands in the encoder blocks (forward + dX)")
+                    help="bf16 = BASELINE configs[1] (the headline); fp8 = BASELINE configs[4]'s fp8 GEMM operands in the encoder blocks (forward, dX and weight-gradient products)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--roofline-steps', type=int, default=3, help='extra single-stream steps after the timed region that time every launch on its own')
