@@ -52,16 +52,20 @@ int leccr_last_gemm_kernel(void);              /* which kernel the last leccr_ge
                                                 * 5 the 4-wave TN weight-gradient kernel, 6 its fp8 form; tests use it */
 int leccr_prof_enable(int on);
 int leccr_prof_read(double* ms, double* work, int64_t* launches);
-/* The first n <= 13 kinds: the five above, then {layernorm_fwd, layernorm_bwd, colsum, embedding stages, adamw, dropout} -
+/* The first n <= 14 kinds: the five above, then {layernorm_fwd, layernorm_bwd, colsum, embedding stages, adamw, dropout} -
  * the HBM-bound launches, whose work[] entry is ALGORITHMIC BYTES (every operand read once, every result written once) - then
  * {fp8-operand NT GEMMs (forward / dX), fp8-operand weight-gradient GEMMs}: flops, kept apart from the bf16 launches of kinds 0 / 1
- * so that a mixed-precision step can be priced launch by launch (fp8 against the fp8 MFMA peak, bf16 against the bf16 one). */
+ * so that a mixed-precision step can be priced launch by launch (fp8 against the fp8 MFMA peak, bf16 against the bf16 one); then
+ * {leccr_split3 passes}: bytes. */
 int leccr_prof_read_n(int n, double* ms, double* work, int64_t* launches);
 /* The launches of the kinds in kind_mask (bit k = index k above) as one busy time: the union of their [start, stop]
  * intervals (launches that overlap on two streams are not counted twice), their total work and count. */
 int leccr_prof_read_union(int kind_mask, double* busy_ms, double* work, int64_t* launches);
 int64_t leccr_prof_dropped(void);              /* launches since leccr_prof_enable(1) that found the record buffer (131 072
                                                 * entries) full and were not timed: the read-outs undercount when > 0 */
+int leccr_debug_set_stamps(void* device_buffer);   /* diagnostic builds only (-DLECCR_G256_STAMPS, scripts/build_variant.sh): where the
+                                                * 256x256 GEMM leaves its in-kernel s_memtime stamps; a no-op pointer store in the
+                                                * production build (no stamp instruction is compiled in) */
 
 /* ---- GEMM -------------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )      (+ C if accumulate)
@@ -130,6 +134,18 @@ typedef struct leccr_gemm_params {
 } leccr_gemm_params;
 
 int leccr_gemm(const leccr_gemm_params* p, void* stream);
+
+/* ---- fp32 operands on the bf16 matrix cores ("bf16x3") ---------------------------------------------------------
+ * The reference's arithmetic is fp32 (models/xvlm.py:88 `clip_encoder.float()`, clip/model.py:171-192; HF BertModel in fp32).  An
+ * fp32 x is hi + lo + e, hi = bf16(x), lo = bf16(x - hi), |e| <= 2^-18 |x|, and x w = hi_x hi_w + hi_x lo_w + lo_x hi_w + O(2^-17 |x w|):
+ * three bf16 products accumulated in f32 = ONE bf16 leccr_gemm over a reduction index three times as long.  leccr_split3 writes
+ * the operand copies: dst [rows, 3 * cols] bf16, every row = three segments of `cols`,
+ *   form 0 ("X": activations; the [in, out] weight copy of the dX product):  hi | hi | lo
+ *   form 1 ("G": gradients; the [out, in] weight of the forward product):    hi | lo | hi
+ * so that an X-form operand against a G-form operand pairs up as hh + hl + lh whichever is A or B (NT: K' = 3 K, lda = ldb = 3 K).
+ * The same memory read as [3 * rows, cols] is the row-interleaved form of the weight-gradient product (TN: K' = 3 * rows).
+ * transpose = 1: the split of src^T, dst [cols, 3 * rows].  src f32, row stride ld_src elements. */
+int leccr_split3(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int form, int transpose, void* stream);
 
 /* ---- LayerNorm --------------------------------------------------------------------------------------------
  * y = (x - mean) * rstd * gamma + beta over the last axis, statistics in f32.

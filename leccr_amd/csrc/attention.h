@@ -42,6 +42,12 @@ int attn_mfma_bwd(const void* q, const void* k, const void* v, const void* o, co
                   const uint8_t* kmask, void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st,
                   const AttnQ8* q8 = nullptr, bool* fused = nullptr);
 
+// f32, head size 64: flash kernels on v_mfma_f32_32x32x2_f32 (attention_f32.hip) - the reference-precision path
+bool attn_f32_supported(const AttnDims& D, int dtype, const void* const* ptrs, int nptrs);
+int attn_f32_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const AttnDims& D, hipStream_t st);
+int attn_f32_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const uint8_t* kmask,
+                 void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st);
+
 extern bool g_force_generic_attn;
 int attn_set_variant(int v);      // 0 = default (environment), 16 / 32 = queries per wave of the MFMA forward kernel; returns the one in effect
 

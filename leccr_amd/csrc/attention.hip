@@ -4,7 +4,7 @@
 
 namespace leccr {
 bool g_force_generic_attn = false;
-static int g_last_attn_kernel = -1;      // 0 generic, 1 MFMA flash (head 64), 2 thin-K, 3 thin-Q
+static int g_last_attn_kernel = -1;      // 0 generic, 1 MFMA flash (head 64), 2 thin-K, 3 thin-Q, 4 f32 MFMA flash (head 64)
 // LECCR_ATTN_THIN=2: the thin kernels also take the head-64 problems with a thin side (default: those stay on the MFMA kernels)
 static bool thin_first() {
     static const bool v = [] { const char* e = getenv("LECCR_ATTN_THIN"); return e && e[0] == '2'; }();
@@ -48,6 +48,13 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
         if (const int kind = attn_thin_kind(D, dtype)) {
             g_last_attn_kernel = 1 + kind;
             return attn_thin_fwd(kind, q, k, v, o, lse, kmask, D, st);
+        }
+    }
+    {
+        const void* ptrs[4] = {q, k, v, o};
+        if (!g_force_generic_attn && attn_f32_supported(D, dtype, ptrs, 4)) {      // fp32 (reference precision) on the f32 matrix-core instruction
+            g_last_attn_kernel = 4;
+            return attn_f32_fwd(q, k, v, o, lse, kmask, D, st);
         }
     }
     g_last_attn_kernel = 0;
@@ -113,6 +120,13 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
         if (const int kind = attn_thin_kind(D, dtype)) {
             g_last_attn_kernel = 1 + kind;
             return attn_thin_bwd(kind, q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
+        }
+    }
+    {
+        const void* ptrs[8] = {q, k, v, o, dout, dq, dk, dv};
+        if (!g_force_generic_attn && attn_f32_supported(D, dtype, ptrs, 8)) {
+            g_last_attn_kernel = 4;
+            return attn_f32_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
         }
     }
     g_last_attn_kernel = 0;

@@ -34,7 +34,8 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 enum ProfKind { PROF_GEMM_NT = 0, PROF_GEMM_TN = 1, PROF_GEMM_GENERIC = 2, PROF_ATTN_FWD = 3, PROF_ATTN_BWD = 4,
                 PROF_LN_FWD = 5, PROF_LN_BWD = 6, PROF_COLSUM = 7, PROF_EMBED = 8, PROF_ADAMW = 9, PROF_DROPOUT = 10,
                 PROF_GEMM_FP8_NT = 11, PROF_GEMM_FP8_TN = 12,       // fp8-operand launches (forward / dX; weight gradients): priced against the fp8 peak
-                PROF_KINDS = 13, PROF_KINDS_V1 = 5 };
+                PROF_SPLIT = 13,                                     // leccr_split3 passes (fp32 operands as bf16 hi / lo pairs): bytes
+                PROF_KINDS = 14, PROF_KINDS_V1 = 5 };
 struct ProfScope {
     int slot;
     hipStream_t st;

@@ -876,7 +876,7 @@ static bool shape_compiled(const leccr_gemm_params& p) {
     using namespace g256;
     const int f = flags_of(p);
     if (p.trans_a == 1) return p.c_dtype == LECCR_F32 && p.epilogue == LECCR_EPI_NONE && (f == F_ACCUM);
-    if (p.c_dtype == LECCR_F32) return p.epilogue == LECCR_EPI_NONE && f == 0;
+    // (f32 C: the same epilogue shapes - the reference-precision path runs its fp32 operands as bf16 hi / lo splits, split.hip)
     switch (p.epilogue) {
         case LECCR_EPI_NONE: return f == 0 || f == F_RES;
         case LECCR_EPI_QUICKGELU:
@@ -982,7 +982,17 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
         } else if (splits > 1) launch_inst<1, float, LECCR_EPI_NONE, F_ATOMIC>(a, grid, st);
         else launch_inst<1, float, LECCR_EPI_NONE, F_ACCUM>(a, grid, st);
     } else if (p.c_dtype == LECCR_F32) {
-        launch_inst<0, float, LECCR_EPI_NONE, 0>(a, grid, st);
+        switch (p.epilogue) {
+            case LECCR_EPI_NONE:
+                if (f == F_RES) launch_inst<0, float, LECCR_EPI_NONE, F_RES>(a, grid, st);
+                else launch_inst<0, float, LECCR_EPI_NONE, 0>(a, grid, st);
+                break;
+            case LECCR_EPI_QUICKGELU: launch_inst<0, float, LECCR_EPI_QUICKGELU, F_AUXOUT>(a, grid, st); break;
+            case LECCR_EPI_GELU: launch_inst<0, float, LECCR_EPI_GELU, F_AUXOUT>(a, grid, st); break;
+            case LECCR_EPI_DQUICKGELU: launch_inst<0, float, LECCR_EPI_DQUICKGELU, 0>(a, grid, st); break;
+            case LECCR_EPI_DGELU: launch_inst<0, float, LECCR_EPI_DGELU, 0>(a, grid, st); break;
+            default: set_error("gemm256: bad epilogue %d", p.epilogue); return LECCR_EINVAL;
+        }
     } else {
         switch (p.epilogue) {
             case LECCR_EPI_NONE:

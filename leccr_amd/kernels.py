@@ -4,6 +4,7 @@ No autograd here (see ops.py) and no fallback: every function launches a HIP ker
 current torch stream.  torch is used for allocation only.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -20,10 +21,78 @@ def _rows2d(t):
     return t2, t2.shape[0], t2.shape[1], t2.stride(0)
 
 
+# ---- fp32 operands on the bf16 matrix cores (leccr_split3: x = hi + lo, three bf16 products in one launch over 3 K) ----------------
+# The reference's arithmetic is fp32 (models/xvlm.py:88).  With f32_mfma (default; LECCR_F32_MFMA=0 or set_f32_mfma(False): the scalar
+# f32 kernels, correctness yardstick) every f32 gemm() of a shape the MFMA kernels take runs as ONE bf16 product over hi / lo splits of
+# its operands, f32 accumulation and output: ~2^-17 relative per product term instead of bf16's 2^-9.
+FORM_X, FORM_G = 0, 1          # hi|hi|lo (activations, [in, out] weight copies)   /   hi|lo|hi (gradients, [out, in] weights)
+f32_mfma = os.environ.get('LECCR_F32_MFMA', '1') != '0'
+f32_split_launches = 0         # gemm() calls that took the split path (tests read it)
+_SPLIT_MIN_WORK = 1 << 18      # M * N * K below which the one-launch scalar kernel is as good
+
+
+def set_f32_mfma(on):
+    global f32_mfma
+    prev, f32_mfma = f32_mfma, bool(on)
+    return prev
+
+
+def split3(x, form, transpose=False):
+    """f32 [rows, cols] (unit inner stride) -> bf16 [rows, 3 * cols] (transpose: [cols, 3 * rows]) in hi / lo form `form`."""
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and form in (FORM_X, FORM_G)
+    rows, cols = x.shape
+    out = torch.empty((cols, 3 * rows) if transpose else (rows, 3 * cols), device=x.device, dtype=torch.bfloat16)
+    check(lib().leccr_split3(ptr(x), ptr(out), rows, cols, x.stride(0), form, int(transpose), stream()), 'leccr_split3')
+    return out
+
+
+def _split_plan(a, b, trans_a, trans_b, out, accumulate, asum):
+    """Which split layout an f32 product takes on the MFMA kernels, or None (the scalar kernel): 'nt' / 'ntb' (B stored [K, N]:
+    transposed split) / 'tn' (reduction over rows: the [rows, 3 cols] copies read as [3 rows, cols])."""
+    if not (f32_mfma and a.dtype == torch.float32 and b.dtype == torch.float32 and a.is_cuda):
+        return None
+    if out is not None and out.dtype != torch.float32:
+        return None
+    M, Kd = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N = b.shape[1] if trans_b else b.shape[0]
+    if M * N * Kd < _SPLIT_MIN_WORK or N % 4:
+        return None
+    if not trans_a:
+        return ('ntb' if trans_b else 'nt') if Kd % 64 == 0 else None
+    if trans_b and M % 8 == 0 and N % 8 == 0 and a.stride(0) == M and b.stride(0) == N:
+        return 'tn'
+    return None
+
+
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
-         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None, c8=None, write_c=True):
+         out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None, c8=None, write_c=True,
+         a3=None, b3=None):
     """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major.
-    write_c=False (fp8 operands with c8 only): the bf16 C is not written - only its fp8 copy c8 (and aux_out / colsum); returns None."""
+    write_c=False (fp8 operands with c8 only): the bf16 C is not written - only its fp8 copy c8 (and aux_out / colsum); returns None.
+    f32 operands: see f32_mfma above.  a3 / b3 = (split copy, form): the caller already holds leccr_split3 copies of a / b (as they
+    are stored; for trans_b alone b3 is the transposed split) - they must be of opposite forms; missing ones are made here."""
+    plan = _split_plan(a, b, trans_a, trans_b, out, accumulate, asum) if a.dtype == torch.float32 else None
+    if plan is not None:
+        global f32_split_launches
+        f32_split_launches += 1
+        fa = a3[1] if a3 is not None else (1 - b3[1] if b3 is not None else FORM_X)
+        assert b3 is None or b3[1] == 1 - fa
+        a_s = a3[0] if a3 is not None else split3(a, fa)
+        b_s = b3[0] if b3 is not None else split3(b, 1 - fa, transpose=(plan == 'ntb'))
+        if plan == 'tn':
+            a_s, b_s = a_s.view(3 * a.shape[0], a.shape[1]), b_s.view(3 * b.shape[0], b.shape[1])
+            if asum is not None:        # the column sums of the split copy would count hi twice: one pass over the f32 operand instead
+                if alpha == 1.0:
+                    colsum_(a, asum)
+                else:
+                    tmp = torch.zeros_like(asum)
+                    colsum_(a, tmp)
+                    axpy(tmp, asum, alpha)
+            return gemm(a_s, b_s, trans_a=True, trans_b=True, out=out, out_dtype=torch.float32, accumulate=accumulate, alpha=alpha,
+                        colsum=colsum)
+        assert a_s.shape == (a.shape[0], 3 * a.shape[1]) and b_s.shape[1] == a_s.shape[1]
+        return gemm(a_s, b_s, bias=bias, epilogue=epilogue, aux=aux, aux_out=aux_out, residual=residual, out=out,
+                    out_dtype=torch.float32, accumulate=accumulate, alpha=alpha, colsum=colsum)
     assert a.dim() == 2 and b.dim() == 2 and (a.dtype == b.dtype or a.dtype == torch.float8_e5m2)
     assert a.stride(1) == 1 and b.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -214,6 +283,10 @@ def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None
                                ptr(dv), ptr(delta), b, heads, Lq, Lk, hd, q.stride(1), k.stride(1), v.stride(1),
                                o.stride(1), dtype_code(q), float(drop_p), int(seed), stream()), 'leccr_attn_bwd')
     return dq, dk, dv
+
+
+def colsum_(x, out):
+    return colsum(x, out)
 
 
 def colsum(x, out):

@@ -1242,3 +1242,129 @@ def test_gemm_fp8_fused_copy_of_the_output(K, grad):
         assert torch.equal(kw2['aux_out'], kw['aux_out'])
         with pytest.raises((RuntimeError, AssertionError)):               # forward form: no fused column sums
             K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), c8=(y8b, sc), colsum=torch.zeros(N, device=DEV), **kw2)
+
+
+# ------------------------------------------------------------------------------------------------ fp32 operands on the bf16 matrix cores
+@pytest.mark.parametrize('rows,cols,ld', [(300, 768, 768), (37, 64, 96), (5, 20, 20), (256, 3072, 3072)])
+@pytest.mark.parametrize('form', [0, 1])
+def test_split3_writes_hi_lo_segments(K, rows, cols, ld, form):
+    """leccr_split3: hi = bf16(x), lo = bf16(x - hi), laid out hi|hi|lo (form 0) or hi|lo|hi (form 1) - bit for bit what torch's own
+    conversions give - and the transposed variant is the split of x^T."""
+    x = _rand((rows, ld), torch.float32, 11)[:, :cols]
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    segs = (hi, hi, lo) if form == 0 else (hi, lo, hi)
+    want = torch.cat(segs, dim=1)
+    got = K.split3(x.to(DEV), form)
+    assert got.shape == (rows, 3 * cols) and torch.equal(got.cpu().view(torch.int16), want.contiguous().view(torch.int16))
+    got_t = K.split3(x.to(DEV), form, transpose=True)
+    want_t = torch.cat([s.t() for s in segs], dim=1).contiguous()
+    assert torch.equal(got_t.cpu().view(torch.int16), want_t.view(torch.int16))
+    # hi + lo reproduces x to 2^-17 relative
+    assert float(((hi.float() + lo.float()) - x).abs().max()) <= 2.0 ** -17 * float(x.abs().max())
+
+
+@pytest.mark.parametrize('M,N,K_', [(577 * 2, 768, 768), (1154, 2304, 768), (4096, 3072, 768), (2048, 768, 3072), (300, 260, 192), (64, 256, 128)])
+@pytest.mark.parametrize('case', ['plain', 'res', 'act', 'gelu', 'dact', 'dx'])
+def test_gemm_f32_operands_run_as_bf16_splits_on_the_matrix_cores(K, M, N, K_, case):
+    """f32 gemm() = ONE bf16 MFMA launch over hi / lo splits (3 K): same tolerance as the scalar f32 kernel (2e-5 of the largest
+    magnitude), every epilogue of the path, NT / B-transposed forms; the scalar kernel (set_f32_mfma(False)) agrees."""
+    from leccr_amd._lib import lib
+    a, b = _rand((M, K_), torch.float32, 21), _rand((N, K_), torch.float32, 22, 0.05)
+    bias, res, pre_in = _rand((N,), torch.float32, 23), _rand((M, N), torch.float32, 24), _rand((M, N), torch.float32, 25)
+    u = a.double() @ b.double().t()
+
+    def run():
+        if case == 'plain':
+            return K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV)), u + bias.double(), None
+        if case == 'res':
+            return K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), residual=res.to(DEV)), u + bias.double() + res.double(), None
+        if case in ('act', 'gelu'):
+            epi = 1 if case == 'act' else 2
+            pre = torch.empty(M, N, device=DEV)
+            out = K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), epilogue=epi, aux_out=pre)
+            return out, ACT[epi](u + bias.double()), (pre, u + bias.double())
+        if case == 'dact':
+            x = pre_in.double()
+            s = torch.sigmoid(1.702 * x)
+            return K.gemm(a.to(DEV), b.to(DEV), epilogue=3, aux=pre_in.to(DEV)), u * (s * (1 + 1.702 * x * (1 - s))), None
+        bt = b.t().contiguous()               # dx: B stored [K, N] (the [out, in] weight read for dX)
+        return K.gemm(a.to(DEV), bt.to(DEV), trans_b=True), u, None
+
+    n0 = K.f32_split_launches
+    out, ref, extra = run()
+    assert K.f32_split_launches == n0 + 1 and lib().leccr_last_gemm_kernel() in (1, 2, 3)
+    e, s = _err(out, ref)
+    assert e <= 2e-5 * s, (e, s)
+    if extra is not None:
+        e, s = _err(*extra)
+        assert e <= 2e-5 * s, (e, s)
+    prev = K.set_f32_mfma(False)
+    try:
+        out2, _, _ = run()
+        assert lib().leccr_last_gemm_kernel() == 0
+    finally:
+        K.set_f32_mfma(prev)
+    e, s = _err(out2, ref)
+    assert e <= 2e-5 * s, (e, s)
+    assert float((out2 - out).abs().max()) <= 3e-5 * s
+
+
+@pytest.mark.parametrize('Kt,M,N,alpha', [(20000, 768, 768, 1.0), (577 * 16, 2304, 768, 1.0), (64 * 300, 3072, 512, 0.5), (1000, 264, 136, 1.0)])
+def test_gemm_f32_weight_gradient_as_row_interleaved_splits(K, Kt, M, N, alpha):
+    """dW += alpha dY^T X with f32 operands: the [rows, 3 cols] split copies read as [3 rows, cols] (reduction over rows), the bias
+    gradient from one pass over the f32 dY (the split copy would count hi twice); pre-split operands give the same bits."""
+    from leccr_amd._lib import lib
+    dy, x = _rand((Kt, M), torch.float32, 31), _rand((Kt, N), torch.float32, 32)
+    w0, b0 = _rand((M, N), torch.float32, 33), _rand((M,), torch.float32, 34)
+    ref = w0.double() + alpha * (dy.double().t() @ x.double())
+    refb = b0.double() + alpha * dy.double().sum(0)
+    out, ob = w0.clone().to(DEV), b0.clone().to(DEV)
+    n0 = K.f32_split_launches
+    K.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True, out=out, accumulate=True, alpha=alpha, asum=ob)
+    assert K.f32_split_launches == n0 + 1 and lib().leccr_last_gemm_kernel() != 0
+    e, s = _err(out, ref)
+    assert e <= 2e-5 * s, (e, s)
+    e, s = _err(ob, refb)
+    assert e <= 2e-5 * s, (e, s)
+    out2 = w0.clone().to(DEV)
+    K.gemm(dy.to(DEV), x.to(DEV), trans_a=True, trans_b=True, out=out2, accumulate=True, alpha=alpha,
+           a3=(K.split3(dy.to(DEV), K.FORM_G), K.FORM_G), b3=(K.split3(x.to(DEV), K.FORM_X), K.FORM_X))
+    e, s = _err(out2, ref)
+    assert e <= 2e-5 * s, (e, s)
+
+
+@pytest.mark.parametrize('b,heads,Lq,Lk,masked,drop', [(2, 12, 577, 577, False, 0.0), (3, 12, 32, 32, True, 0.1), (2, 8, 577, 4, False, 0.1),
+                                                       (2, 8, 4, 64, True, 0.0), (1, 16, 730, 730, False, 0.0), (2, 4, 129, 97, True, 0.2)])
+def test_attention_f32_runs_on_the_f32_matrix_cores_and_matches_the_scalar_kernels(K, b, heads, Lq, Lk, masked, drop):
+    """fp32 attention at head size 64 = the v_mfma_f32_32x32x2_f32 flash kernels (leccr_last_attn_kernel() == 4): same products in f32 as
+    the scalar kernels (LECCR_ATTN_F32_MFMA=0 / other head sizes), so the two agree to summation order - forward, lse, all gradients,
+    key-padding mask and dropout included."""
+    from leccr_amd._lib import lib
+    import os
+    import subprocess
+    import sys
+    hd, d = 64, heads * 64
+    q, kv, do = _rand((b, Lq, d), torch.float32, 200), _rand((b, Lk, 2 * d), torch.float32, 201), _rand((b, Lq, d), torch.float32, 202)
+    kmask = None
+    if masked:
+        lens = torch.randint(1, Lk + 1, (b,), generator=torch.Generator().manual_seed(203))
+        kmask = (torch.arange(Lk)[None, :] >= lens[:, None]).to(torch.uint8).to(DEV)
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    o, lse = K.attn_fwd(qd, kvd[..., :d], kvd[..., d:], heads, kmask, drop, 77)
+    assert lib().leccr_last_attn_kernel() == 4
+    dq, dk, dv = K.attn_bwd(qd, kvd[..., :d], kvd[..., d:], o, do.to(DEV), lse, heads, kmask, drop_p=drop, seed=77)
+    assert lib().leccr_last_attn_kernel() == 4
+    # the same problem on the scalar kernels: force them for this call
+    lib().leccr_set_force_generic(1)
+    try:
+        o2, lse2 = K.attn_fwd(qd, kvd[..., :d], kvd[..., d:], heads, kmask, drop, 77)
+        assert lib().leccr_last_attn_kernel() == 0
+        dq2, dk2, dv2 = K.attn_bwd(qd, kvd[..., :d], kvd[..., d:], o2, do.to(DEV), lse2, heads, kmask, drop_p=drop, seed=77)
+    finally:
+        lib().leccr_set_force_generic(0)
+    for name, x, y in (('o', o, o2), ('lse', lse, lse2), ('dq', dq, dq2), ('dk', dk, dk2), ('dv', dv, dv2)):
+        fin = torch.isfinite(y)
+        assert torch.equal(torch.isfinite(x), fin), name
+        e, s = float((x[fin] - y[fin]).abs().max()), float(y[fin].abs().max()) + 1e-12
+        assert e <= 2e-5 * s, (name, e, s)

@@ -501,7 +501,10 @@ def test_video_production_kernels_vs_oracle(dtype, vw, vl):
     assert len(rows) > 90
     if dtype == 'fp32':
         gmax = max(r[2] for r in rows)
-        bad = [(n, err / rn, cos) for n, err, rn, cos, *_ in rows if rn >= 1e-6 * gmax and err > 1e-3 * rn]
+        # fp32 operands run as bf16 hi / lo splits on the matrix cores (kernels.f32_mfma: ~2^-17 per product term, where the scalar f32
+        # kernels had 2^-24): measured worst tensors at the 4096-wide reductions are two bias gradients (column sums that cancel
+        # heavily) at 1.1e-3 / 2.2e-3 of their norm, cosine 0.999998; everything else stays below 1e-3
+        bad = [(n, err / rn, cos) for n, err, rn, cos, *_ in rows if rn >= 1e-6 * gmax and err > (3e-3 if n.endswith('.bias') else 1e-3) * rn]
     else:       # every tensor within 3x its own bf16-storage noise (oracle.lowp), at 512- and 4096-wide reductions alike
         bad = outside_noise_model(rows)
     assert not bad, bad[:8]
