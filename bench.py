@@ -412,7 +412,7 @@ def _main(args, real_stdout):
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
-    NK = 13
+    NK = 14
     ms, work, n = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
     busy, gwork, gn = C.c_double(), C.c_double(), C.c_int64()
     prof_steps = args.roofline_steps if args.roofline_steps > 0 else 0
@@ -469,8 +469,14 @@ def _main(args, real_stdout):
         bf_ms, bf_fl, bf_n = leg_ms[0] + leg_ms[1], leg_work[0] + leg_work[1], leg_n[0] + leg_n[1]
         f8_ms, f8_fl, f8_n = leg_ms[11] + leg_ms[12], leg_work[11] + leg_work[12], leg_n[11] + leg_n[12]
         gemm_ms, gemm_fl, gemm_n = bf_ms + f8_ms, bf_fl + f8_fl, bf_n + f8_n
-        achieved = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        t_peak = bf_fl / MFMA_BF16_PEAK_TFLOPS + f8_fl / MFMA_FP8_PEAK_TFLOPS
+        # --dtype fp32: every large product is ONE bf16 launch over hi / lo splits of its f32 operands (3 x the reduction length:
+        # kernels.f32_mfma, leccr_split3).  The launches' own flop counts are the bf16 flops ISSUED; the algorithmic flops of the fp32
+        # products are a third of that, and the rate this formulation can reach at the bf16 MFMA peak is a third of 2.5 PF
+        x3 = 3.0 if args.dtype == 'fp32' else 1.0
+        issued = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        gemm_fl, bf_fl = gemm_fl / x3, bf_fl / x3
+        achieved = issued / x3
+        t_peak = bf_fl / (MFMA_BF16_PEAK_TFLOPS / x3) + f8_fl / MFMA_FP8_PEAK_TFLOPS
         peak = gemm_fl / t_peak if t_peak > 0 else MFMA_BF16_PEAK_TFLOPS
         mixed = None
         if f8_n:
@@ -487,7 +493,7 @@ def _main(args, real_stdout):
                 tr = json.load(fh)      # of this same command (FETCH_SIZE x2 + WRITE_SIZE, per launch) are reported
             traffic, traffic_src = round(tr['hbm_bytes_per_launch']), 'profiles/' + os.path.basename(tj)
         hbm = []
-        for k, name in enumerate(HBM_KINDS, start=5):
+        for k, name in list(enumerate(HBM_KINDS, start=5)) + [(13, 'split3 (f32 -> bf16 hi / lo copies)')]:
             if leg_n[k] and leg_ms[k] > 0:
                 tbs = leg_work[k] / (leg_ms[k] * 1e-3) / 1e12
                 hbm.append({'kernel': name, 'launches_per_step': leg_n[k] // leg, 'ms_per_step': round(leg_ms[k] / leg, 3),
@@ -515,7 +521,10 @@ def _main(args, real_stdout):
                        'world': world, 'backend': backend if world > 1 else None, 'rccl_version': rccl,
                        'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'LECCR_RCCL_CUS': rccl_cus()},
             'roofline': {'bound': 'mfma', 'kernel': ('gemm256 family (256x256 MFMA GEMMs: 8-wave NT forward / dX, 4-wave TN weight gradient'
-                                                     + (', fp8-operand 4-wave NT / TN' if args.dtype == 'fp8' else '') + ')'),
+                                                     + (', fp8-operand 4-wave NT / TN' if args.dtype == 'fp8' else '') + ')'
+                                                     + ('; fp32 operands as bf16 hi / lo splits: achieved = fp32-product flops / time, peak = bf16 MFMA peak / 3 '
+                                                        '(three bf16 products per fp32 product; the f32 MFMA instruction peaks at 157)' if args.dtype == 'fp32' else '')),
+                         'mfma_issued_tflops': round(issued, 1),
                          'achieved': round(achieved, 1), 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'by_operand_type': mixed,
                          'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'traffic_unit': 'HBM bytes per launch (PMC)', 'traffic_source': traffic_src,

@@ -144,8 +144,11 @@ int leccr_gemm(const leccr_gemm_params* p, void* stream);
  *   form 1 ("G": gradients; the [out, in] weight of the forward product):    hi | lo | hi
  * so that an X-form operand against a G-form operand pairs up as hh + hl + lh whichever is A or B (NT: K' = 3 K, lda = ldb = 3 K).
  * The same memory read as [3 * rows, cols] is the row-interleaved form of the weight-gradient product (TN: K' = 3 * rows).
- * transpose = 1: the split of src^T, dst [cols, 3 * rows].  src f32, row stride ld_src elements. */
-int leccr_split3(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int form, int transpose, void* stream);
+ * transpose = 1: the split of src^T, dst [cols, 3 * rows].  src f32, row stride ld_src elements.
+ * colsum (optional, transpose = 0, cols % 8 == 0, cols <= 8192): colsum[c] += sum_r src[r][c] in the same pass - the bias gradient
+ * when src is a dY (the column sums of the split copy itself would count hi twice). */
+int leccr_split3(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int form, int transpose, float* colsum,
+                 void* stream);
 
 /* ---- LayerNorm --------------------------------------------------------------------------------------------
  * y = (x - mean) * rstd * gamma + beta over the last axis, statistics in f32.

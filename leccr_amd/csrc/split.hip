@@ -46,6 +46,43 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ s
     *reinterpret_cast<bf16x8*>(d + 2 * cols) = form == 0 ? l : h;
 }
 
+// The same with the column sums of src riding along (colsum[c] += sum_r src[r][c]: the bias gradient when src is a dY - one pass
+// over dY instead of the split pass plus leccr_colsum's).  A thread keeps ONE 8-column chunk for all the rows it visits (block =
+// rpb rows x `chunks` threads, blocks stride over the rows), so its eight partial sums stay in registers; the rpb row-threads of a
+// chunk are added up in LDS and each block issues one f32 atomic per column.
+__global__ __launch_bounds__(1024) void split3_colsum_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows,
+                                                             int64_t cols, int64_t ld, int form, float* __restrict__ colsum, int rpb) {
+    extern __shared__ float part[];                    // [rpb][cols]
+    const int chunks = (int)(cols >> 3);
+    const int ch = threadIdx.x % chunks, rr = threadIdx.x / chunks;
+    const int64_t c = (int64_t)ch << 3;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rr; r < rows; r += (int64_t)gridDim.x * rpb) {
+        const float* s = src + r * ld + c;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(s), b = *reinterpret_cast<const f32x4*>(s + 4);
+        bf16x8 h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bf16_t hh, ll;
+            split2(a[i], hh, ll); h[i] = hh; l[i] = ll; acc[i] += a[i];
+            split2(b[i], hh, ll); h[4 + i] = hh; l[4 + i] = ll; acc[4 + i] += b[i];
+        }
+        bf16_t* d = dst + r * 3 * cols + c;
+        *reinterpret_cast<bf16x8*>(d) = h;
+        *reinterpret_cast<bf16x8*>(d + cols) = form == 0 ? h : l;
+        *reinterpret_cast<bf16x8*>(d + 2 * cols) = form == 0 ? l : h;
+    }
+    float* mine = part + (size_t)rr * cols + c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[i] = acc[i];
+    __syncthreads();
+    for (int64_t col = threadIdx.x; col < cols; col += blockDim.x) {
+        float t = 0.f;
+        for (int j = 0; j < rpb; ++j) t += part[(size_t)j * cols + col];
+        atomicAdd(colsum + col, t);
+    }
+}
+
 // any cols (scalar accesses): small / odd operands
 __global__ __launch_bounds__(256) void split3_scalar_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows,
                                                             int64_t cols, int64_t ld, int form) {
@@ -90,7 +127,8 @@ __global__ __launch_bounds__(256) void split3_t_kernel(const float* __restrict__
 
 using namespace leccr;
 
-extern "C" int leccr_split3(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld, int form, int transpose, void* stream) {
+extern "C" int leccr_split3(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld, int form, int transpose, float* colsum,
+                            void* stream) {
     LECCR_REQUIRE(src && dst, LECCR_EINVAL, "split3: null pointer");
     LECCR_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols, LECCR_EINVAL, "split3: bad sizes");
     LECCR_REQUIRE(form == 0 || form == 1, LECCR_EINVAL, "split3: form must be 0 (hi|hi|lo) or 1 (hi|lo|hi)");
@@ -98,9 +136,22 @@ extern "C" int leccr_split3(const float* src, void* dst, int64_t rows, int64_t c
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_SPLIT, 10.0 * (double)rows * (double)cols, st);
     bf16_t* d = reinterpret_cast<bf16_t*>(dst);
+    const bool vec = (cols & 7) == 0 && (ld & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0;
+    if (colsum) {
+        LECCR_REQUIRE(!transpose && vec && (cols >> 3) <= 1024, LECCR_EINVAL, "split3: colsum needs transpose = 0, cols %% 8 == 0, cols <= 8192, 16-byte aligned rows");
+        const int chunks = (int)(cols >> 3);
+        int rpb = 512 / chunks;
+        if (rpb < 1) rpb = 1;
+        int64_t grid = cdiv(rows, (int64_t)rpb * 8);              // >= 8 rows per thread amortise the atomics
+        if (grid > 2048) grid = 2048;
+        if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(split3_colsum_kernel, dim3((unsigned)grid), dim3(chunks * rpb), (size_t)rpb * cols * sizeof(float), st, src, d, rows,
+                           cols, ld, form, colsum, rpb);
+        return check_launch("split3");
+    }
     if (transpose) {
         hipLaunchKernelGGL(split3_t_kernel, dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32)), dim3(256), 0, st, src, d, rows, cols, ld, form);
-    } else if ((cols & 7) == 0 && (ld & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 15) == 0) {
+    } else if (vec) {
         hipLaunchKernelGGL(split3_kernel, dim3((unsigned)cdiv(rows * (cols >> 3), 256)), dim3(256), 0, st, src, d, rows, cols, ld, form);
     } else {
         hipLaunchKernelGGL(split3_scalar_kernel, dim3((unsigned)cdiv(rows * cols, 256)), dim3(256), 0, st, src, d, rows, cols, ld, form);

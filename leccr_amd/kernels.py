@@ -37,13 +37,21 @@ def set_f32_mfma(on):
     return prev
 
 
-def split3(x, form, transpose=False):
-    """f32 [rows, cols] (unit inner stride) -> bf16 [rows, 3 * cols] (transpose: [cols, 3 * rows]) in hi / lo form `form`."""
+def split3(x, form, transpose=False, colsum=None):
+    """f32 [rows, cols] (unit inner stride) -> bf16 [rows, 3 * cols] (transpose: [cols, 3 * rows]) in hi / lo form `form`.
+    colsum ([cols] f32): += the column sums of x, in the same pass (the bias gradient beside a dY's split)."""
     assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and form in (FORM_X, FORM_G)
     rows, cols = x.shape
     out = torch.empty((cols, 3 * rows) if transpose else (rows, 3 * cols), device=x.device, dtype=torch.bfloat16)
-    check(lib().leccr_split3(ptr(x), ptr(out), rows, cols, x.stride(0), form, int(transpose), stream()), 'leccr_split3')
+    if colsum is not None:
+        assert colsum.dtype == torch.float32 and colsum.numel() == cols and colsum.is_contiguous() and not transpose
+    check(lib().leccr_split3(ptr(x), ptr(out), rows, cols, x.stride(0), form, int(transpose), ptr(colsum), stream()), 'leccr_split3')
     return out
+
+
+def split3_colsum_ok(x):
+    """Shapes whose split pass can carry the column sums (leccr_split3's colsum)."""
+    return x.shape[1] % 8 == 0 and x.shape[1] <= 8192 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
 
 
 def _split_plan(a, b, trans_a, trans_b, out, accumulate, asum):

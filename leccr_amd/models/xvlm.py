@@ -4,7 +4,9 @@ Extensions (all optional, defaults reproduce the reference's hard-coded choices)
   config['clip_name']      'ViT-B/32' (reference default, xvlm.py:85) | 'ViT-B/16' | 'ViT-L/14'
   config['text_config']    dict of BERT geometry overrides (default: bert-base-multilingual-cased geometry)
   config['clip_geometry']  dict of CLIP constructor arguments overriding clip_name (tiny parity fixtures)
-  config['compute_dtype']  'fp32' (reference precision, parity path) | 'bf16' (MFMA path) | 'fp8' (BASELINE configs[4]: the bf16 path with
+  config['compute_dtype']  'fp32' (DEFAULT = what the reference's configs get: reference precision, f32 activations, every large product on
+                           the matrix cores as bf16 hi / lo splits - leccr_split3 - and the f32 MFMA flash attention; LECCR_F32_MFMA=0: the
+                           scalar f32 kernels) | 'bf16' (MFMA path, BASELINE config B) | 'fp8' (BASELINE configs[4]: the bf16 path with
                            OCP fp8 operands - e4m3 forward, e5m2 gradients, per-tensor delayed scaling - in the forward and dX GEMMs of
                            the ViT blocks and BERT layers; LayerNorm, softmax, residuals, weight gradients, heads and losses as in bf16)
   config['clip_text_tower'] keep the unused CLIP text tower's parameters for state_dict compatibility (default True)
@@ -259,6 +261,14 @@ class XVLMBase(nn.Module):
             a.need_transposed(layer._qkv_w)
         if self.fp8:
             self._enable_fp8(a, dev)
+        elif self.compute_dtype == torch.float32:
+            # reference precision (xvlm.py:88: fp32 throughout) on the matrix cores: the encoder blocks hand bf16 hi / lo split copies
+            # of their f32 activations / gradients from product to product (ops.X3; kernels.f32_mfma = False at run time: scalar kernels)
+            if self.clip_encoder is not None:
+                for blk in self.clip_encoder.visual.transformer.resblocks:
+                    blk.fp8 = ops.X3
+            for layer in self.text_encoder.encoder.layer:
+                layer.fp8 = ops.X3
         if getattr(self, 'caption_encoder_name', None) == 'clip' and self.clip_encoder is not None:
             self.clip_encoder.prepare_text_tower(self.compute_dtype)        # forward-only caption encoder: static compute copies
         a.refresh()

@@ -130,15 +130,52 @@ fp8_dw = os.environ.get('LECCR_FP8_DW', '1') != '0'
 fp8_dw_launches = 0          # fp8 weight-gradient products launched (tests read it)
 
 
+# fp32 mode (compute_dtype 'fp32' with kernels.f32_mfma): the encoder blocks carry mode X3 in their `fp8` attribute and the SAME
+# hand-over points that pass fp8 copies around pass the bf16 hi / lo split copies of leccr_split3 instead - an activation is split
+# ONCE (X form: forward product and weight-gradient product), a gradient once (G form: dX product and weight-gradient product, its
+# column sums = the bias gradient riding in the same pass).  Linears outside the blocks go through kernels.gemm's automatic
+# splitting (each product splits its own operands).
+X3 = 'x3'
+
+
+def _x3_lin_ok(rows, w):
+    """A Linear whose three products (forward, dX, dW) all run on the split copies: in / out features whole 64-element K-tiles."""
+    out_f, in_f = w._lp.shape
+    return (K.f32_mfma and w._lp.dtype == torch.float32 and w._lp.stride(1) == 1 and out_f % 64 == 0 and in_f % 64 == 0
+            and rows * out_f * in_f >= K._SPLIT_MIN_WORK)
+
+
+def _is_x3(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
 def x8_of(fp8, x2, w, x8=None):
-    """The e4m3 copy of x2 that Linear `w` multiplies in fp8 mode (x8 if the producer wrote it), None when that product is bf16."""
+    """The e4m3 copy of x2 that Linear `w` multiplies in fp8 mode (x8 if the producer wrote it), None when that product is bf16.
+    Mode X3: the X-form split copy of the f32 x2."""
+    if fp8 == X3:
+        if x2.dtype != torch.float32 or not _x3_lin_ok(x2.shape[0], w) or x2.stride(1) != 1:
+            return None
+        return x8 if x8 is not None else K.split3(x2, K.FORM_X)
     if not (fp8 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8)):
         return None
     return x8 if x8 is not None else w._xsite.quantize(x2)
 
 
-def g8_of(fp8, dy2, w, g8=None):
-    """The e5m2 copy of the incoming gradient dy2 of Linear `w` in fp8 mode, None when its dX product is bf16."""
+def g8_of(fp8, dy2, w, g8=None, bias=None):
+    """The e5m2 copy of the incoming gradient dy2 of Linear `w` in fp8 mode, None when its dX product is bf16.
+    Mode X3: the G-form split copy of the f32 dy2; with `bias` (the Linear's bias holder) its gradient colsum(dy2) is summed in the
+    same pass and the copy is tagged (`_bias_done`) so that lin_dw does not sum it again."""
+    if fp8 == X3:
+        if dy2 is None or dy2.dtype != torch.float32 or not _x3_lin_ok(dy2.shape[0], w) or dy2.stride(1) != 1:
+            return None
+        if g8 is not None:
+            return g8
+        fuse = bias is not None and fuse_bias_grad and K.split3_colsum_ok(dy2)
+        g3 = K.split3(dy2, K.FORM_G, colsum=bias._g.reshape(-1) if fuse else None)
+        if fuse:
+            g3._bias_done = True
+            _mark(bias)
+        return g3
     if not (fp8 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t)):
         return None
     return g8 if g8 is not None else w._gsite.quantize(dy2)
@@ -148,7 +185,10 @@ def dw_keep(x2, x8, w):
     """What the backward pass must keep of a Linear's input x2 for its weight-gradient product: x2 itself, or - when that product will
     run from the fp8 copy x8 (fp8_dw, >= 2048 rows, in / out whole 256-tiles) - only the rows past the last whole 128-row K-tile, which
     go to the bf16 kernel (an empty tensor when there are none).  The bf16 h1 / h2 / activation tensors of a block are needed for
-    nothing else, so fp8 mode holds 1 byte per element of them instead of 2 (+1)."""
+    nothing else, so fp8 mode holds 1 byte per element of them instead of 2 (+1).
+    Mode X3 (x8 = the bf16 split copy): the weight-gradient product reads only that copy - the f32 tensor is not kept."""
+    if _is_x3(x8):
+        return x2[:0] if (x2.dtype == torch.float32 and _x3_lin_ok(x8.shape[0], w)) else x2
     if (fp8_dw and x8 is not None and x2.shape[0] >= 2048 and x2.shape[1] % 256 == 0 and w._q8.shape[0] % 256 == 0
             and x8.stride(0) % 16 == 0 and x8.data_ptr() % 16 == 0):
         return x2[x2.shape[0] // 128 * 128:].clone()
@@ -178,7 +218,10 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
     x8: x2's fp8 copy when the producer already wrote it (c8_site).  c8_site: the activation site of the Linear that CONSUMES this
     output: once that site has a scale, the epilogue also writes the output's fp8 copy under it (no separate quantise pass over
     it).  want8: return (y, y8 or None) instead of y.  c8_only (fp8_only_ok): y itself is not written, (None, y8) comes back."""
-    if fp8 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8):
+    if fp8 == X3 and _is_x3(x8):              # f32 operands as bf16 hi / lo splits: x8 = X-form copy of x2, the weight split in G form
+        y = K.gemm(x8, K.split3(w._lp, K.FORM_G), bias=_bias(b), out_dtype=torch.float32, **kw)
+        return (y, None) if want8 else y
+    if fp8 and fp8 != X3 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8):
         if x8 is None:
             x8 = w._xsite.quantize(x2)
         c8 = None
@@ -194,7 +237,10 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
 def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False, **kw):
     """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N].
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
-    if fp8 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t):
+    if fp8 == X3 and _is_x3(g8):              # G-form copy of dY against the X-form split of W^T ([in, 3 out], K-contiguous)
+        y = K.gemm(g8, K.split3(w._lp, K.FORM_X, transpose=True), out_dtype=torch.float32, **kw)
+        return (y, None) if want8 else y
+    if fp8 and fp8 != X3 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t):
         if g8 is None:
             g8 = w._gsite.quantize(dy2)
         c8 = None
@@ -284,12 +330,20 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_d
     dy2 None (fp8_only_ok): only the fp8 copy of the gradient exists - no tail rows, and the bias gradient was summed by the
     producing GEMM's epilogue (bias_done)."""
     global _wgrad_stream, _wgrad_join_queued, _wgrad_throttle
-    if not (fp8_dw and g8 is not None and x8 is not None and _fp8_dw_ok(g8, x8)):
+    if _is_x3(g8) and _is_x3(x8) and g8.shape[0] == x8.shape[0]:
+        pass            # mode X3: both split copies at hand - the product reads only them
+    elif _is_x3(g8) or _is_x3(x8):
+        if dy2 is None or x2.shape[0] != dy2.shape[0]:
+            raise RuntimeError('lin_dw: a split copy without its partner and without the f32 operands')
+        g8 = x8 = None
+    elif not (fp8_dw and g8 is not None and x8 is not None and _fp8_dw_ok(g8, x8)):
         if dy2 is None or x2.shape[0] != dy2.shape[0]:
             raise RuntimeError('lin_dw: only the fp8 copy of an operand was kept (dw_keep / fp8_only_ok) but the fp8 weight-gradient product '
                                'is not available for dY8 %s / X8 %s' % (None if g8 is None else tuple(g8.shape), None if x8 is None else tuple(x8.shape)))
         g8 = x8 = None
-    if dy2 is None:
+    if _is_x3(g8):
+        bias_done = bias_done or getattr(g8, '_bias_done', False)
+    elif dy2 is None:
         assert g8.shape[0] % 128 == 0 and (b is None or bias_done)
     ref = dy2 if dy2 is not None else g8
     if not (wgrad_overlap and ref.is_cuda):
@@ -369,7 +423,13 @@ def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None, bias_done=Fals
         _mark(b)
         b = None
     fused = b is not None and dy_bias is None and scale == 1.0 and fuse_bias_grad
-    if g8 is not None:
+    if _is_x3(g8):
+        # f32 operands as bf16 hi / lo splits: the [rows, 3 cols] copies read as [3 rows, cols], one TN launch over 3 x rows
+        rows = g8.shape[0]
+        K.gemm(g8.view(3 * rows, g8.shape[1] // 3), x8.view(3 * rows, x8.shape[1] // 3), trans_a=True, trans_b=True, out=w._g,
+               accumulate=True, alpha=scale)
+        fused = False           # (the split copy's own column sums would count hi twice: colsum over the f32 gradient below)
+    elif g8 is not None:
         # fp8 operands: whole 128-row K-tiles on the scaled-MFMA kernel, the (< 128-row) tail and the bias sums from the bf16 tensors
         global fp8_dw_launches
         fp8_dw_launches += 1
@@ -584,7 +644,7 @@ class ViTBlockFn(torch.autograd.Function):
         dx2 = dx2.contiguous()
         g2 = _rows(dx2)
         g2_8 = _g8_take(g2) if blk.fp8 else None          # written by the next block's LayerNorm-1 backward (fp8 mode)
-        g2_8 = g8_of(blk.fp8, g2, blk.mlp.c_proj.weight, g2_8)
+        g2_8 = g8_of(blk.fp8, g2, blk.mlp.c_proj.weight, g2_8, bias=blk.mlp.c_proj.bias)
         # (fp8: when c_fc's dX and weight-gradient products both read dpre's e5m2 copy, the bf16 dpre is not written; its column sums -
         #  c_fc's bias gradient - then come out of the same epilogue)
         dpre_8only = blk.fp8 and g2_8 is not None and h2_8 is not None and fp8_only_ok(g2.shape[0], blk.mlp.c_fc.weight, True)
@@ -596,7 +656,7 @@ class ViTBlockFn(torch.autograd.Function):
         # cost that kernel a fifth of its occupancy - 253 us against 201 us per launch on the main chain
         lin_dw(g2, act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, g8=g2_8, x8=act8)
         if dpre is not None:
-            dpre8 = g8_of(blk.fp8, dpre, blk.mlp.c_fc.weight, dpre8)
+            dpre8 = g8_of(blk.fp8, dpre, blk.mlp.c_fc.weight, dpre8, bias=blk.mlp.c_fc.bias)
         dh2 = lin_dx(dpre if dpre is not None else dpre8, blk.mlp.c_fc.weight, fp8=blk.fp8, g8=dpre8)
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
@@ -604,7 +664,7 @@ class ViTBlockFn(torch.autograd.Function):
         dx1, _, g1_8 = _ln_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g, blk.ln_2.bias._g,
                                site=_q8_site(blk.fp8, b * N, blk.attn.out_proj.weight, '_gsite'), dres=dx2)
         g1 = _rows(dx1)
-        g1_8 = g8_of(blk.fp8, g1, blk.attn.out_proj.weight, g1_8)
+        g1_8 = g8_of(blk.fp8, g1, blk.attn.out_proj.weight, g1_8, bias=blk.attn.out_proj.bias)
         do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8, g8=g1_8).view(b, N, d)
         lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, g8=g1_8, x8=o_8)
         dqkv = torch.empty_like(qkv)
@@ -615,7 +675,7 @@ class ViTBlockFn(torch.autograd.Function):
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], causal=getattr(blk, 'causal', False),
                    q8=None if dqkv8 is None else (dqkv8[..., :d], dqkv8[..., d:2 * d], dqkv8[..., 2 * d:], g_site))
-        dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight, None if dqkv8 is None else _rows(dqkv8))
+        dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight, None if dqkv8 is None else _rows(dqkv8), bias=blk.attn.in_proj_bias)
         dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)
         lin_dw(_rows(dqkv), h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
         # (fp8: dx is the gradient the previous block's c_proj dX product consumes: its e5m2 copy goes with it)
@@ -756,7 +816,7 @@ class BertLayerFn(torch.autograd.Function):
                                  out.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, out.dense.weight, '_gsite'),
                                  drop=(ph, seeds[2]) if ph > 0 else None)
         g2, gd2 = _rows(g2), _rows(gd2)
-        gd2_8 = g8_of(layer.fp8, gd2, out.dense.weight, gd2_8)
+        gd2_8 = g8_of(layer.fp8, gd2, out.dense.weight, gd2_8, bias=out.dense.bias)
         inter = layer.intermediate.dense
         dpre_8only = layer.fp8 and gd2_8 is not None and x1_8 is not None and fp8_only_ok(gd2.shape[0], inter.weight, True)
         dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, g8=gd2_8, epilogue=EPI_DGELU, aux=pre,
@@ -764,14 +824,14 @@ class BertLayerFn(torch.autograd.Function):
                              **(dict(colsum=inter.bias._g.reshape(-1)) if dpre_8only else {}))
         lin_dw(gd2, h, out.dense.weight, out.dense.bias, g8=gd2_8, x8=h8)
         if dpre is not None:
-            dpre8 = g8_of(layer.fp8, dpre, inter.weight, dpre8)
+            dpre8 = g8_of(layer.fp8, dpre, inter.weight, dpre8, bias=inter.bias)
         dx1 = lin_dx(dpre if dpre is not None else dpre8, inter.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
         lin_dw(dpre, x1, inter.weight, inter.bias, g8=dpre8, x8=x1_8, bias_done=dpre is None)
         g1, gd1, gd1_8 = _ln_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                                  ao.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, ao.dense.weight, '_gsite'),
                                  drop=(ph, seeds[1]) if ph > 0 else None)
         g1, gd1 = _rows(g1), _rows(gd1)
-        gd1_8 = g8_of(layer.fp8, gd1, ao.dense.weight, gd1_8)
+        gd1_8 = g8_of(layer.fp8, gd1, ao.dense.weight, gd1_8, bias=ao.dense.bias)
         do = lin_dx(gd1, ao.dense.weight, fp8=layer.fp8, g8=gd1_8).view(b, L, d)
         lin_dw(gd1, _rows(o), ao.dense.weight, ao.dense.bias, g8=gd1_8, x8=o_8)
         dqkv = torch.empty_like(qkv)
@@ -780,7 +840,7 @@ class BertLayerFn(torch.autograd.Function):
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, layer.heads, kmask,
                    dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], drop_p=pa, seed=seeds[0],
                    q8=None if dqkv8 is None else (dqkv8[..., :d], dqkv8[..., d:2 * d], dqkv8[..., 2 * d:], g_site))
-        dqkv8 = g8_of(layer.fp8, _rows(dqkv), layer._qkv_w, None if dqkv8 is None else _rows(dqkv8))
+        dqkv8 = g8_of(layer.fp8, _rows(dqkv), layer._qkv_w, None if dqkv8 is None else _rows(dqkv8), bias=layer._qkv_b)
         dx = lin_dx(_rows(dqkv), layer._qkv_w, fp8=layer.fp8, g8=dqkv8, residual=g1).view(b, L, d)       # + residual path of s1 = .. + x
         lin_dw(_rows(dqkv), x, layer._qkv_w, layer._qkv_b, g8=dqkv8, x8=x_8)
         for p in (out.LayerNorm.weight, out.LayerNorm.bias, ao.LayerNorm.weight, ao.LayerNorm.bias):

@@ -1245,7 +1245,7 @@ def test_gemm_fp8_fused_copy_of_the_output(K, grad):
 
 
 # ------------------------------------------------------------------------------------------------ fp32 operands on the bf16 matrix cores
-@pytest.mark.parametrize('rows,cols,ld', [(300, 768, 768), (37, 64, 96), (5, 20, 20), (256, 3072, 3072)])
+@pytest.mark.parametrize('rows,cols,ld', [(300, 768, 768), (37, 64, 96), (5, 20, 20), (256, 3072, 3072), (20000, 2304, 2304), (1000, 8192, 8192)])
 @pytest.mark.parametrize('form', [0, 1])
 def test_split3_writes_hi_lo_segments(K, rows, cols, ld, form):
     """leccr_split3: hi = bf16(x), lo = bf16(x - hi), laid out hi|hi|lo (form 0) or hi|lo|hi (form 1) - bit for bit what torch's own
@@ -1262,6 +1262,12 @@ def test_split3_writes_hi_lo_segments(K, rows, cols, ld, form):
     assert torch.equal(got_t.cpu().view(torch.int16), want_t.view(torch.int16))
     # hi + lo reproduces x to 2^-17 relative
     assert float(((hi.float() + lo.float()) - x).abs().max()) <= 2.0 ** -17 * float(x.abs().max())
+    if cols % 8 == 0:       # the bias gradient rides in the same pass: colsum += column sums of the f32 source, same bytes out
+        cs = torch.full((cols,), 0.5, device=DEV)
+        got_c = K.split3(x.to(DEV), form, colsum=cs)
+        assert torch.equal(got_c.cpu().view(torch.int16), want.contiguous().view(torch.int16))
+        e, s_ = _err(cs, 0.5 + x.double().sum(0))
+        assert e <= 2e-5 * s_, (e, s_)
 
 
 @pytest.mark.parametrize('M,N,K_', [(577 * 2, 768, 768), (1154, 2304, 768), (4096, 3072, 768), (2048, 768, 3072), (300, 260, 192), (64, 256, 128)])
