@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // 106 with the colsum partials: 4 waves - forcing 5 there spills and costs 75 %).
 // EX: the instantiation with the optional second outputs (dropout(dx), fp8 copy); the plain one keeps its 94 registers / 5 waves.
 template <typename T, int NCH, bool CS, bool EX>
-__global__ __launch_bounds__(256, NCH <= 3 ? ((CS || EX) ? 4 : 5) : 1) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xin,
+__global__ __launch_bounds__(256, NCH <= 3 ? ((CS || EX) ? 4 : 5) : (NCH == 4 ? 4 : 1)) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xin,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, const T* __restrict__ dres,
@@ -502,7 +502,9 @@ static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, 
                            int64_t rows, int64_t d, void* dx_drop, const DropCfg& drop, const Q8Out& q8, hipStream_t st) {
     int64_t nb = cdiv(rows, 4);
     const bool ex = dx_drop != nullptr || q8.out != nullptr;
-    const int64_t resident = (colsum_of || ex) ? 1024 : 1280;      // 4 / 5 workgroups per CU fit (registers): exactly one round
+    // 4 / 5 workgroups per CU fit (registers): exactly one round.  768 < d <= 1024 (four chunks per lane: 110 registers) fits 4 - with 1280
+    // workgroups a fifth of them ran as a second round: 456 us against 356 us for the (4-per-CU) EX instantiation at [186880, 1024]
+    const int64_t resident = (colsum_of || ex || (d > 768 && d <= 1024)) ? 1024 : 1280;
     if (nb > resident) nb = resident;
     dim3 grid((unsigned)nb);
 #define LB(N, CS_, EX_)                                                                                                         \
@@ -554,7 +556,7 @@ static int ln_fwd_entry(const void* x, const void* add, const float* gamma, cons
     DropCfg drop = make_drop(p, seed);
     if (p == 0.f) drop.thr = 0;
     const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
-    ProfScope prof(PROF_LN_FWD, (double)rows * d * esz * (2 + (add ? 1 : 0) + (sum_out ? 1 : 0)) + 8.0 * rows, st);
+    ProfScope prof(PROF_LN_FWD, (double)rows * d * (esz * (2 + (add ? 1 : 0) + (sum_out ? 1 : 0)) + (y8 ? 1.0 : 0.0)) + 8.0 * rows, st);
     DISPATCH_T(dtype, ln_fwd_dispatch<float>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, q8, st),
                ln_fwd_dispatch<bf16_t>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, q8, st));
 }
@@ -593,7 +595,7 @@ static int ln_bwd_entry(const void* dy, const void* x_in, const float* gamma, co
     hipStream_t st = as_stream(stream);
     const DropCfg drop = make_drop(dx_drop ? p : 0.f, seed);
     const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
-    ProfScope prof(PROF_LN_BWD, (double)rows * d * esz * (3 + (dres ? 1 : 0) + (dx_drop ? 1 : 0)) + 8.0 * rows, st);
+    ProfScope prof(PROF_LN_BWD, (double)rows * d * (esz * (3 + (dres ? 1 : 0) + (dx_drop ? 1 : 0)) + (g8 ? 1.0 : 0.0)) + 8.0 * rows, st);
     DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, q8, st),
                ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, q8, st));
 }

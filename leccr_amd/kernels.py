@@ -28,7 +28,8 @@ def _rows2d(t):
 FORM_X, FORM_G = 0, 1          # hi|hi|lo (activations, [in, out] weight copies)   /   hi|lo|hi (gradients, [out, in] weights)
 f32_mfma = os.environ.get('LECCR_F32_MFMA', '1') != '0'
 f32_split_launches = 0         # gemm() calls that took the split path (tests read it)
-_SPLIT_MIN_WORK = 1 << 18      # M * N * K below which the one-launch scalar kernel is as good
+_SPLIT_MIN_WORK = 1 << 27      # M * N * K below which the exact scalar kernel is as fast (the 256-wide heads in front of the 1 / temp
+                               # amplified losses among them: [b, 768] x [256, 768] at b = 256 is 2^25.6)
 
 
 def set_f32_mfma(on):

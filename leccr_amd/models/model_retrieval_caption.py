@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import diag, ops
 from .attention import CrossAttention
 from .layers import Linear
 from .xvlm import XVLMBase, _dist_info, local_rows
@@ -171,7 +171,10 @@ class RetrievalModel(XVLMBase):
         text_feat_s, text_feat_t = feats[:b], feats[b:]
         cq = self.caption_proj1(after_caption, out_f32=True).contiguous()   # [b, n, D] f32
         # every block the loss terms gather (W > 1), in one collective instead of sixteen
+        diag.begin('loss_stage_fwd')
+        diag.begin('allgather')
         self.gathers.packed([image_feat, text_feat_s, text_feat_t, cq, pc, pv], None if idx is None else idx.view(-1, 1))
+        diag.end('allgather')
         loss_cv = self._cv_loss_pooled(pc, pv, idx) * self.weight_cv_loss
 
         loss_itc_vs = self.get_contrastive_loss(image_feat, text_feat_s, idx=idx, tval=tval)
@@ -184,5 +187,6 @@ class RetrievalModel(XVLMBase):
         loss_dstl = ops.DstlFn.apply(gather_rows(image_feat), gather_rows(cq), gather_rows(text_feat_s),
                                      gather_rows(text_feat_t), 0.8, local_rows(image_feat.size(0))) * self.weight_dstl_loss
         loss_itc_vt = loss_itc_vt * (1 - self.weight_dstl_loss) + loss_dstl
+        diag.end('loss_stage_fwd')
         return (loss_itc_vs + loss_cv, loss_itc_vt, loss_itc_st, loss_itc_c * self.weight_caption_loss,
                 loss_reg_c * self.weight_reg_loss)

@@ -115,8 +115,11 @@ def attach_grad_sync(optimizer):
             reduce_range(0, split)
         reduce_range(split, late['hi'])
         late['hi'] = grad.numel()
+        from . import diag
+        diag.begin('allreduce_exposed')          # how long the stream of optimizer.step() waits here = what the backward did not hide
         for w in pending:
             w.wait()
+        diag.end('allreduce_exposed')
         pending.clear()
         gemm_cus(0)
 

@@ -275,6 +275,23 @@ def fixture_model_w2():
     print('model_tiny_w2 losses', out['r0/losses'], out['r1/losses'])
 
 
+def fixture_model_w4():
+    """The same global batch over FOUR ranks of the reference under gloo DDP (SURVEY.md 8(c) `losses_w4`; xvlm.py:50-70,
+    model_retrieval_caption.py:94-143): per-rank losses and the DDP-averaged gradients, with the 1/W-vs-full scaling at W = 4."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_w2_worker, args=(4, 29613, ret), nprocs=4, join=True)
+    out = {}
+    for r in range(4):
+        for k, v in ret[r].items():
+            if r == 0 or k == 'losses':
+                out[f'r{r}/{k}'] = v
+            else:
+                assert np.allclose(v, ret[0][k], atol=1e-7), k
+    np.savez_compressed(os.path.join(OUT, 'model_tiny_w4.npz'), **out)
+    print('model_tiny_w4 losses', [out[f'r{r}/losses'] for r in range(4)])
+
+
 def fixture_losses(clip_model, xvlm):
     """Each loss function on its own, with gradients w.r.t. its inputs and temp."""
     model = build_model(clip_model, xvlm)
@@ -616,13 +633,16 @@ def main():
     if os.path.dirname(os.path.dirname(OUT)) not in sys.path:
         sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))          # tests.helpers (seeded_fill_)
     only = set(sys.argv[1:])
+    if only == {'w4'}:
+        fixture_model_w4()
+        return
     torch.set_num_threads(4)
     clip_model, xvlm = import_reference()
     if not dist.is_initialized():
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29610')
         dist.init_process_group('gloo', rank=0, world_size=1)
     if only:            # python tests/golden/make_golden.py full  -> only the full-geometry fixtures (minutes of CPU)
-        assert only <= {'full', 'captions', 'b32', 'clipcap'}, only
+        assert only <= {'full', 'captions', 'b32', 'clipcap', 'w4'}, only
         if only == {'clipcap'}:
             fixture_model_clipcap(clip_model, xvlm)
             dist.destroy_process_group()
@@ -660,6 +680,7 @@ def main():
     fixture_caption_store()
     dist.destroy_process_group()
     fixture_model_w2()
+    fixture_model_w4()
 
 
 if __name__ == '__main__':

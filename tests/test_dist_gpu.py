@@ -47,7 +47,7 @@ def _worker(rank, world, port, ret):
     from leccr_amd.parallel import attach_grad_sync
     from tests.helpers import grad_close, load_npz, weights
     from tests.test_model_gpu import MODEL_VIT, TINY_BERT, build, run
-    z1, z2 = load_npz('model_tiny_w1.npz'), load_npz('model_tiny_w2.npz')
+    z1, z2 = load_npz('model_tiny_w1.npz'), load_npz(f'model_tiny_w{world}.npz')
     model = build(dict(clip_geometry=MODEL_VIT, text_config=TINY_BERT, compute_dtype='fp32'), weights(z1))
     opt = attach_grad_sync(create_optimizer(dict(lr=0.0, weight_decay=0.0), model))
     b = 8 // world
@@ -77,6 +77,18 @@ def test_two_rank_losses_and_gradients_match_reference_ddp():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, 29651, ret), nprocs=2, join=True)
     for r in (0, 1):
+        n, bad = ret[r]
+        assert n > 100 and not bad, (r, bad)
+
+
+def test_four_rank_losses_and_gradients_match_reference_ddp():
+    """The reference captured under FOUR-rank DDP (tests/golden/model_tiny_w4.npz; SURVEY.md 8(c) `losses_w4`): four HIP ranks on the
+    GPU reproduce its per-rank losses and rank-averaged gradients - the packed gather, the local-rows backward and the 1/W-vs-full
+    scaling (models/xvlm.py:50-70, model_retrieval_caption.py:94-143) at W = 4, against the reference itself, not the oracle."""
+    mgr = _manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(4, 29655, ret), nprocs=4, join=True)
+    for r in range(4):
         n, bad = ret[r]
         assert n > 100 and not bad, (r, bad)
 

@@ -117,7 +117,7 @@ def test_evaluation_coarse_video_double_sim():
 
 
 # ----------------------------------------------------------------------------------------- full geometry, end to end
-def _full_eval_case(dtype, ni=64, per=5):
+def _full_eval_case(dtype, ni=64, per=5, geometry=None, structured=False):
     """evaluation_coarse (image_Retrieval_caption.py:83-163) on the reference's DEFAULT towers at full size - ViT-B/32 @384 (145
     tokens; models/xvlm.py:83-88) + mBERT, 12 + 12 layers, 3 + 2 + 2 interaction layers - over `ni` images with a generated caption
     each (L_c = 64) and per * ni texts (L_t = 32, MSCOCO-style 5 per image): scores from the HIP encoders, scores from the oracle's
@@ -125,13 +125,42 @@ def _full_eval_case(dtype, ni=64, per=5):
     from leccr_amd.evaluation import evaluation_coarse
     from oracle import leccr_oracle as O
     from tests.helpers import B32_GEOMETRY, MBERT_VOCAB, full_geometry_model, seeded_tokens
-    model, _ = full_geometry_model(dtype, seed=161, geometry=B32_GEOMETRY)
+    model, _ = full_geometry_model(dtype, seed=161, geometry=geometry or B32_GEOMETRY)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith('caption_encoder.')}
-    model = model.to('cuda').eval()
     g = torch.Generator().manual_seed(7)
     image = torch.randn(ni, 3, 384, 384, generator=g)
     ids_c, m_c = seeded_tokens(8, ni, 64, MBERT_VOCAB, min_len=8)
     ids_t, m_t = seeded_tokens(9, ni * per, 32, MBERT_VOCAB, min_len=8)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        vis = O.encode_image(sd, 'clip_encoder.visual.', image)
+        cap = O.bert_forward(sd, 'text_encoder.', ids_c, m_c, 12)
+        a_img, _, _ = O.interaction_with_caption(sd, vis, cap, ~m_c.bool())
+        txt = O.bert_forward(sd, 'text_encoder.', ids_t, m_t, 12)
+        if structured:
+            # Scores with STRUCTURE (random-init towers score every pair within 1e-4 of every other: nothing for a ranking test to
+            # hold on to).  The two projection heads are fitted - ridge least squares on the oracle's own [CLS] vectors - so that image i
+            # lands on a unit code c_i and each of its `per` texts on the same code: ground-truth scores near 1, the rest near 0, as a
+            # trained model's are.  The towers (what the kernels compute) stay as they are; only the 256-wide heads are chosen.
+            codes = torch.linalg.qr(torch.randn(256, ni, generator=g, dtype=torch.float64))[0].t().contiguous()      # [ni, 256] orthonormal rows
+
+            def fit(x, target):
+                x = x.double()
+                mu = x.mean(0, keepdim=True)
+                a = x - mu
+                gram = a @ a.t()
+                lam = 1e-3 * float(torch.diagonal(gram).mean())
+                w = (a.t() @ torch.linalg.solve(gram + lam * torch.eye(len(a), dtype=torch.float64), target)).t()      # [256, in]
+                return w.float().contiguous(), (-(w @ mu.t()).squeeze(1)).float().contiguous()
+            wv, bv = fit(a_img[:, 0, :], codes)
+            wt, bt = fit(txt[:, 0, :], codes[torch.arange(ni * per) // per])
+            for name, t in (('vision_proj.weight', wv), ('vision_proj.bias', bv), ('text_proj.weight', wt), ('text_proj.bias', bt)):
+                sd[name] = t
+                dict(model.named_parameters())[name].data.copy_(t)
+        fv = O.get_features(sd, image_embeds=a_img)
+        ft = O.get_features(sd, text_embeds=txt)
+    ref = (fv @ ft.t()).numpy()
+    model = model.to('cuda').eval()
 
     class Tok:
         def __call__(self, text, **kw):
@@ -146,14 +175,6 @@ def _full_eval_case(dtype, ni=64, per=5):
     bs = 6                                              # config batch_size_test (Retrieval_multi30k_de_ft.yaml); ragged last batch
     loader = Loader([(image[i:i + bs], [f'c{j}' for j in range(i, min(ni, i + bs))], None) for i in range(0, ni, bs)])
     i2t, t2i = evaluation_coarse(model, loader, Tok(), 'cuda', {'batch_size_test_text': 32, 'max_tokens': 200})
-    torch.set_num_threads(16)
-    with torch.no_grad():
-        vis = O.encode_image(sd, 'clip_encoder.visual.', image)
-        cap = O.bert_forward(sd, 'text_encoder.', ids_c, m_c, 12)
-        a_img, _, _ = O.interaction_with_caption(sd, vis, cap, ~m_c.bool())
-        fv = O.get_features(sd, image_embeds=a_img)
-        ft = O.get_features(sd, text_embeds=O.bert_forward(sd, 'text_encoder.', ids_t, m_t, 12))
-    ref = (fv @ ft.t()).numpy()
     img2txt = {i: list(range(i * per, (i + 1) * per)) for i in range(ni)}
     txt2img = {t: t // per for t in range(ni * per)}
     return i2t, t2i, ref, img2txt, txt2img
@@ -204,3 +225,34 @@ def test_full_geometry_evaluation_bf16_reports_delta_recall():
     delta = {k: float(got[k]) - float(want[k]) for k in ('txt_r1', 'txt_r5', 'txt_r10', 'img_r1', 'img_r5', 'img_r10')}
     print(f'full-geometry eval bf16: max |score err| {err:.2e}, delta R@K {delta}')
     assert all(abs(v) <= 8.0 for v in delta.values()), delta
+
+
+
+@pytest.mark.parametrize('tower', ['b32', 'b16'])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp32'])
+def test_full_geometry_evaluation_with_structured_scores_ranks_equal_the_oracle(dtype, tower):
+    """Ranking parity where the scores HAVE structure: full ViT-B/32 or ViT-B/16 @384 + mBERT towers, 32 images x
+    160 texts, projection heads fitted on the oracle's [CLS] vectors so that ground-truth pairs score near 1 and the rest near 0
+    (certified below on the ORACLE's scores: every ground-truth item leads its best competitor by >= 0.05).  Then the bf16 path - the
+    benchmarked one - must give the IDENTICAL 13-key itm_eval dict and the identical integer rank of every ground-truth item, as the
+    fp32 path does: bf16's ~1e-2 score noise must not move a single rank once the gaps are those of a model that has learnt something."""
+    from leccr_amd.evaluation import itm_eval
+    from oracle import leccr_oracle as O
+    from tests.helpers import B16_GEOMETRY, B32_GEOMETRY
+    ni, per = 32, 5
+    i2t, t2i, ref, img2txt, txt2img = _full_eval_case(dtype, ni=ni, per=per, geometry=B16_GEOMETRY if tower == 'b16' else B32_GEOMETRY,
+                                                      structured=True)
+    gts_i = [img2txt[i] for i in range(ni)]
+    gts_t = [[txt2img[t]] for t in range(ni * per)]
+    gap = min(min(ref[i, g] - np.max(np.delete(ref[i], gts_i[i])) for g in gts_i[i]) for i in range(ni))
+    gap = min(gap, min(ref.T[t, gts_t[t][0]] - np.max(np.delete(ref.T[t], gts_t[t])) for t in range(ni * per)))
+    assert gap >= 0.05, ('the planted structure is too weak to be a ranking test', gap)
+    err = float(np.max(np.abs(i2t - ref)))
+    assert err < (1e-4 if dtype == 'fp32' else 0.1), err
+    got = itm_eval(i2t, t2i, txt2img, img2txt)
+    want = O.itm_eval(ref, ref.T.copy(), txt2img, img2txt)
+    assert {k: float(v) for k, v in got.items()} == {k: float(v) for k, v in want.items()}, (got, want)
+    assert float(want['txt_r1']) == 100.0 and float(want['img_r1']) == 100.0        # (what the planted structure means)
+    for s_hip, s_ref, gts in ((i2t, ref, gts_i), (t2i, ref.T, gts_t)):
+        assert np.array_equal(_gt_ranks(s_hip, gts), _gt_ranks(s_ref, gts))
+    print(f'structured eval {tower} {dtype}: min ground-truth lead {gap:.3f}, max |score err| {err:.2e}')

@@ -1272,10 +1272,11 @@ def test_split3_writes_hi_lo_segments(K, rows, cols, ld, form):
 
 @pytest.mark.parametrize('M,N,K_', [(577 * 2, 768, 768), (1154, 2304, 768), (4096, 3072, 768), (2048, 768, 3072), (300, 260, 192), (64, 256, 128)])
 @pytest.mark.parametrize('case', ['plain', 'res', 'act', 'gelu', 'dact', 'dx'])
-def test_gemm_f32_operands_run_as_bf16_splits_on_the_matrix_cores(K, M, N, K_, case):
+def test_gemm_f32_operands_run_as_bf16_splits_on_the_matrix_cores(K, M, N, K_, case, monkeypatch):
     """f32 gemm() = ONE bf16 MFMA launch over hi / lo splits (3 K): same tolerance as the scalar f32 kernel (2e-5 of the largest
     magnitude), every epilogue of the path, NT / B-transposed forms; the scalar kernel (set_f32_mfma(False)) agrees."""
     from leccr_amd._lib import lib
+    monkeypatch.setattr(K, '_SPLIT_MIN_WORK', 1)         # (the small shapes here would otherwise stay on the scalar kernel)
     a, b = _rand((M, K_), torch.float32, 21), _rand((N, K_), torch.float32, 22, 0.05)
     bias, res, pre_in = _rand((N,), torch.float32, 23), _rand((M, N), torch.float32, 24), _rand((M, N), torch.float32, 25)
     u = a.double() @ b.double().t()
@@ -1317,10 +1318,11 @@ def test_gemm_f32_operands_run_as_bf16_splits_on_the_matrix_cores(K, M, N, K_, c
 
 
 @pytest.mark.parametrize('Kt,M,N,alpha', [(20000, 768, 768, 1.0), (577 * 16, 2304, 768, 1.0), (64 * 300, 3072, 512, 0.5), (1000, 264, 136, 1.0)])
-def test_gemm_f32_weight_gradient_as_row_interleaved_splits(K, Kt, M, N, alpha):
+def test_gemm_f32_weight_gradient_as_row_interleaved_splits(K, Kt, M, N, alpha, monkeypatch):
     """dW += alpha dY^T X with f32 operands: the [rows, 3 cols] split copies read as [3 rows, cols] (reduction over rows), the bias
     gradient from one pass over the f32 dY (the split copy would count hi twice); pre-split operands give the same bits."""
     from leccr_amd._lib import lib
+    monkeypatch.setattr(K, '_SPLIT_MIN_WORK', 1)
     dy, x = _rand((Kt, M), torch.float32, 31), _rand((Kt, N), torch.float32, 32)
     w0, b0 = _rand((M, N), torch.float32, 33), _rand((M,), torch.float32, 34)
     ref = w0.double() + alpha * (dy.double().t() @ x.double())

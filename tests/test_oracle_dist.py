@@ -1,5 +1,5 @@
-"""Oracle under 2-rank gloo: AllGather slice-only backward + DDP averaging vs the reference's own 2-rank run
-(fixture model_tiny_w2.npz, captured from the reference under DistributedDataParallel)."""
+"""Oracle under 2- and 4-rank gloo: AllGather slice-only backward + DDP averaging vs the reference's own 2- and 4-rank runs
+(fixtures model_tiny_w2.npz / model_tiny_w4.npz, captured from the reference under DistributedDataParallel)."""
 import os
 
 import numpy as np
@@ -17,7 +17,7 @@ def _worker(rank, world, port, ret):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     torch.set_num_threads(2)
     from oracle import leccr_oracle as O
-    z1, z2 = load_npz('model_tiny_w1.npz'), load_npz('model_tiny_w2.npz')
+    z1, z2 = load_npz('model_tiny_w1.npz'), load_npz(f'model_tiny_w{world}.npz')
     sd = weights(z1, requires_grad=True)
     b = 8 // world
     sl = slice(rank * b, (rank + 1) * b)
@@ -47,6 +47,15 @@ def test_oracle_two_ranks_match_reference_ddp():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, 29631, ret), nprocs=2, join=True)
     assert ret[0] == [] and ret[1] == [], (ret[0], ret[1])
+
+
+def test_oracle_four_ranks_match_reference_ddp():
+    """SURVEY.md 8(c) `losses_w4`: the reference itself captured at W = 4 (tests/golden/make_golden.py w4) - the oracle under 4-rank
+    gloo reproduces its per-rank losses and DDP-averaged gradients (1/4 for pre-gather parameters, full for temp / cproj / vproj)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(4, 29635, ret), nprocs=4, join=True)
+    assert all(ret[r] == [] for r in range(4)), [ret[r] for r in range(4)]
 
 
 def test_world_fixtures_are_the_oracle_under_w_rank_gloo():
