@@ -62,6 +62,7 @@ def parse():
     ap.add_argument('--eval-text-batch', type=int, default=32, help='batch_size_test_text (Retrieval_multi30k_de_ft.yaml: 32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
+    ap.add_argument('--parity-rows', type=int, default=16, help='rows of the batch the parity probe runs through the CPU oracle (config E: 4 keeps it to minutes)')
     ap.add_argument('--roofline-steps', type=int, default=3, help='extra single-stream steps after the timed region that time every launch on its own')
     ap.add_argument('--cpu-batch', type=int, default=32, help='cpu_baseline batch (BASELINE config A: 32)')
     ap.add_argument('--cpu-steps', type=int, default=3, help='timed cpu_baseline steps after one warm-up (BASELINE.md section 3: median of 3)')
@@ -628,7 +629,7 @@ def _main(args, real_stdout):
     if not args.no_parity and (world == 1 or (rank == 0 and args.model == 'image')):
         # W > 1: the model's forward gathers across ranks, so rank 0 runs only the collective-free part on its own rows (encoders ->
         # features -> logits against the oracle); the five losses are compared on one rank only
-        parity = parity_probe(args, cfg, model, batch, fwd, with_losses=world == 1)
+        parity = parity_probe(args, cfg, model, batch, fwd, rows=args.parity_rows, with_losses=world == 1)
         if args.model == 'image' and world == 1:
             retrieval = retrieval_probe(args, model, batch)
     if rank == 0:

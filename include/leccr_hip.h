@@ -207,7 +207,10 @@ int leccr_layernorm_bwd_ex(const void* dy, const void* x_in, const float* gamma,
  */
 int leccr_last_attn_kernel(void);              /* which family the last leccr_attn_fwd / _bwd launched: 0 generic (f32, other shapes),
                                                 * 1 MFMA flash kernels (bf16, head 64), 2 thin-K, 3 thin-Q (bf16, <= 8 keys / queries per
-                                                * batch element at d = heads * hd in {512, 768, 1024}: attention_thin.hip); tests use it */
+                                                * batch element at d = heads * hd in {512, 768, 1024}: attention_thin.hip), 4 f32 flash kernels
+                                                * on v_mfma_f32_32x32x2_f32 (f32, head 64, LECCR_ATTN_F32=exact: attention_f32.hip), 5 f32 flash
+                                                * kernels with every operand as a bf16 (hi, lo) pair on v_mfma_f32_32x32x16_bf16 (f32, head 64,
+                                                * default: attention_x3.hip); tests use it */
 int leccr_set_attn_variant(int v);            /* bf16 head-64 MFMA kernels: 32 = 32 rows per wave, v_mfma_f32_32x32x16_bf16 (default),
                                                 * 16 = the 16-row kernels (v_mfma_f32_16x16x32_bf16); 0 = back to the default
                                                 * (environment LECCR_ATTN_FWD); returns the variant in effect.  Tests / benchmarks */

@@ -48,6 +48,12 @@ int attn_f32_fwd(const void* q, const void* k, const void* v, void* o, float* ls
 int attn_f32_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const uint8_t* kmask,
                  void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st);
 
+// .. and the same problems with every operand as a bf16 (hi, lo) pair on v_mfma_f32_32x32x16_bf16 (attention_x3.hip): the default for f32
+bool attn_x3_wanted();
+int attn_x3_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const AttnDims& D, hipStream_t st);
+int attn_x3_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const uint8_t* kmask,
+                void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st);
+
 extern bool g_force_generic_attn;
 int attn_set_variant(int v);      // 0 = default (environment), 16 / 32 = queries per wave of the MFMA forward kernel; returns the one in effect
 

@@ -4,7 +4,7 @@
 
 namespace leccr {
 bool g_force_generic_attn = false;
-static int g_last_attn_kernel = -1;      // 0 generic, 1 MFMA flash (head 64), 2 thin-K, 3 thin-Q, 4 f32 MFMA flash (head 64)
+static int g_last_attn_kernel = -1;      // 0 generic, 1 MFMA flash (head 64), 2 thin-K, 3 thin-Q, 4 f32 MFMA flash (head 64), 5 f32 as bf16 hi / lo pairs (head 64)
 // LECCR_ATTN_THIN=2: the thin kernels also take the head-64 problems with a thin side (default: those stay on the MFMA kernels)
 static bool thin_first() {
     static const bool v = [] { const char* e = getenv("LECCR_ATTN_THIN"); return e && e[0] == '2'; }();
@@ -53,6 +53,10 @@ static int attn_fwd_impl(const void* q, const void* k, const void* v, void* o, f
     {
         const void* ptrs[4] = {q, k, v, o};
         if (!g_force_generic_attn && attn_f32_supported(D, dtype, ptrs, 4)) {      // fp32 (reference precision) on the f32 matrix-core instruction
+            if (attn_x3_wanted()) {                                                // .. as bf16 (hi, lo) operand pairs: 5.3 x fewer matrix-pipe cycles
+                g_last_attn_kernel = 5;
+                return attn_x3_fwd(q, k, v, o, lse, kmask, D, st);
+            }
             g_last_attn_kernel = 4;
             return attn_f32_fwd(q, k, v, o, lse, kmask, D, st);
         }
@@ -125,6 +129,10 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
     {
         const void* ptrs[8] = {q, k, v, o, dout, dq, dk, dv};
         if (!g_force_generic_attn && attn_f32_supported(D, dtype, ptrs, 8)) {
+            if (attn_x3_wanted()) {
+                g_last_attn_kernel = 5;
+                return attn_x3_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
+            }
             g_last_attn_kernel = 4;
             return attn_f32_bwd(q, k, v, o, dout, lse, kmask, dq, dk, dv, delta, D, st);
         }

@@ -16,7 +16,8 @@ def t(f, reps=5):
 SH = [('warm', 256, 12, 576)] + [('vit %d' % L, 256, 12, L) for L in (512, 560, 576, 577, 578, 592, 608, 640)] if os.environ.get('SWEEP') else [('warm', 256, 12, 576), ('vit 577', 256, 12, 577), ('vit 576', 256, 12, 576), ('bert 32', 512, 12, 32), ('bert 64', 256, 12, 64)]
 for name, b, h, L in SH:
     d = h * 64
-    qkv = torch.randn(b, L, 3 * d, device=dev).bfloat16()
+    qkv = torch.randn(b, L, 3 * d, device=dev)
+    if os.environ.get("DT", "bf16") == "bf16": qkv = qkv.bfloat16()
     q, k, v = qkv[..., :d], qkv[..., d:2*d], qkv[..., 2*d:]
     o, lse = K.attn_fwd(q, k, v, h)
     do = torch.randn_like(o)
