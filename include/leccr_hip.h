@@ -131,6 +131,14 @@ typedef struct leccr_gemm_params {
     float* c8_site;
     int32_t c8_fmt;
     int32_t reserved2;
+    void* c3;                    /* optional bf16 (hi, lo) split copy of the C written, [M, 3 N] in the form c3_form of leccr_split3 (0: hi|hi|lo,
+                                    1: hi|lo|hi) - the operand copy the NEXT product of the fp32 path consumes, without leccr_split3's pass over
+                                    C.  bf16 operands, f32 C, trans_a = trans_b = 0, no accumulate.  The 8-wave 256x256 kernel writes it from its
+                                    epilogue registers; every other kernel is followed by a leccr_split3 pass over C here.  With c3, C itself
+                                    may be NULL when the 256x256 kernel takes the shape (M, N >= 256, >= 192 tiles, N % 8 == 0): a consumer
+                                    chain that reads only the copy (the 4d-wide MLP activation and its gradient) */
+    int32_t c3_form;
+    int32_t reserved3;
 } leccr_gemm_params;
 
 int leccr_gemm(const leccr_gemm_params* p, void* stream);

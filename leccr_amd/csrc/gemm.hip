@@ -441,7 +441,14 @@ static int gemm_dispatch(const leccr_gemm_params& p, hipStream_t st, bool* colsu
 extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     LECCR_REQUIRE(pp != nullptr, LECCR_EINVAL, "gemm: null params");
     const leccr_gemm_params& p = *pp;
-    LECCR_REQUIRE(p.A && p.B && (p.C || (p.c8 && (p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A))), LECCR_EINVAL, "gemm: null operand");
+    LECCR_REQUIRE(p.A && p.B && (p.C || (p.c8 && (p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A)) || p.c3), LECCR_EINVAL, "gemm: null operand");
+    if (p.c3) {
+        LECCR_REQUIRE(p.ab_dtype == LECCR_BF16 && p.c_dtype == LECCR_F32 && !p.trans_a && !p.trans_b && !p.accumulate && (p.c3_form == 0 || p.c3_form == 1) &&
+                          (p.N & 3) == 0 && ((uintptr_t)p.c3 & 7) == 0,
+                      LECCR_EINVAL, "gemm: c3 (split copy of C) needs bf16 operands, an f32 C, trans_a = trans_b = 0, no accumulate, N %% 4 == 0");
+        LECCR_REQUIRE(p.C || (!g_force_generic && g_gemm_variant == 0 && gemm256_wanted(p)), LECCR_EINVAL,
+                      "gemm: a null C beside c3 needs a shape the 8-wave 256x256 kernel takes (M, N >= 256, >= 192 tiles, N %% 8 == 0)");
+    }
     LECCR_REQUIRE(p.M >= 0 && p.N >= 0 && p.K >= 0, LECCR_EINVAL, "gemm: negative size");
     // checks every operand format shares (they used to sit below the fp8 branch, which returned before reaching them)
     LECCR_REQUIRE(p.lda >= (p.trans_a ? p.M : p.K) && p.ldb >= (p.trans_b ? p.N : p.K) && p.ldc >= p.N, LECCR_EINVAL,
@@ -485,6 +492,8 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     LECCR_REQUIRE(!(p.asum && !p.trans_a), LECCR_EINVAL, "gemm: asum is defined for trans_a = 1 only");
     bool colsum_fused = false;
     int rc = gemm_dispatch(p, st, &colsum_fused);
+    if (rc == LECCR_OK && p.c3 && g_last_kernel != 2)      // kernels without the split epilogue: leccr_split3 over the C just written
+        rc = leccr_split3((const float*)p.C, p.c3, p.M, p.N, p.ldc, p.c3_form, 0, nullptr, stream);
     if (rc == LECCR_OK && p.colsum && !colsum_fused)     // paths without the fused epilogue: one pass over the C just written
         rc = leccr_colsum(p.C, p.colsum, p.M, p.N, p.ldc, p.c_dtype, stream);
     if (rc == LECCR_OK && p.asum && !(g_last_kernel == 5 || (g_last_kernel == 2 && gemm256_fuses_asum(p)))) {

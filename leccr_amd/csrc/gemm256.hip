@@ -59,6 +59,8 @@ struct Args {
     int n_items;
     unsigned long long* stamps;          // diagnostic builds only (LECCR_G256_STAMPS): per-segment cycle sums
     float* asum;                         // TRANS = 1 with F_ASUM: asum[m] += alpha * sum_k A[k, m] (the bias gradient), or null
+    bf16_t* c3;                          // f32 C only: the (hi, lo) split copy of C, [M, 3 N] in form c3_form (split.hip), or null; C may then be null
+    int c3_form;
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page256[512];
@@ -817,7 +819,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                         }
                         if constexpr ((FLAGS & F_RES) != 0) v += load4(rrow + ni * 16);
                         if constexpr ((FLAGS & F_ACCUM) != 0) v += load4(crow + ni * 16);
-                        store4(crow + ni * 16, v);
+                        if constexpr (TRANS == 0 && sizeof(TC) == 4) {
+                            if (a.c3) {         // the operand copy the fp32 path's next product reads (leccr_split3's layout), from the registers
+                                bf16x4 h4, l4;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    h4[r] = (bf16_t)v[r];
+                                    l4[r] = (bf16_t)(v[r] - (float)h4[r]);
+                                }
+                                bf16_t* d3 = a.c3 + m * 3 * a.N + nb + ni * 16;
+                                *reinterpret_cast<bf16x4*>(d3) = h4;
+                                *reinterpret_cast<bf16x4*>(d3 + a.N) = a.c3_form == 0 ? h4 : l4;
+                                *reinterpret_cast<bf16x4*>(d3 + 2 * a.N) = a.c3_form == 0 ? l4 : h4;
+                            }
+                            if (a.C) store4(crow + ni * 16, v);
+                        } else {
+                            store4(crow + ni * 16, v);
+                        }
                     }
                 }
             }
@@ -948,6 +966,8 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     a.bias = p.bias; a.aux = p.aux; a.ldaux = p.ldaux; a.aux_out = p.aux_out; a.residual = p.residual; a.ldr = p.ldr;
     a.alpha = p.alpha; a.accumulate = p.accumulate;
     a.asum = p.trans_a == 1 ? p.asum : nullptr;
+    a.c3 = (p.trans_a == 0 && p.c_dtype == LECCR_F32) ? (bf16_t*)p.c3 : nullptr;
+    a.c3_form = p.c3_form;
     a.tiles_m = (int)cdiv(p.M, BM); a.tiles_n = (int)cdiv(p.N, BN);
     const int64_t ktiles = cdiv(p.K, BK);
     const int tiles = a.tiles_m * a.tiles_n;

@@ -50,6 +50,12 @@ def split3(x, form, transpose=False, colsum=None):
     return out
 
 
+def gemm256_takes(M, N, Kd):
+    """Shapes of an NT product the 8-wave 256 x 256 kernel takes (gemm256_wanted in gemm256.hip): the ones whose epilogue can write
+    the split copy c3 without a C."""
+    return M >= 256 and N >= 256 and N % 8 == 0 and Kd >= 128 and Kd % 64 == 0 and -(-M // 256) * -(-N // 256) >= 192
+
+
 def split3_colsum_ok(x):
     """Shapes whose split pass can carry the column sums (leccr_split3's colsum)."""
     return x.shape[1] % 8 == 0 and x.shape[1] <= 8192 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -75,11 +81,14 @@ def _split_plan(a, b, trans_a, trans_b, out, accumulate, asum):
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
          out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None, c8=None, write_c=True,
-         a3=None, b3=None):
+         a3=None, b3=None, c3_form=None):
     """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major.
     write_c=False (fp8 operands with c8 only): the bf16 C is not written - only its fp8 copy c8 (and aux_out / colsum); returns None.
     f32 operands: see f32_mfma above.  a3 / b3 = (split copy, form): the caller already holds leccr_split3 copies of a / b (as they
-    are stored; for trans_b alone b3 is the transposed split) - they must be of opposite forms; missing ones are made here."""
+    are stored; for trans_b alone b3 is the transposed split) - they must be of opposite forms; missing ones are made here.
+    c3_form (bf16 operands, f32 C, NT): also return the bf16 (hi, lo) split copy [M, 3 N] of C in that form, written by the kernel's
+    epilogue where it can (else by a leccr_split3 pass inside leccr_gemm): -> (C, C3); write_c=False then leaves C itself unwritten
+    (None) - only for shapes gemm256_takes()."""
     plan = _split_plan(a, b, trans_a, trans_b, out, accumulate, asum) if a.dtype == torch.float32 else None
     if plan is not None:
         global f32_split_launches
@@ -109,7 +118,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     assert K == Kb, (a.shape, b.shape, trans_a, trans_b)
     fp8 = a.dtype in (torch.float8_e4m3fn, torch.float8_e5m2)
     if not write_c:
-        assert fp8 and c8 is not None and out is None and not trans_a
+        assert out is None and not trans_a and ((fp8 and c8 is not None) or (c3_form is not None and gemm256_takes(M, N, K)))
     elif out is None:
         out = torch.empty(M, N, device=a.device, dtype=out_dtype or (torch.bfloat16 if fp8 else a.dtype))
     assert out is None or (out.shape == (M, N) and out.stride(1) == 1)
@@ -120,6 +129,8 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     if fp8:     # fp8 operands (quantize_fp8): b e4m3, a e4m3 (forward) or e5m2 (gradients); alpha_dev = their two inverse scales
         assert b.dtype == torch.float8_e4m3fn and trans_a == trans_b      # NT (forward / dX) or the weight-gradient form dY^T X
         p.ab_dtype, p.c_dtype = (FP8 if a.dtype == torch.float8_e4m3fn else FP8_BF8A), (dtype_code(out) if out is not None else BF16)
+    elif out is None:       # c3 without a C: bf16 operands, the (unwritten) C counts as f32
+        p.ab_dtype, p.c_dtype = dtype_code(a), F32
     else:
         p.ab_dtype, p.c_dtype = dtype_code(a), dtype_code(out)
     if alpha_dev is not None:
@@ -131,7 +142,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
         assert bias.dtype == torch.float32 and bias.numel() == N and bias.is_contiguous()
     p.bias = ptr(bias)
     p.epilogue, p.accumulate = epilogue, int(accumulate)
-    odt = out.dtype if out is not None else torch.bfloat16
+    odt = out.dtype if out is not None else (torch.float32 if c3_form is not None else torch.bfloat16)
     for t in (aux, aux_out, residual):
         if t is not None:
             assert t.dtype == odt and t.shape == (M, N) and t.stride(1) == 1
@@ -151,8 +162,14 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
         t8, site8 = c8
         assert t8.shape == (M, N) and t8.stride(1) == 1 and t8.element_size() == 1
         p.c8, p.ldc8, p.c8_site, p.c8_fmt = ptr(t8), t8.stride(0), ptr(site8.row), site8.fmt
+    c3 = None
+    if c3_form is not None:
+        assert not fp8 and a.dtype == torch.bfloat16 and (out is None or out.dtype == torch.float32)
+        assert not trans_a and not trans_b and not accumulate and c3_form in (FORM_X, FORM_G) and N % 4 == 0
+        c3 = torch.empty(M, 3 * N, device=a.device, dtype=torch.bfloat16)
+        p.c3, p.c3_form = ptr(c3), c3_form
     check(lib().leccr_gemm(C.byref(p), stream()), 'leccr_gemm')
-    return out
+    return (out, c3) if c3_form is not None else out
 
 
 def _q8_out(site, rows, d, device):

@@ -136,6 +136,7 @@ fp8_dw_launches = 0          # fp8 weight-gradient products launched (tests read
 # column sums = the bias gradient riding in the same pass).  Linears outside the blocks go through kernels.gemm's automatic
 # splitting (each product splits its own operands).
 X3 = 'x3'
+fuse_x3_copies = os.environ.get('LECCR_X3_FUSE', '1') != '0'      # the GEMM epilogues write the split copies of the 4d-wide MLP tensors
 
 
 def _x3_lin_ok(rows, w):
@@ -211,7 +212,7 @@ def fp8_only_ok(rows, w, grad):
 fp8_c8_only = os.environ.get('LECCR_FP8_C8_ONLY', '1') != '0'
 
 
-def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_only=False, **kw):
+def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_only=False, c3_consumer=None, **kw):
     """y = x2 @ W^T (+ b) with W in nn.Linear layout [out, in]; x2 [M, in] (row stride free).
     fp8 (compute_dtype 'fp8', the encoder blocks' Linears): x2 is quantised to e4m3 under the Linear's activation site and
     multiplied with the weight's e4m3 copy on the scaled-MFMA kernel; the saved-for-backward tensors stay bf16.
@@ -219,7 +220,14 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
     output: once that site has a scale, the epilogue also writes the output's fp8 copy under it (no separate quantise pass over
     it).  want8: return (y, y8 or None) instead of y.  c8_only (fp8_only_ok): y itself is not written, (None, y8) comes back."""
     if fp8 == X3 and _is_x3(x8):              # f32 operands as bf16 hi / lo splits: x8 = X-form copy of x2, the weight split in G form
-        y = K.gemm(x8, K.split3(w._lp, K.FORM_G), bias=_bias(b), out_dtype=torch.float32, **kw)
+        w3 = K.split3(w._lp, K.FORM_G)
+        if want8 and c3_consumer is not None and fuse_x3_copies and _x3_lin_ok(x8.shape[0], c3_consumer):
+            # the Linear that consumes this output reads only its X-form split copy (forward and weight-gradient product): the GEMM's
+            # epilogue writes that copy from its registers, and where the 256 x 256 kernel takes the shape the f32 output is not
+            # written at all (the 4d-wide activation: 6 instead of 4 + 4 + 6 bytes per element through HBM)
+            only = K.gemm256_takes(x8.shape[0], w3.shape[0], w3.shape[1])
+            return K.gemm(x8, w3, bias=_bias(b), out_dtype=torch.float32, c3_form=K.FORM_X, write_c=not only, **kw)
+        y = K.gemm(x8, w3, bias=_bias(b), out_dtype=torch.float32, **kw)
         return (y, None) if want8 else y
     if fp8 and fp8 != X3 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8):
         if x8 is None:
@@ -234,11 +242,24 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
     return (y, None) if want8 else y
 
 
-def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False, **kw):
+def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False, c3_consumer=None, c3_bias=None, **kw):
     """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N].
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
     if fp8 == X3 and _is_x3(g8):              # G-form copy of dY against the X-form split of W^T ([in, 3 out], K-contiguous)
-        y = K.gemm(g8, K.split3(w._lp, K.FORM_X, transpose=True), out_dtype=torch.float32, **kw)
+        w3t = K.split3(w._lp, K.FORM_X, transpose=True)
+        if want8 and c3_consumer is not None and fuse_x3_copies and _x3_lin_ok(g8.shape[0], c3_consumer) \
+                and K.gemm256_takes(g8.shape[0], w3t.shape[0], w3t.shape[1]):
+            # the gradient this product writes is read only through its G-form copy (dX and weight-gradient product of the consumer):
+            # written by the epilogue, no f32 tensor; the consumer's bias gradient = column sums of the copy's hi and lo segments
+            _, y3 = K.gemm(g8, w3t, out_dtype=torch.float32, c3_form=K.FORM_G, write_c=False, **kw)
+            if c3_bias is not None:
+                n = w3t.shape[0]
+                K.colsum(y3[:, :n], c3_bias._g.reshape(-1))
+                K.colsum(y3[:, n:2 * n], c3_bias._g.reshape(-1))
+                _mark(c3_bias)
+                y3._bias_done = True
+            return None, y3
+        y = K.gemm(g8, w3t, out_dtype=torch.float32, **kw)
         return (y, None) if want8 else y
     if fp8 and fp8 != X3 and getattr(w, '_q8t', None) is not None and _fp8_ok(dy2, w._q8t):
         if g8 is None:
@@ -619,10 +640,10 @@ class ViTBlockFn(torch.autograd.Function):
         # (.. and when c_proj's forward and weight-gradient products both read that copy, the bf16 activation is not written at all)
         act_8only = blk.fp8 and h2_8 is not None and fp8_only_ok(M, blk.mlp.c_proj.weight, False)
         act, act8 = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, x8=h2_8, epilogue=EPI_QUICKGELU, aux_out=pre,
-                            c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True, c8_only=act_8only)
+                            c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True, c8_only=act_8only, c3_consumer=blk.mlp.c_proj.weight)
         if act is None:
             act = pre[:0]                                   # (the tail rows dw_keep would keep: none)
-            x2 = lin_fwd(act8, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=True, x8=act8, residual=_rows(x1)).view(b, N, d)
+            x2 = lin_fwd(act8, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
         else:
             act8 = x8_of(blk.fp8, act, blk.mlp.c_proj.weight, act8)
             x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
@@ -650,6 +671,7 @@ class ViTBlockFn(torch.autograd.Function):
         dpre_8only = blk.fp8 and g2_8 is not None and h2_8 is not None and fp8_only_ok(g2.shape[0], blk.mlp.c_fc.weight, True)
         dpre, dpre8 = lin_dx(g2, blk.mlp.c_proj.weight, fp8=blk.fp8, g8=g2_8, epilogue=EPI_DQUICKGELU, aux=pre,
                              c8_site=_site(blk.mlp.c_fc.weight, '_gsite'), want8=True, c8_only=dpre_8only,
+                             c3_consumer=blk.mlp.c_fc.weight, c3_bias=blk.mlp.c_fc.bias,
                              **(dict(colsum=blk.mlp.c_fc.bias._g.reshape(-1)) if dpre_8only else {}))
         # bias gradients of c_proj / out_proj = column sums of dx2 / dx1.  They ride the weight-gradient stream as 40 us HBM-bound
         # passes beside the dX chain: folded into the LayerNorm backward launches (whose `dres` operands those tensors are) they
@@ -783,7 +805,7 @@ class BertLayerFn(torch.autograd.Function):
         out = layer.output
         h_8only = layer.fp8 and x1_8 is not None and fp8_only_ok(b * L, out.dense.weight, False)       # as the ViT block's activation
         h, h8 = lin_fwd(_rows(x1), layer.intermediate.dense.weight, layer.intermediate.dense.bias, fp8=layer.fp8, x8=x1_8, epilogue=EPI_GELU,
-                        aux_out=pre, c8_site=_site(out.dense.weight, '_xsite'), want8=True, c8_only=h_8only)
+                        aux_out=pre, c8_site=_site(out.dense.weight, '_xsite'), want8=True, c8_only=h_8only, c3_consumer=out.dense.weight)
         if h is None:
             h = h8                                          # the products below take the fp8 copy; no bf16 rows are kept
         else:
@@ -820,7 +842,7 @@ class BertLayerFn(torch.autograd.Function):
         inter = layer.intermediate.dense
         dpre_8only = layer.fp8 and gd2_8 is not None and x1_8 is not None and fp8_only_ok(gd2.shape[0], inter.weight, True)
         dpre, dpre8 = lin_dx(gd2, out.dense.weight, fp8=layer.fp8, g8=gd2_8, epilogue=EPI_DGELU, aux=pre,
-                             c8_site=_site(inter.weight, '_gsite'), want8=True, c8_only=dpre_8only,
+                             c8_site=_site(inter.weight, '_gsite'), want8=True, c8_only=dpre_8only, c3_consumer=inter.weight, c3_bias=inter.bias,
                              **(dict(colsum=inter.bias._g.reshape(-1)) if dpre_8only else {}))
         lin_dw(gd2, h, out.dense.weight, out.dense.bias, g8=gd2_8, x8=h8)
         if dpre is not None:

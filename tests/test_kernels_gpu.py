@@ -1377,3 +1377,64 @@ def test_attention_f32_runs_on_the_f32_matrix_cores_and_matches_the_scalar_kerne
         assert torch.equal(torch.isfinite(x), fin), name
         e, s = float((x[fin] - y[fin]).abs().max()), float(y[fin].abs().max()) + 1e-12
         assert e <= 5e-5 * s, (name, e, s)             # operands as (hi, lo) pairs: 2^-17 per product term (measured worst: 2.3e-5, 4 queries)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('b,heads,Lq,Lk,hd,masked,drop', [(4, 8, 8, 8, 512, False, 0.0), (3, 8, 20, 20, 512, True, 0.1), (3, 8, 2, 64, 512, True, 0.1),
+                                                          (3, 8, 8, 2, 512, False, 0.1), (2, 8, 4, 8, 512, True, 0.0), (2, 4, 33, 64, 128, True, 0.2),
+                                                          (2, 2, 64, 7, 1024, False, 0.0)])
+def test_attention_few_rows_wide_heads(K, dtype, b, heads, Lq, Lk, hd, masked, drop):
+    """The reference's shipped video geometry (Retrieval_msrvtt.yaml:36-37: nn.MultiheadAttention(4096, 8) = 8 heads of 512 over 8-20 frames,
+    2-4 caption queries, 64 caption tokens; models/attention.py:90,107): the head-dimension-on-the-lanes kernels (attention_generic.hip,
+    attn_wide_*) against an f64 reference that applies the same key mask and the same dropout mask - forward, lse, all three gradients."""
+    d = heads * hd
+    q, kv, do = _rand((b, Lq, d), dtype, 300, 0.3), _rand((b, Lk, 2 * d), dtype, 301, 0.3), _rand((b, Lq, d), dtype, 302)
+    k, v = kv[..., :d], kv[..., d:]
+    kmask = None
+    if masked:
+        lens = torch.randint(1, Lk + 1, (b,), generator=torch.Generator().manual_seed(303))
+        lens[0] = Lk
+        kmask = (torch.arange(Lk)[None, :] >= lens[:, None]).to(torch.uint8)
+    qd, kvd = q.to(DEV), kv.to(DEV)
+    km_d = kmask.to(DEV) if masked else None
+    o, lse = K.attn_fwd(qd, kvd[..., :d], kvd[..., d:], heads, km_d, drop, 91)
+    mask = K.dropout(torch.ones(b * heads * Lq * Lk, device=DEV), drop, 91).view(b, heads, Lq, Lk).cpu().double() if drop > 0 else 1.0
+    qr, kr, vr = (t.double().requires_grad_(True) for t in (q, k, v))
+    qh = qr.reshape(b, Lq, heads, hd).permute(0, 2, 1, 3)
+    kh = kr.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    vh = vr.reshape(b, Lk, heads, hd).permute(0, 2, 1, 3)
+    sc = qh @ kh.transpose(-1, -2) / math.sqrt(hd)
+    if masked:
+        sc = sc.masked_fill(kmask.bool()[:, None, None, :], float('-inf'))
+    ref = ((torch.softmax(sc, -1) * mask) @ vh).permute(0, 2, 1, 3).reshape(b, Lq, d)
+    e, s = _err(o, ref)
+    assert e <= _tol(dtype) * s, ('o', e, s)
+    e, s = _err(lse, torch.logsumexp(sc, -1))
+    assert e <= 1e-4 * s + 1e-4, ('lse', e, s)
+    (ref * do.double()).sum().backward()
+    dq, dk, dv = K.attn_bwd(qd, kvd[..., :d], kvd[..., d:], o, do.to(DEV), lse, heads, km_d, drop_p=drop, seed=91)
+    for name, got, r in (('dq', dq, qr.grad), ('dk', dk, kr.grad), ('dv', dv, vr.grad)):
+        e, s = _err(got, r)
+        assert e <= (1e-4 if dtype == torch.float32 else 3e-2) * s, (name, e, s)
+
+
+@pytest.mark.parametrize('M,N,K_,fused', [(147712 // 8, 3072, 768, True), (16384, 3072, 768, True), (300, 260, 192, False), (1154, 768, 768, False)])
+@pytest.mark.parametrize('case', ['act', 'dact'])
+def test_gemm_writes_the_split_copy_of_its_output(K, M, N, K_, fused, case):
+    """leccr_gemm_params.c3: the bf16 (hi, lo) copy of the f32 C for the next product of the fp32 path, from the 256 x 256 kernel's epilogue
+    registers (or a leccr_split3 pass for other kernels) - bit-identical to leccr_split3 of the C the same call writes; and with C
+    omitted (write_c=False, shapes the 256 x 256 kernel takes) the copy alone is the same bytes."""
+    from leccr_amd._lib import lib
+    a, b = _rand((M, K_), torch.float32, 41), _rand((N, K_), torch.float32, 42, 0.05)
+    bias, pre_in = _rand((N,), torch.float32, 43), _rand((M, N), torch.float32, 44)
+    a3, b3 = K.split3(a.to(DEV), K.FORM_X), K.split3(b.to(DEV), K.FORM_G)
+    form = K.FORM_X if case == 'act' else K.FORM_G
+    kw = dict(bias=bias.to(DEV), epilogue=1, aux_out=torch.empty(M, N, device=DEV)) if case == 'act' else dict(epilogue=3, aux=pre_in.to(DEV))
+    c, c3 = K.gemm(a3, b3, out_dtype=torch.float32, c3_form=form, **kw)
+    assert (lib().leccr_last_gemm_kernel() == 2) == fused and K.gemm256_takes(M, N, 3 * K_) == fused
+    assert torch.equal(c3.view(torch.int16), K.split3(c, form).view(torch.int16))
+    plain = K.gemm(a3, b3, out_dtype=torch.float32, **(dict(kw, aux_out=torch.empty(M, N, device=DEV)) if case == 'act' else kw))
+    assert torch.equal(plain, c)
+    if fused:
+        none, c3b = K.gemm(a3, b3, out_dtype=torch.float32, c3_form=form, write_c=False, **kw)
+        assert none is None and torch.equal(c3b.view(torch.int16), c3.view(torch.int16))
