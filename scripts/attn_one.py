@@ -5,7 +5,8 @@ import torch
 from leccr_amd import kernels as K
 reps = int(sys.argv[1]); L = int(sys.argv[2]) if len(sys.argv) > 2 else 577
 b, h, d = 256, 12, 768
-qkv = torch.randn(b, L, 3 * d, device='cuda').bfloat16()
+qkv = torch.randn(b, L, 3 * d, device='cuda')
+if os.environ.get('DT', 'bf16') == 'bf16': qkv = qkv.bfloat16()
 q, k, v = qkv[..., :d], qkv[..., d:2*d], qkv[..., 2*d:]
 o, lse = K.attn_fwd(q, k, v, h)
 do = torch.randn_like(o)
