@@ -820,21 +820,57 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                         if constexpr ((FLAGS & F_RES) != 0) v += load4(rrow + ni * 16);
                         if constexpr ((FLAGS & F_ACCUM) != 0) v += load4(crow + ni * 16);
                         if constexpr (TRANS == 0 && sizeof(TC) == 4) {
-                            if (a.c3) {         // the operand copy the fp32 path's next product reads (leccr_split3's layout), from the registers
-                                bf16x4 h4, l4;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    h4[r] = (bf16_t)v[r];
-                                    l4[r] = (bf16_t)(v[r] - (float)h4[r]);
-                                }
-                                bf16_t* d3 = a.c3 + m * 3 * a.N + nb + ni * 16;
-                                *reinterpret_cast<bf16x4*>(d3) = h4;
-                                *reinterpret_cast<bf16x4*>(d3 + a.N) = a.c3_form == 0 ? h4 : l4;
-                                *reinterpret_cast<bf16x4*>(d3 + 2 * a.N) = a.c3_form == 0 ? l4 : h4;
-                            }
+                            if (a.c3) acc[ni][mi] = v;          // kept for the split copy below
                             if (a.C) store4(crow + ni * 16, v);
                         } else {
                             store4(crow + ni * 16, v);
+                        }
+                    }
+                }
+            }
+            if constexpr (TRANS == 0 && sizeof(TC) == 4) {
+                // c3: the (hi, lo) operand copy the fp32 path's next product reads (leccr_split3's [M, 3 N] layout), from the epilogue values
+                // now in the accumulators.  Straight from the accumulator layout a lane would write three 8-byte pieces of one row (16 rows x
+                // 32 bytes per wave store: measured +7 % on the launch); through the wave-private LDS strip of the bf16 epilogue a lane owns 8
+                // consecutive columns of two rows: 16-byte stores, 8 lanes = one 128-byte run per segment.
+                if (a.c3) {
+                    float* stg = reinterpret_cast<float*>(smem + 2 * SLOT) + wave * (16 * 64);
+                    int lane_e = lane;
+                    asm volatile("" : "+v"(lane_e));
+                    const int rrow = lane_e >> 3, rc = (lane_e & 7) * 2;
+                    const int64_t ncol = n0 + wc * 64 + (lane_e & 7) * 8;
+                    const bool col_ok = interior || ncol < a.N;
+                    const int wrow = lane_e & 15, wq = lane_e >> 4;
+                    float* wbase = stg + wrow * 64;
+                    const float* rb0 = stg + rrow * 64;
+                    const float* rb1 = stg + (rrow + 8) * 64;
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) *reinterpret_cast<f32x4*>(wbase + (((ni * 4 + wq) ^ wrow) << 2)) = acc[ni][mi];
+                        WAVE_LDS_FENCE();
+                        f32x4 vv[4];
+                        vv[0] = *reinterpret_cast<const f32x4*>(rb0 + ((rc ^ rrow) << 2));
+                        vv[1] = *reinterpret_cast<const f32x4*>(rb0 + (((rc + 1) ^ rrow) << 2));
+                        vv[2] = *reinterpret_cast<const f32x4*>(rb1 + ((rc ^ (rrow + 8)) << 2));
+                        vv[3] = *reinterpret_cast<const f32x4*>(rb1 + (((rc + 1) ^ (rrow + 8)) << 2));
+                        WAVE_LDS_FENCE();
+#pragma unroll
+                        for (int hp = 0; hp < 2; ++hp) {
+                            const int64_t m = m0 + wr * 128 + mi * 16 + hp * 8 + rrow;
+                            if (!(interior || (col_ok && m < a.M))) continue;
+                            bf16x8 h8, l8;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                h8[r] = (bf16_t)vv[2 * hp][r];
+                                l8[r] = (bf16_t)(vv[2 * hp][r] - (float)h8[r]);
+                                h8[4 + r] = (bf16_t)vv[2 * hp + 1][r];
+                                l8[4 + r] = (bf16_t)(vv[2 * hp + 1][r] - (float)h8[4 + r]);
+                            }
+                            bf16_t* d3 = a.c3 + m * 3 * a.N + ncol;
+                            *reinterpret_cast<bf16x8*>(d3) = h8;
+                            *reinterpret_cast<bf16x8*>(d3 + a.N) = a.c3_form == 0 ? h8 : l8;
+                            *reinterpret_cast<bf16x8*>(d3 + 2 * a.N) = a.c3_form == 0 ? l8 : h8;
                         }
                     }
                 }

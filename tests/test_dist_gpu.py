@@ -127,8 +127,10 @@ def test_two_rank_training_with_the_optimizer_fused_into_backward():
     (f0, n0), (f1, _), (p0, _), (p1, _) = ret[(True, 0)], ret[(True, 1)], ret[(False, 0)], ret[(False, 1)]
     assert n0 == 2
     assert np.array_equal(f0, f1) and np.array_equal(p0, p1)               # ranks stay in lock step (same summed gradients)
-    # fused = plain: the gradient atomics' order differs, and Adam's m / sqrt(v) amplifies that on near-zero gradients
-    assert np.max(np.abs(f0 - p0)) <= 1e-5 * np.max(np.abs(p0))
+    # fused = plain: the gradient atomics' order differs, and Adam's m / sqrt(v) amplifies that on near-zero gradients (lr 1e-3: an element
+    # whose gradient is rounding noise moves by up to 2e-3 over two steps).  Round 4's fp32 path sums more tensors with atomics (the bias
+    # gradients ride in the split passes): measured 0 - 1.5e-5 from run to run where it was <= 1e-5 - a schedule race would show 1e-3 and up
+    assert np.max(np.abs(f0 - p0)) <= 5e-5 * np.max(np.abs(p0))
 
 
 def _eval_worker(rank, world, port, ret):
