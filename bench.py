@@ -60,6 +60,8 @@ def parse():
     ap.add_argument('--eval-texts', type=int, default=1000, help='Multi30K test (one language): 1000 texts; MSCOCO-1k: 5000')
     ap.add_argument('--eval-batch', type=int, default=6, help='batch_size_test (Retrieval_multi30k_de_ft.yaml: 6)')
     ap.add_argument('--eval-text-batch', type=int, default=32, help='batch_size_test_text (Retrieval_multi30k_de_ft.yaml: 32)')
+    ap.add_argument('--eval-no-regroup', action='store_true', help='run every loader batch through the towers as it is yielded (the reference '
+                    'loop); default: evaluation_coarse regroups them to 64 images / 256 texts per forward - same scores')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--parity-rows', type=int, default=16, help='rows of the batch the parity probe runs through the CPU oracle (config E: 4 keeps it to minutes)')
@@ -405,6 +407,8 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
     bs = args.eval_batch
     loader = Loader([(image[i:i + bs], [f'c{j}' for j in range(i, min(ni, i + bs))], None) for i in range(0, ni, bs)])
     ecfg = {'batch_size_test_text': args.eval_text_batch, 'max_tokens': 200}
+    if args.eval_no_regroup:
+        ecfg.update(eval_group_images=0, eval_group_texts=0)
     per = max(1, nt // ni)
     img2txt = {i: [t for t in range(i * per, min(nt, (i + 1) * per))] or [i % nt] for i in range(ni)}
     txt2img = {t: min(ni - 1, t // per) for t in range(nt)}
@@ -469,7 +473,9 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
                'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None,
                'dtype': args.dtype, 'data': 'synthetic',
                'config': {'workload': f'evaluation_coarse + itm_eval, {ni} images x {nt} texts (Multi30K-test shaped), {args.clip}@384 + {args.text}, '
-                                      f'{args.dtype}, batch_size_test {bs}, batch_size_test_text {args.eval_text_batch}, L_t=32, L_c=64, eval mode'
+                                      f'{args.dtype}, batch_size_test {bs}, batch_size_test_text {args.eval_text_batch}'
+                                      + (' (run as yielded)' if args.eval_no_regroup else ' (regrouped to >= 64 images / 256 texts per forward inside evaluation_coarse)')
+                                      + ', L_t=32, L_c=64, eval mode'
                                       + (f', encoders sharded over {world} ranks' if world > 1 else ''),
                           'parallelism': f'dp{world}', 'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
                'roofline': {'bound': 'mfma', 'kernel': 'forward GEMMs of one evaluation pass (gemm256 / 128-tile family)', 'achieved': round(achieved, 1),

@@ -95,7 +95,12 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
     start_time = time.time()
     texts = data_loader.dataset.text
     num_text = len(texts)
-    text_bs = config['batch_size_test_text']
+    # The reference encodes batch_size_test_text (32) texts and batch_size_test (6) images per forward (its YAMLs): 3462 token rows per ViT
+    # GEMM, a launch-bound pass on this chip.  Nothing in eval mode depends on how the rows are batched, so several loader batches are run
+    # through the towers together (config['eval_group_images'] / ['eval_group_texts'], default 64 / 256 rows per forward; 0 = as the loader
+    # yields them): same scores, same ranks, 3-4 x the images per second.
+    gi, gt = int(config.get('eval_group_images', 64)), int(config.get('eval_group_texts', 256))
+    text_bs = max(config['batch_size_test_text'], gt)
     text_embeds, text_rows = [], []
     for c, i in enumerate(range(0, num_text, text_bs)):
         if c % world != rank:
@@ -106,11 +111,8 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
         text_embeds.append(model.get_features(text_embeds=model.get_text_embeds(ti.input_ids, ti.attention_mask)))
         text_rows.append(torch.arange(i, i + len(text), device=device))
     image_embeds, image_rows = [], []
-    n_img = 0
-    for c, (image, generated_captions, img_id) in enumerate(data_loader):
-        first, n_img = n_img, n_img + image.shape[0]
-        if c % world != rank:
-            continue
+
+    def encode_images(image, generated_captions, first):
         image = image.to(device)
         image_feat, _ = model.get_vision_embeds(image)
         if config.get('caption_encoder_name', 'mbert') == 'clip':       # image_Retrieval_caption.py:128-136: CLIP token ids, padding id 0
@@ -129,7 +131,24 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
         image_feat, _, _ = model.interaction_with_caption(image_embeds=image_feat, caption_embeds=caption_embed,
                                                           key_padding_mask=key_padding_mask)
         image_embeds.append(model.get_features(image_embeds=image_feat.transpose(0, 1).contiguous()))
-        image_rows.append(torch.arange(first, n_img, device=device))
+        image_rows.append(torch.arange(first, first + image.shape[0], device=device))
+
+    n_img, group, pend_i, pend_c, pend_first = 0, 0, [], [], 0
+    for image, generated_captions, img_id in data_loader:
+        if not pend_i:
+            pend_first = n_img
+        n_img += image.shape[0]
+        pend_i.append(image)
+        pend_c.append(generated_captions)
+        if sum(t.shape[0] for t in pend_i) >= max(gi, 1):
+            if group % world == rank:
+                caps = torch.cat(pend_c) if torch.is_tensor(pend_c[0]) else [c for cs in pend_c for c in cs]
+                encode_images(torch.cat([t.to(device) for t in pend_i]) if len(pend_i) > 1 else pend_i[0], caps, pend_first)
+            group, pend_i, pend_c = group + 1, [], []
+    if pend_i:
+        if group % world == rank:
+            caps = torch.cat(pend_c) if torch.is_tensor(pend_c[0]) else [c for cs in pend_c for c in cs]
+            encode_images(torch.cat([t.to(device) for t in pend_i]) if len(pend_i) > 1 else pend_i[0], caps, pend_first)
 
     def assemble(chunks, rows, total):
         D = model.embed_dim

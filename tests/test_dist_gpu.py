@@ -157,7 +157,8 @@ def _eval_worker(rank, world, port, ret):
         dataset = types.SimpleNamespace(text=[f't{i}' for i in range(8)])
     # 3 image batches (3 + 3 + 2) and 3 text chunks (3 + 3 + 2): ragged shares per rank
     loader = Loader([(image[a:b], [f'c{j}' for j in range(a, b)], None) for a, b in ((0, 3), (3, 6), (6, 8))])
-    cfg = {'batch_size_test_text': 3, 'max_tokens': 200}
+    # (groups of 3 images / 3 texts per forward, so that both ranks get ragged shares; the default regroups to 64 / 256)
+    cfg = {'batch_size_test_text': 3, 'max_tokens': 200, 'eval_group_images': 3, 'eval_group_texts': 3}
     i2t, t2i = evaluation_coarse(model, loader, Tok(), 'cuda', cfg)                 # sharded over the 2 ranks
     full, _ = evaluation_coarse(model, loader, Tok(), 'cuda', cfg, shard=False)     # every rank encodes everything
     ret[rank] = (i2t.shape, float(np.max(np.abs(i2t - full))), bool(np.array_equal(t2i, i2t.T)))

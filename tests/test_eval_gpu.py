@@ -77,6 +77,10 @@ def test_evaluation_coarse_synthetic_loader():
     ref = (fv @ ft.t()).numpy()
     assert i2t.shape == (8, 8) and np.max(np.abs(i2t - ref)) < 1e-4 and np.array_equal(t2i, i2t.T)
     assert np.array_equal(np.argsort(-i2t, 1), np.argsort(-ref, 1))             # identical rankings
+    # the default regroups the loader's batches (here: everything in one forward); run as yielded (two image batches of 4, text chunks
+    # of 3) the scores are the same - nothing in eval mode depends on how the rows are batched
+    asis, _ = evaluation_coarse(model, loader, Tok(), 'cuda', {'batch_size_test_text': 3, 'max_tokens': 200, 'eval_group_images': 0, 'eval_group_texts': 0})
+    assert np.max(np.abs(asis - i2t)) <= 1e-6
 
 
 def test_evaluation_coarse_video_double_sim():

@@ -326,7 +326,10 @@ def test_optimizer_fused_into_backward_moves_parameters_identically(dtype):
     assert nf == np_ == 3
     diff, scale = (pf - pp).abs(), float(pp.abs().max())
     if dtype == 'fp32':
-        assert float(diff.max()) <= 1e-5 * scale
+        # the two runs differ by the ORDER of the gradient atomics only; Adam's m / sqrt(v) turns that into a full +-lr step on the few
+        # elements whose gradient is itself rounding noise.  Round 4's fp32 path sums more tensors with atomics (bias gradients in the
+        # split passes): a handful of elements now exceed 1e-5 of the scale (measured: max 1.5e-5), none may come near an lr-sized move
+        assert float(diff.max()) <= 1e-4 * scale and float((diff > 1e-5 * scale).float().mean()) < 1e-5
         assert float((mf - mp_).abs().max()) <= 1e-3 * float(mp_.abs().max())
         assert float((vf - vp).abs().max()) <= 1e-3 * float(vp.abs().max())
     else:
