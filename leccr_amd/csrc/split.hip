@@ -97,25 +97,55 @@ __global__ __launch_bounds__(256) void split3_scalar_kernel(const float* __restr
     d[2 * cols] = form == 0 ? l : h;
 }
 
-// dst[c][s * rows + r] = part_s(src[r][c]): 32 x 32 tiles through LDS (weights: small, once per product)
+// dst[c][s * rows + r] = part_s(src[r][c]) (weights: [out, in] -> the K-contiguous [in, 3 out] copy of the dX product, once per product).
+// 64 x 64 tiles through LDS: 16-byte row reads of the source, and 16-byte stores of the copy - thread (c, g) owns 16 consecutive r of one
+// destination row c (two bf16x8 per segment).  (The first version moved 2-byte pieces from 32 x 32 tiles: 34 us per weight, 4.6 ms of the
+// fp32 step for 135 launches.)  Tails in either direction take the scalar path of the same tile loop.
 __global__ __launch_bounds__(256) void split3_t_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows,
                                                        int64_t cols, int64_t ld, int form) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int64_t r0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const bool full = r0 + 64 <= rows && c0 + 64 <= cols && (ld & 3) == 0 && (rows & 7) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    if (full) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t r = r0 + ty + 8 * i, c = c0 + tx;
-        tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[r * ld + c] : 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 4) + 16 * i, c4 = (tid & 15) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (r0 + r) * ld + c0 + c4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r][c4 + e] = v[e];
+        }
+    } else {
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            tile[r][c] = (r0 + r < rows && c0 + c < cols) ? src[(r0 + r) * ld + c0 + c] : 0.f;
+        }
     }
     __syncthreads();
+    const int c = tid & 63, g = tid >> 6;              // destination row c0 + c, source rows r0 + 16 g .. + 15
+    if (full) {
+        bf16_t* d = dst + (c0 + c) * 3 * rows + r0 + 16 * g;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t c = c0 + ty + 8 * i, r = r0 + tx;
-        if (c < cols && r < rows) {
+        for (int k = 0; k < 2; ++k) {
+            bf16x8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16_t hh, ll;
+                split2(tile[16 * g + 8 * k + j][c], hh, ll);
+                h[j] = hh; l[j] = ll;
+            }
+            *reinterpret_cast<bf16x8*>(d + 8 * k) = h;
+            *reinterpret_cast<bf16x8*>(d + rows + 8 * k) = form == 0 ? h : l;
+            *reinterpret_cast<bf16x8*>(d + 2 * rows + 8 * k) = form == 0 ? l : h;
+        }
+    } else if (c0 + c < cols) {
+        for (int j = 0; j < 16; ++j) {
+            const int64_t r = r0 + 16 * g + j;
+            if (r >= rows) break;
             bf16_t h, l;
-            split2(tile[tx][ty + 8 * i], h, l);
-            bf16_t* d = dst + c * 3 * rows + r;
+            split2(tile[16 * g + j][c], h, l);
+            bf16_t* d = dst + (c0 + c) * 3 * rows + r;
             d[0] = h;
             d[rows] = form == 0 ? h : l;
             d[2 * rows] = form == 0 ? l : h;
@@ -150,7 +180,7 @@ extern "C" int leccr_split3(const float* src, void* dst, int64_t rows, int64_t c
         return check_launch("split3");
     }
     if (transpose) {
-        hipLaunchKernelGGL(split3_t_kernel, dim3((unsigned)cdiv(cols, 32), (unsigned)cdiv(rows, 32)), dim3(256), 0, st, src, d, rows, cols, ld, form);
+        hipLaunchKernelGGL(split3_t_kernel, dim3((unsigned)cdiv(cols, 64), (unsigned)cdiv(rows, 64)), dim3(256), 0, st, src, d, rows, cols, ld, form);
     } else if (vec) {
         hipLaunchKernelGGL(split3_kernel, dim3((unsigned)cdiv(rows * (cols >> 3), 256)), dim3(256), 0, st, src, d, rows, cols, ld, form);
     } else {
