@@ -188,8 +188,8 @@ def dw_keep(x2, x8, w):
     go to the bf16 kernel (an empty tensor when there are none).  The bf16 h1 / h2 / activation tensors of a block are needed for
     nothing else, so fp8 mode holds 1 byte per element of them instead of 2 (+1).
     Mode X3 (x8 = the bf16 split copy): the weight-gradient product reads only that copy - the f32 tensor is not kept."""
-    if _is_x3(x8):
-        return x2[:0] if (x2.dtype == torch.float32 and _x3_lin_ok(x8.shape[0], w)) else x2
+    if _is_x3(x8):          # (an empty tensor of its own: a zero-row VIEW of x2 would keep x2's storage alive)
+        return x2.new_empty((0, x2.shape[1])) if (x2.dtype == torch.float32 and _x3_lin_ok(x8.shape[0], w)) else x2
     if (fp8_dw and x8 is not None and x2.shape[0] >= 2048 and x2.shape[1] % 256 == 0 and w._q8.shape[0] % 256 == 0
             and x8.stride(0) % 16 == 0 and x8.data_ptr() % 16 == 0):
         return x2[x2.shape[0] // 128 * 128:].clone()
