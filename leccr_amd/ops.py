@@ -279,6 +279,7 @@ def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False,
 # partial round of tiles (6-7 % of a 1731-tile launch) - the other stream's workgroups fill those CUs.  Measured on the batch-256
 # step: 155.0 -> 150.8 ms.  LECCR_DW_STREAM=0 keeps everything on one stream.
 wgrad_overlap = os.environ.get('LECCR_DW_STREAM', '1') != '0'
+wgrad_overlap_f32 = os.environ.get('LECCR_DW_STREAM_F32', '0') != '0'      # .. for the fp32 path (see lin_dw)
 fuse_bias_grad = os.environ.get('LECCR_FUSE_BIAS_GRAD', '1') != '0'      # bias gradients inside the dW GEMM (0: separate colsum launches)
 # The text towers (caption BERT forward, text BERT forward + backward: small-M GEMMs that leave CUs idle) run on a third stream
 # beside the image tower (150.8 -> 148.7 ms on the batch-256 step).  LECCR_TEXT_STREAM=0 keeps them on the main stream.
@@ -367,7 +368,11 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_d
     elif dy2 is None:
         assert g8.shape[0] % 128 == 0 and (b is None or bias_done)
     ref = dy2 if dy2 is not None else g8
-    if not (wgrad_overlap and ref.is_cuda):
+    # fp32 path: the weight-gradient products stay on the main stream.  Their launches are long (reduction over 3 x rows) persistent
+    # kernels that hold every CU, and the fp32 step's main chain is full of short HBM-bound launches (split passes, LayerNorm) that then
+    # queue behind them: same-box A/B 397.0 ms with the side stream, 374.8 without (LECCR_DW_STREAM_F32=1 turns it back on)
+    f32_path = _is_x3(g8) or (dy2 is not None and dy2.dtype == torch.float32)
+    if not (wgrad_overlap and ref.is_cuda) or (f32_path and not wgrad_overlap_f32):
         return _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8, bias_done)
     main = torch.cuda.current_stream()
     if _wgrad_stream is None:

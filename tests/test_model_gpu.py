@@ -241,6 +241,7 @@ def test_side_streams_give_the_same_gradients():
 
     def grads(overlap):
         prev, ops.wgrad_overlap, ops.text_overlap = (ops.wgrad_overlap, ops.text_overlap), overlap, overlap
+        prev32, ops.wgrad_overlap_f32 = ops.wgrad_overlap_f32, overlap      # (the fp32 path keeps its weight-gradient launches on the main stream by default)
         try:
             model.arena.zero_grad()
             losses = model(batch['image'].to(DEV), [Enc(batch['ids_s'].to(DEV), batch['mask_s'].to(DEV)),
@@ -250,6 +251,7 @@ def test_side_streams_give_the_same_gradients():
             return model.arena.grad.clone()            # main-stream copy right behind backward()
         finally:
             ops.wgrad_overlap, ops.text_overlap = prev
+            ops.wgrad_overlap_f32 = prev32
     g_side, g_one = grads(True), grads(False)
     assert ops._wgrad_stream is not None and ops._text_stream is not None          # the side streams were really used
     err = float((g_side - g_one).abs().max())
