@@ -446,7 +446,7 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
         LECCR_REQUIRE(p.ab_dtype == LECCR_BF16 && p.c_dtype == LECCR_F32 && !p.trans_a && !p.trans_b && !p.accumulate && (p.c3_form == 0 || p.c3_form == 1) &&
                           (p.N & 3) == 0 && ((uintptr_t)p.c3 & 7) == 0,
                       LECCR_EINVAL, "gemm: c3 (split copy of C) needs bf16 operands, an f32 C, trans_a = trans_b = 0, no accumulate, N %% 4 == 0");
-        LECCR_REQUIRE(p.C || (!g_force_generic && g_gemm_variant == 0 && gemm256_wanted(p)), LECCR_EINVAL,
+        LECCR_REQUIRE(p.C || (g_gemm_variant == 0 && mfma_ok(p) && gemm256_wanted(p)), LECCR_EINVAL,
                       "gemm: a null C beside c3 needs a shape the 8-wave 256x256 kernel takes (M, N >= 256, >= 192 tiles, N %% 8 == 0)");
     }
     LECCR_REQUIRE(p.M >= 0 && p.N >= 0 && p.K >= 0, LECCR_EINVAL, "gemm: negative size");

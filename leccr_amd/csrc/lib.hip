@@ -117,5 +117,5 @@ extern "C" int leccr_prof_read_union(int kind_mask, double* busy_ms, double* wor
     return LECCR_OK;
 }
 
-extern "C" int leccr_version(void) { return 2; }
+extern "C" int leccr_version(void) { return 3; }      // 3: leccr_gemm_params.c3 / c3_form, leccr_split3, leccr_debug_set_stamps declared
 extern "C" const char* leccr_last_error(void) { return leccr::g_err; }

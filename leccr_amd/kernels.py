@@ -90,6 +90,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     epilogue where it can (else by a leccr_split3 pass inside leccr_gemm): -> (C, C3); write_c=False then leaves C itself unwritten
     (None) - only for shapes gemm256_takes()."""
     plan = _split_plan(a, b, trans_a, trans_b, out, accumulate, asum) if a.dtype == torch.float32 else None
+    assert c3_form is None or a.dtype == torch.bfloat16 or plan in ('nt', 'ntb'), 'c3 exists for the bf16 / split-operand NT products only'
     if plan is not None:
         global f32_split_launches
         f32_split_launches += 1
@@ -110,7 +111,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
                         colsum=colsum)
         assert a_s.shape == (a.shape[0], 3 * a.shape[1]) and b_s.shape[1] == a_s.shape[1]
         return gemm(a_s, b_s, bias=bias, epilogue=epilogue, aux=aux, aux_out=aux_out, residual=residual, out=out,
-                    out_dtype=torch.float32, accumulate=accumulate, alpha=alpha, colsum=colsum)
+                    out_dtype=torch.float32, accumulate=accumulate, alpha=alpha, colsum=colsum, c3_form=c3_form, write_c=write_c)
     assert a.dim() == 2 and b.dim() == 2 and (a.dtype == b.dtype or a.dtype == torch.float8_e5m2)
     assert a.stride(1) == 1 and b.stride(1) == 1
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape

@@ -258,6 +258,35 @@ def test_side_streams_give_the_same_gradients():
     assert err <= 1e-5 * float(g_one.abs().max()), err
 
 
+def test_stage_timers_bracket_the_exchange_steps():
+    """leccr_amd.diag (bench.py's stage_ms_per_rank): with the timers on, a training step leaves stream-event spans around the packed
+    gather and the loss stage; off (the default) nothing is recorded."""
+    from leccr_amd import diag
+    model = build(dict(clip_geometry=MID_VIT, text_config=MID_BERT, compute_dtype='bf16', embed_dim=256, clip_text_tower=False), seed=3)
+    batch = _mid_batch()
+
+    def step():
+        losses = model(batch['image'].to(DEV), [Enc(batch['ids_s'].to(DEV), batch['mask_s'].to(DEV)),
+                                                Enc(batch['ids_t'].to(DEV), batch['mask_t'].to(DEV))],
+                       captions=Enc(batch['ids_c'].to(DEV), batch['mask_c'].to(DEV)), idx=batch['idx'].to(DEV))
+        diag.begin('backward')
+        sum(losses).backward()
+        diag.end('backward')
+    diag.reset()
+    step()
+    assert diag.report() == {}
+    diag.enabled = True
+    try:
+        step()
+        step()
+        rep = diag.report()
+    finally:
+        diag.enabled = False
+        diag.reset()
+    assert rep['loss_stage_fwd_n'] == rep['allgather_n'] == rep['backward_n'] == 2
+    assert rep['backward_ms'] > rep['loss_stage_fwd_ms'] >= rep['allgather_ms'] >= 0.0
+
+
 def test_train_step_updates_like_reference_optimizer():
     """create_optimizer/create_scheduler + one step: parameters move exactly as transformers.AdamW would move them
     given the gradients the kernels produced; never-trained parameters stay untouched."""
