@@ -157,6 +157,13 @@ int leccr_gemm(const leccr_gemm_params* p, void* stream);
  * when src is a dY (the column sums of the split copy itself would count hi twice). */
 int leccr_split3(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int form, int transpose, float* colsum,
                  void* stream);
+/* nseg = 3: leccr_split3.  nseg = 6 (the precision option LECCR_F32_SPLITS=6): three bf16 pieces p0 + p1 + p2 of every element and the six
+ * products of order >= 2^-16 (p0 q0, p0 q1, p1 q0, p0 q2, p1 q1, p2 q0: 2^-24 relative, fp32-grade) as [rows, 6 * cols] copies -
+ * X form p0|p0|p1|p0|p1|p2, G form p0|p1|p0|p2|p1|p0 - run by the same bf16 leccr_gemm over 6 K (a sixth of the bf16 rate, still 2.6 x the
+ * f32 MFMA instruction's peak).  Untuned (one element per thread): what it is for is to show that the few tolerances the 3-segment form
+ * needed widened are the form's own noise (tests/test_model_gpu.py). */
+int leccr_split_n(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int form, int nseg, int transpose, float* colsum,
+                  void* stream);
 
 /* ---- LayerNorm --------------------------------------------------------------------------------------------
  * y = (x - mean) * rstd * gamma + beta over the last axis, statistics in f32.

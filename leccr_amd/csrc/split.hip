@@ -24,6 +24,37 @@ __device__ __forceinline__ void split2(float x, bf16_t& hi, bf16_t& lo) {
     lo = static_cast<bf16_t>(x - static_cast<float>(hi));   // exact difference, rounded once
 }
 
+// Six segments (leccr_split_n, nseg = 6): x = p0 + p1 + p2 + e, three bf16 pieces, |e| <= 2^-27 |x|, and the six products of order >= 2^-16
+//        x w ~ p0 q0 + p0 q1 + p1 q0 + p0 q2 + p1 q1 + p2 q0          (2^-24 relative: fp32-grade, at a sixth of the bf16 rate)
+// as segments   X form: p0 | p0 | p1 | p0 | p1 | p2      G form: p0 | p1 | p0 | p2 | p1 | p0     (the 3-segment forms are their first halves).
+__device__ __forceinline__ int seg_piece(int form, int s) {       // which piece (0 = hi, 1 = mid, 2 = lo) segment s of the form carries
+    constexpr int X[6] = {0, 0, 1, 0, 1, 2}, G[6] = {0, 1, 0, 2, 1, 0};
+    return form == 0 ? X[s] : G[s];
+}
+__device__ __forceinline__ void split3p(float x, bf16_t (&p)[3]) {
+    p[0] = static_cast<bf16_t>(x);
+    const float r1 = x - static_cast<float>(p[0]);
+    p[1] = static_cast<bf16_t>(r1);
+    p[2] = static_cast<bf16_t>(r1 - static_cast<float>(p[1]));
+}
+
+// nseg = 6, any shape / alignment (a precision option, not a tuned path): one element per thread, optional transpose and column sums
+__global__ __launch_bounds__(256) void split6_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows, int64_t cols,
+                                                     int64_t ld, int form, int transpose, float* __restrict__ colsum) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= rows * cols) return;
+    // consecutive threads walk the DESTINATION's contiguous dimension
+    const int64_t r = transpose ? id % rows : id / cols, c = transpose ? id / rows : id % cols;
+    const float x = src[r * ld + c];
+    bf16_t p[3];
+    split3p(x, p);
+    const int64_t seg = transpose ? rows : cols;
+    bf16_t* d = transpose ? dst + c * 6 * rows + r : dst + r * 6 * cols + c;
+#pragma unroll
+    for (int s = 0; s < 6; ++s) d[s * seg] = p[seg_piece(form, s)];
+    if (colsum) atomicAdd(colsum + c, x);
+}
+
 // one thread: 8 consecutive elements of a row -> three 16-byte stores
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int64_t rows,
                                                      int64_t cols, int64_t ld, int form) {
@@ -156,6 +187,21 @@ __global__ __launch_bounds__(256) void split3_t_kernel(const float* __restrict__
 }  // namespace leccr
 
 using namespace leccr;
+
+extern "C" int leccr_split_n(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld, int form, int nseg, int transpose,
+                             float* colsum, void* stream) {
+    if (nseg == 3) return leccr_split3(src, dst, rows, cols, ld, form, transpose, colsum, stream);
+    LECCR_REQUIRE(nseg == 6, LECCR_EINVAL, "split_n: nseg must be 3 or 6");
+    LECCR_REQUIRE(src && dst, LECCR_EINVAL, "split_n: null pointer");
+    LECCR_REQUIRE(rows >= 0 && cols >= 0 && ld >= cols && (form == 0 || form == 1), LECCR_EINVAL, "split_n: bad sizes / form");
+    LECCR_REQUIRE(!(colsum && transpose), LECCR_EINVAL, "split_n: colsum with transpose");
+    if (rows == 0 || cols == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PROF_SPLIT, 16.0 * (double)rows * (double)cols, st);
+    hipLaunchKernelGGL(split6_kernel, dim3((unsigned)cdiv(rows * cols, 256)), dim3(256), 0, st, src, reinterpret_cast<bf16_t*>(dst), rows, cols, ld,
+                       form, transpose, colsum);
+    return check_launch("split_n");
+}
 
 extern "C" int leccr_split3(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld, int form, int transpose, float* colsum,
                             void* stream) {

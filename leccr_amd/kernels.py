@@ -28,6 +28,16 @@ def _rows2d(t):
 FORM_X, FORM_G = 0, 1          # hi|hi|lo (activations, [in, out] weight copies)   /   hi|lo|hi (gradients, [out, in] weights)
 f32_mfma = os.environ.get('LECCR_F32_MFMA', '1') != '0'
 f32_split_launches = 0         # gemm() calls that took the split path (tests read it)
+# segments per copy: 3 (hi | hi | lo against hi | lo | hi: 2^-17 per product term, the default) or 6 (three bf16 pieces, six products:
+# 2^-24, fp32-grade, twice the matrix-core work; LECCR_F32_SPLITS=6 / set_f32_segments(6))
+NS = 6 if os.environ.get('LECCR_F32_SPLITS', '3') == '6' else 3
+
+
+def set_f32_segments(n):
+    global NS
+    assert n in (3, 6)
+    prev, NS = NS, n
+    return prev
 _SPLIT_MIN_WORK = 1 << 27      # M * N * K below which the exact scalar kernel is as fast (the 256-wide heads in front of the 1 / temp
                                # amplified losses among them: [b, 768] x [256, 768] at b = 256 is 2^25.6)
 
@@ -43,10 +53,10 @@ def split3(x, form, transpose=False, colsum=None):
     colsum ([cols] f32): += the column sums of x, in the same pass (the bias gradient beside a dY's split)."""
     assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1 and form in (FORM_X, FORM_G)
     rows, cols = x.shape
-    out = torch.empty((cols, 3 * rows) if transpose else (rows, 3 * cols), device=x.device, dtype=torch.bfloat16)
+    out = torch.empty((cols, NS * rows) if transpose else (rows, NS * cols), device=x.device, dtype=torch.bfloat16)
     if colsum is not None:
         assert colsum.dtype == torch.float32 and colsum.numel() == cols and colsum.is_contiguous() and not transpose
-    check(lib().leccr_split3(ptr(x), ptr(out), rows, cols, x.stride(0), form, int(transpose), ptr(colsum), stream()), 'leccr_split3')
+    check(lib().leccr_split_n(ptr(x), ptr(out), rows, cols, x.stride(0), form, NS, int(transpose), ptr(colsum), stream()), 'leccr_split_n')
     return out
 
 
@@ -58,7 +68,7 @@ def gemm256_takes(M, N, Kd):
 
 def split3_colsum_ok(x):
     """Shapes whose split pass can carry the column sums (leccr_split3's colsum)."""
-    return x.shape[1] % 8 == 0 and x.shape[1] <= 8192 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+    return NS == 6 or (x.shape[1] % 8 == 0 and x.shape[1] <= 8192 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
 def _split_plan(a, b, trans_a, trans_b, out, accumulate, asum):
@@ -99,7 +109,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
         a_s = a3[0] if a3 is not None else split3(a, fa)
         b_s = b3[0] if b3 is not None else split3(b, 1 - fa, transpose=(plan == 'ntb'))
         if plan == 'tn':
-            a_s, b_s = a_s.view(3 * a.shape[0], a.shape[1]), b_s.view(3 * b.shape[0], b.shape[1])
+            a_s, b_s = a_s.view(NS * a.shape[0], a.shape[1]), b_s.view(NS * b.shape[0], b.shape[1])
             if asum is not None:        # the column sums of the split copy would count hi twice: one pass over the f32 operand instead
                 if alpha == 1.0:
                     colsum_(a, asum)
@@ -109,7 +119,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
                     axpy(tmp, asum, alpha)
             return gemm(a_s, b_s, trans_a=True, trans_b=True, out=out, out_dtype=torch.float32, accumulate=accumulate, alpha=alpha,
                         colsum=colsum)
-        assert a_s.shape == (a.shape[0], 3 * a.shape[1]) and b_s.shape[1] == a_s.shape[1]
+        assert a_s.shape == (a.shape[0], NS * a.shape[1]) and b_s.shape[1] == a_s.shape[1]
         return gemm(a_s, b_s, bias=bias, epilogue=epilogue, aux=aux, aux_out=aux_out, residual=residual, out=out,
                     out_dtype=torch.float32, accumulate=accumulate, alpha=alpha, colsum=colsum, c3_form=c3_form, write_c=write_c)
     assert a.dim() == 2 and b.dim() == 2 and (a.dtype == b.dtype or a.dtype == torch.float8_e5m2)
@@ -166,7 +176,7 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     c3 = None
     if c3_form is not None:
         assert not fp8 and a.dtype == torch.bfloat16 and (out is None or out.dtype == torch.float32)
-        assert not trans_a and not trans_b and not accumulate and c3_form in (FORM_X, FORM_G) and N % 4 == 0
+        assert not trans_a and not trans_b and not accumulate and c3_form in (FORM_X, FORM_G) and N % 4 == 0 and NS == 3
         c3 = torch.empty(M, 3 * N, device=a.device, dtype=torch.bfloat16)
         p.c3, p.c3_form = ptr(c3), c3_form
     check(lib().leccr_gemm(C.byref(p), stream()), 'leccr_gemm')

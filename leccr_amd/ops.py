@@ -221,7 +221,7 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
     it).  want8: return (y, y8 or None) instead of y.  c8_only (fp8_only_ok): y itself is not written, (None, y8) comes back."""
     if fp8 == X3 and _is_x3(x8):              # f32 operands as bf16 hi / lo splits: x8 = X-form copy of x2, the weight split in G form
         w3 = K.split3(w._lp, K.FORM_G)
-        if want8 and c3_consumer is not None and fuse_x3_copies and _x3_lin_ok(x8.shape[0], c3_consumer):
+        if want8 and c3_consumer is not None and fuse_x3_copies and K.NS == 3 and _x3_lin_ok(x8.shape[0], c3_consumer):
             # the Linear that consumes this output reads only its X-form split copy (forward and weight-gradient product): the GEMM's
             # epilogue writes that copy from its registers, and where the 256 x 256 kernel takes the shape the f32 output is not
             # written at all (the 4d-wide activation: 6 instead of 4 + 4 + 6 bytes per element through HBM)
@@ -247,7 +247,7 @@ def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False,
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
     if fp8 == X3 and _is_x3(g8):              # G-form copy of dY against the X-form split of W^T ([in, 3 out], K-contiguous)
         w3t = K.split3(w._lp, K.FORM_X, transpose=True)
-        if want8 and c3_consumer is not None and fuse_x3_copies and _x3_lin_ok(g8.shape[0], c3_consumer) \
+        if want8 and c3_consumer is not None and fuse_x3_copies and K.NS == 3 and _x3_lin_ok(g8.shape[0], c3_consumer) \
                 and K.gemm256_takes(g8.shape[0], w3t.shape[0], w3t.shape[1]):
             # the gradient this product writes is read only through its G-form copy (dX and weight-gradient product of the consumer):
             # written by the epilogue, no f32 tensor; the consumer's bias gradient = column sums of the copy's hi and lo segments
@@ -452,7 +452,7 @@ def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None, bias_done=Fals
     if _is_x3(g8):
         # f32 operands as bf16 hi / lo splits: the [rows, 3 cols] copies read as [3 rows, cols], one TN launch over 3 x rows
         rows = g8.shape[0]
-        K.gemm(g8.view(3 * rows, g8.shape[1] // 3), x8.view(3 * rows, x8.shape[1] // 3), trans_a=True, trans_b=True, out=w._g,
+        K.gemm(g8.view(K.NS * rows, g8.shape[1] // K.NS), x8.view(K.NS * rows, x8.shape[1] // K.NS), trans_a=True, trans_b=True, out=w._g,
                accumulate=True, alpha=scale)
         fused = False           # (the split copy's own column sums would count hi twice: colsum over the f32 gradient below)
     elif g8 is not None:

@@ -1438,3 +1438,34 @@ def test_gemm_writes_the_split_copy_of_its_output(K, M, N, K_, fused, case):
     if fused:
         none, c3b = K.gemm(a3, b3, out_dtype=torch.float32, c3_form=form, write_c=False, **kw)
         assert none is None and torch.equal(c3b.view(torch.int16), c3.view(torch.int16))
+
+
+@pytest.mark.parametrize('M,N,K_', [(1152, 768, 768), (304, 264, 192)])
+def test_gemm_f32_six_segment_operands(K, M, N, K_, monkeypatch):
+    """LECCR_F32_SPLITS=6: three bf16 pieces per element, six products in one launch over 6 K - fp32-grade (2^-24 per term): error against f64
+    at the level of the scalar f32 kernel's, an order of magnitude under the 3-segment form's; NT, B-transposed and weight-gradient forms."""
+    monkeypatch.setattr(K, '_SPLIT_MIN_WORK', 1)
+    a, b = _rand((M, K_), torch.float32, 51), _rand((N, K_), torch.float32, 52, 0.05)
+    ref = a.double() @ b.double().t()
+    e3, s = _err(K.gemm(a.to(DEV), b.to(DEV)), ref)
+    prev = K.set_f32_segments(6)
+    try:
+        x6 = K.split3(a.to(DEV), K.FORM_X)
+        assert x6.shape == (M, 6 * K_)
+        p0 = a.bfloat16(); p1 = (a - p0.float()).bfloat16(); p2 = (a - p0.float() - p1.float()).bfloat16()
+        assert torch.equal(x6.cpu().view(torch.int16), torch.cat([p0, p0, p1, p0, p1, p2], 1).contiguous().view(torch.int16))
+        g6t = K.split3(b.to(DEV), K.FORM_G, transpose=True)
+        q0 = b.bfloat16(); q1 = (b - q0.float()).bfloat16(); q2 = (b - q0.float() - q1.float()).bfloat16()
+        assert torch.equal(g6t.cpu().view(torch.int16), torch.cat([t.t() for t in (q0, q1, q0, q2, q1, q0)], 1).contiguous().view(torch.int16))
+        n0 = K.f32_split_launches
+        e6, _ = _err(K.gemm(a.to(DEV), b.to(DEV)), ref)
+        e6t, _ = _err(K.gemm(a.to(DEV), b.t().contiguous().to(DEV), trans_b=True), ref)
+        w = torch.zeros(N, M, device=DEV)
+        K.gemm(b.t().contiguous().to(DEV), a.t().contiguous().to(DEV), trans_a=True, trans_b=True, out=w, accumulate=True)   # [K, N]^T [K, M]
+        e6w, _ = _err(w, ref.t())
+        assert K.f32_split_launches == n0 + 3
+    finally:
+        K.set_f32_segments(prev)
+    # measured at K = 768: 3 segments 3.0e-5, 6 segments 1.05e-5 (NT: what is left is the matrix core's own f32 accumulation over 144
+    # k-steps of one accumulator), 1.4e-6 in the split-K weight-gradient form; largest magnitude 6.8
+    assert max(e6, e6t, e6w) <= 4e-6 * s and max(e6, e6t) < 0.5 * e3, (e3, e6, e6t, e6w, s)
