@@ -360,3 +360,24 @@ def test_tokenizing_collate_moves_the_tokenizer_calls_into_the_loader_workers():
         [(torch.zeros(2, 8), 'one two', 'yi er san', 'gen cap', 7, 'v7#enc#0'), (torch.ones(2, 8), 'three', 'si', 'gen', 9, 'v9#enc#0')])
     assert vb[0].shape == (2, 2, 8) and vb[1].dtype == torch.bool and vb[4].tolist() == [7, 9]
     assert vb[2][1].input_ids.tolist() == [[101, 2, 2, 3, 102], [101, 2, 102, 0, 0]] and vb[3].input_ids.shape == (2, 4)
+
+
+def test_fp32_split_path_host_decisions():
+    """Host side of the fp32-on-the-matrix-cores path (kernels.gemm / ops.X3), no GPU: which shapes take the 256 x 256 kernel's fused copy,
+    that CPU tensors never enter the split path (the product path still fails loudly on them), that the segment count is 3 or 6, and
+    that the stage timers record nothing while they are off."""
+    from leccr_amd import diag, kernels as K, ops
+    assert K.gemm256_takes(147712, 3072, 2304) and K.gemm256_takes(16384, 3072, 2304)           # config-B MLP shapes, ViT and BERT
+    assert not K.gemm256_takes(1154, 768, 2304) and not K.gemm256_takes(147712, 3076, 2304) and not K.gemm256_takes(147712, 3072, 100)
+    a, b = torch.zeros(512, 768), torch.zeros(768, 768)
+    assert K._split_plan(a, b, False, False, None, False, None) is None                          # CPU tensors: no plan ..
+    with pytest.raises(Exception):
+        K.gemm(a, b)                                                                             # .. and no fallback either
+    assert K.NS in (3, 6) and K.FORM_X == 0 and K.FORM_G == 1 and ops.X3 == 'x3'
+    prev = K.set_f32_segments(6)
+    assert K.NS == 6 and K.set_f32_segments(prev) == 6 and K.NS == prev
+    with pytest.raises(AssertionError):
+        K.set_f32_segments(4)
+    assert not diag.enabled
+    diag.begin('x'); diag.end('x')
+    assert diag._spans == {} and diag._open == {}
