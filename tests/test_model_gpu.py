@@ -258,6 +258,43 @@ def test_side_streams_give_the_same_gradients():
     assert err <= 1e-5 * float(g_one.abs().max()), err
 
 
+def test_fp32_matrix_core_path_tracks_the_scalar_path_over_training_steps(monkeypatch):
+    """End to end over optimizer steps: the same MID-geometry model trained 12 steps (AdamW, lr 1e-4) through (a) the fp32 path on the
+    matrix cores - split-operand GEMMs at every size (threshold lowered for this geometry), pair-form attention - and (b) the scalar f32
+    kernels (leccr_set_force_generic).  The five losses of every step agree to 2e-4 (the two paths differ by 2^-17 per product term,
+    and Adam does not amplify that in the LOSSES); both trajectories descend."""
+    from leccr_amd import kernels as K
+    from leccr_amd._lib import lib
+    from leccr_amd.optim import create_optimizer
+    monkeypatch.setattr(K, '_SPLIT_MIN_WORK', 1)
+    batch = _mid_batch()
+
+    def train(scalar):
+        model = build(dict(clip_geometry=MID_VIT, text_config=MID_BERT, compute_dtype='fp32', embed_dim=256, clip_text_tower=False), seed=3)
+        with torch.no_grad():
+            model.queries.normal_(0, 0.5)
+        opt = create_optimizer(dict(lr=1e-4, weight_decay=0.01), model)
+        lib().leccr_set_force_generic(1 if scalar else 0)
+        try:
+            n0, out = K.f32_split_launches, []
+            for _ in range(12):
+                losses = model(batch['image'].to(DEV), [Enc(batch['ids_s'].to(DEV), batch['mask_s'].to(DEV)),
+                                                        Enc(batch['ids_t'].to(DEV), batch['mask_t'].to(DEV))],
+                               captions=Enc(batch['ids_c'].to(DEV), batch['mask_c'].to(DEV)), idx=batch['idx'].to(DEV))
+                opt.zero_grad()
+                sum(losses).backward()
+                opt.step()
+                out.append([float(l) for l in losses])
+            return np.array(out), K.f32_split_launches - n0
+        finally:
+            lib().leccr_set_force_generic(0)
+    fast, n_fast = train(False)
+    slow, _ = train(True)
+    assert n_fast > 12 * 50                                     # the split-operand launches really ran
+    assert np.max(np.abs(fast - slow)) <= 2e-4, np.max(np.abs(fast - slow))
+    assert fast[-1].sum() < fast[0].sum() and slow[-1].sum() < slow[0].sum()
+
+
 def test_stage_timers_bracket_the_exchange_steps():
     """leccr_amd.diag (bench.py's stage_ms_per_rank): with the timers on, a training step leaves stream-event spans around the packed
     gather and the loss stage; off (the default) nothing is recorded."""
