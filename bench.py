@@ -624,12 +624,14 @@ def _main(args, real_stdout):
             sched.step()
         mine = diag.report()
         diag.enabled = False
+        stage_ms = {f'rank{rank}': mine}
         if world > 1:
-            allr = [None] * world
-            dist.all_gather_object(allr, mine)
-            stage_ms = {f'rank{r}': d for r, d in enumerate(allr)}
-        else:
-            stage_ms = {'rank0': mine}
+            try:                                    # (diagnostics must never cost the run its result line)
+                allr = [None] * world
+                dist.all_gather_object(allr, mine)
+                stage_ms = {f'rank{r}': d for r, d in enumerate(allr)}
+            except Exception as e:                  # noqa: BLE001
+                print(f'bench.py: stage timers of the other ranks unavailable ({e})', file=sys.stderr)
     parity = None
     retrieval = None
     if not args.no_parity and (world == 1 or (rank == 0 and args.model == 'image')):
