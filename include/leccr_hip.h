@@ -383,6 +383,11 @@ int leccr_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int
  */
 int leccr_fp8_amax(const void* x, int64_t rows, int64_t cols, int64_t ldx, int dtype, float* site, void* stream);
 int leccr_fp8_update(float* sites, int64_t n, void* stream);
+/* The same with the running maximum of the NEXT step starting at keep x this step's amax instead of 0 (0 <= keep < 1): the per-step update of
+ * the activation / gradient sites.  Producers issue their same-address amax atomic only when their own maximum exceeds the stored one; from 0
+ * every resident wave of a site's first launch does (86 us in front of a 171 us LayerNorm pass).  Recorded amax = max(keep x previous, own):
+ * never below the true maximum. */
+int leccr_fp8_update_keep(float* sites, int64_t n, float keep, void* stream);
 int leccr_fp8_quantize(const void* x, void* y, int64_t rows, int64_t cols, int64_t ldx, int64_t ldy, int dtype, int fmt,
                        float* site, void* stream);
 /* Weights (current scaling, once per optimizer step): every Linear's bf16 compute copy [R, C] -> its e4m3 copies in both layouts

@@ -67,6 +67,7 @@ _SIGS = {
     'leccr_colsum': ([vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_fp8_amax': ([vp, i64, i64, i64, C.c_int, vp, vp], C.c_int),
     'leccr_fp8_update': ([vp, i64, vp], C.c_int),
+    'leccr_fp8_update_keep': ([vp, i64, f32, vp], C.c_int),
     'leccr_fp8_quantize': ([vp, vp, i64, i64, i64, i64, C.c_int, C.c_int, vp, vp], C.c_int),
     'leccr_fp8_requantize_weights': ([vp, i64, i64, vp], C.c_int),
     'leccr_l2norm_fwd': ([vp, vp, vp, i64, i64, C.c_int, vp], C.c_int),

@@ -600,9 +600,12 @@ class Fp8Sites:
         self.state[i, 3] = float(fmt)
         return Fp8Site(self.state[i], fmt)
 
-    def update(self):
+    # share of a site's amax that the next step's running maximum starts from (leccr_fp8_update_keep; LECCR_FP8_AMAX_KEEP=0: from zero)
+    keep = float(os.environ.get('LECCR_FP8_AMAX_KEEP', '0.9'))
+
+    def update(self, keep=None):
         if self.n:
-            check(lib().leccr_fp8_update(ptr(self.state), self.n, stream()), 'leccr_fp8_update')
+            check(lib().leccr_fp8_update_keep(ptr(self.state), self.n, self.keep if keep is None else keep, stream()), 'leccr_fp8_update_keep')
 
 
 class Fp8Site:
