@@ -280,6 +280,8 @@ def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False,
 # step: 155.0 -> 150.8 ms.  LECCR_DW_STREAM=0 keeps everything on one stream.
 wgrad_overlap = os.environ.get('LECCR_DW_STREAM', '1') != '0'
 wgrad_overlap_f32 = os.environ.get('LECCR_DW_STREAM_F32', '0') != '0'      # .. for the fp32 path (see lin_dw)
+wgrad_inline_under_pressure = os.environ.get('LECCR_DW_INLINE_PRESSURE', '1') != '0'   # .. and no side stream for a pass that starts under memory pressure
+_pass_inline = None          # this backward pass runs its weight-gradient launches on the main stream (decided at its first one)
 fuse_bias_grad = os.environ.get('LECCR_FUSE_BIAS_GRAD', '1') != '0'      # bias gradients inside the dW GEMM (0: separate colsum launches)
 # The text towers (caption BERT forward, text BERT forward + backward: small-M GEMMs that leave CUs idle) run on a third stream
 # beside the image tower (150.8 -> 148.7 ms on the batch-256 step).  LECCR_TEXT_STREAM=0 keeps them on the main stream.
@@ -298,7 +300,8 @@ _wgrad_join_queued = False
 def begin_step():
     """Called at the start of every model forward: a backward pass that raised leaves its end-of-pass join unqueued-but-flagged;
     the next pass must queue its own."""
-    global _wgrad_join_queued, _g8_slot
+    global _wgrad_join_queued, _g8_slot, _pass_inline
+    _pass_inline = None
     _wgrad_join_queued = False
     _g8_slot = None
     _wgrad_events.clear()
@@ -373,6 +376,16 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_d
     # queue behind them: same-box A/B 397.0 ms with the side stream, 374.8 without (LECCR_DW_STREAM_F32=1 turns it back on)
     f32_path = _is_x3(g8) or (dy2 is not None and dy2.dtype == torch.float32)
     if not (wgrad_overlap and ref.is_cuda) or (f32_path and not wgrad_overlap_f32):
+        return _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8, bias_done)
+    # Under memory pressure (the config-E geometry: 150-175 of 288 GB allocated when the backward pass starts) the side stream needs the
+    # host throttle below to keep the allocator's overhang bounded - and then measures SLOWER than no side stream at all (config E fp8,
+    # same box: 381.4 ms with it, 375.5 without; config B, no pressure: 130.6 with, 132.1 without).  Decided once per backward pass.
+    global _pass_inline
+    if _pass_inline is None:
+        total = torch.cuda.get_device_properties(ref.device).total_memory
+        _pass_inline = wgrad_inline_under_pressure and (torch.cuda.memory_allocated(ref.device) > wgrad_lag_pressure * total
+                                                        or torch.cuda.memory_reserved(ref.device) > wgrad_lag_reserved * total)
+    if _pass_inline:
         return _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8, bias_done)
     main = torch.cuda.current_stream()
     if _wgrad_stream is None:
