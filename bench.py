@@ -61,7 +61,7 @@ def parse():
     ap.add_argument('--eval-batch', type=int, default=6, help='batch_size_test (Retrieval_multi30k_de_ft.yaml: 6)')
     ap.add_argument('--eval-text-batch', type=int, default=32, help='batch_size_test_text (Retrieval_multi30k_de_ft.yaml: 32)')
     ap.add_argument('--eval-no-regroup', action='store_true', help='run every loader batch through the towers as it is yielded (the reference '
-                    'loop); default: evaluation_coarse regroups them to 64 images / 256 texts per forward - same scores')
+                    'loop); default: evaluation_coarse regroups them to 256 images / 1024 texts per forward - same scores')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--parity-rows', type=int, default=16, help='rows of the batch the parity probe runs through the CPU oracle (config E: 4 keeps it to minutes)')
@@ -474,7 +474,7 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
                'dtype': args.dtype, 'data': 'synthetic',
                'config': {'workload': f'evaluation_coarse + itm_eval, {ni} images x {nt} texts (Multi30K-test shaped), {args.clip}@384 + {args.text}, '
                                       f'{args.dtype}, batch_size_test {bs}, batch_size_test_text {args.eval_text_batch}'
-                                      + (' (run as yielded)' if args.eval_no_regroup else ' (regrouped to >= 64 images / 256 texts per forward inside evaluation_coarse)')
+                                      + (' (run as yielded)' if args.eval_no_regroup else ' (regrouped to >= 256 images / 1024 texts per forward inside evaluation_coarse)')
                                       + ', L_t=32, L_c=64, eval mode'
                                       + (f', encoders sharded over {world} ranks' if world > 1 else ''),
                           'parallelism': f'dp{world}', 'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
