@@ -1474,3 +1474,75 @@ def test_gemm_f32_six_segment_operands(K, M, N, K_, monkeypatch):
     # measured at K = 768: 3 segments 3.0e-5, 6 segments 1.05e-5 (NT: what is left is the matrix core's own f32 accumulation over 144
     # k-steps of one accumulator), 1.4e-6 in the split-K weight-gradient form; largest magnitude 6.8
     assert max(e6, e6t, e6w) <= 4e-6 * s and max(e6, e6t) < 0.5 * e3, (e3, e6, e6t, e6w, s)
+
+
+def test_attention_f32_matrix_core_kernels_on_random_small_problems(K):
+    """Edge coverage for the fp32 attention kernels on the matrix cores (attention_x3.hip): 24 random problems - 1 to 140 queries and keys
+    (single rows, partial 32-row tiles, tiles of one key), key-padding masks down to one visible key, dropout on / off, strided packed
+    layouts - each against the scalar kernels on the same inputs (forward, lse, dq / dk / dv)."""
+    from leccr_amd._lib import lib
+    g = torch.Generator().manual_seed(4242)
+    for case in range(24):
+        b, heads = int(torch.randint(1, 4, (1,), generator=g)), int(torch.randint(1, 5, (1,), generator=g))
+        Lq, Lk = (int(torch.randint(1, 141, (1,), generator=g)) for _ in range(2))
+        if case % 5 == 0:
+            Lk = Lq
+        d = heads * 64
+        drop = 0.15 if case % 3 == 0 else 0.0
+        if Lq == Lk and case % 2 == 0:       # packed qkv buffer (row stride 3 d)
+            qkv = torch.randn(b, Lq, 3 * d, generator=g).to(DEV)
+            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        else:
+            q = torch.randn(b, Lq, d, generator=g).to(DEV)
+            kv = torch.randn(b, Lk, 2 * d, generator=g).to(DEV)
+            k, v = kv[..., :d], kv[..., d:]
+        kmask = None
+        if case % 4 != 3:
+            lens = torch.randint(1, Lk + 1, (b,), generator=g)
+            kmask = (torch.arange(Lk)[None, :] >= lens[:, None]).to(torch.uint8).to(DEV)
+        do = torch.randn(b, Lq, d, generator=g).to(DEV)
+        o, lse = K.attn_fwd(q, k, v, heads, kmask, drop, 1000 + case)
+        assert lib().leccr_last_attn_kernel() in (4, 5), case
+        dq, dk, dv = K.attn_bwd(q, k, v, o, do, lse, heads, kmask, drop_p=drop, seed=1000 + case)
+        lib().leccr_set_force_generic(1)
+        try:
+            o2, lse2 = K.attn_fwd(q, k, v, heads, kmask, drop, 1000 + case)
+            dq2, dk2, dv2 = K.attn_bwd(q, k, v, o2, do, lse2, heads, kmask, drop_p=drop, seed=1000 + case)
+        finally:
+            lib().leccr_set_force_generic(0)
+        for name, x, y in (('o', o, o2), ('lse', lse, lse2), ('dq', dq, dq2), ('dk', dk, dk2), ('dv', dv, dv2)):
+            assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(y).all()), (case, name)
+            e, s = float((x - y).abs().max()), float(y.abs().max()) + 1e-12
+            # (absolute floor: a row with ONE visible key has p = 1 and an exactly-zero dS in exact arithmetic; the pair-form dP and the f32
+            #  delta then differ by the form's 2^-17 of |dO||V|, which is all that is left - measured 3.5e-5 on unit-variance inputs)
+            assert e <= 6e-5 * s + 2e-4, (case, name, e, s, b, heads, Lq, Lk, drop, kmask is not None)
+
+
+def test_split3_on_random_shapes_and_strides(K):
+    """leccr_split3 / leccr_split_n over 20 random shapes (odd widths, row strides wider than the row, transposed, with column sums, 3 and 6
+    segments): every segment bit-equal to torch's own hi / mid / lo conversions."""
+    g = torch.Generator().manual_seed(77)
+    X6, G6 = (0, 0, 1, 0, 1, 2), (0, 1, 0, 2, 1, 0)
+    for case in range(20):
+        rows, cols = int(torch.randint(1, 300, (1,), generator=g)), int(torch.randint(1, 40, (1,), generator=g)) * (8 if case % 2 else 1)
+        ld = cols + int(torch.randint(0, 3, (1,), generator=g)) * 4
+        x = torch.randn(rows, ld, generator=g)[:, :cols]
+        p0 = x.bfloat16(); p1 = (x - p0.float()).bfloat16(); p2 = (x - p0.float() - p1.float()).bfloat16()
+        pieces = (p0, p1, p2)
+        for ns in (3, 6):
+            prev = K.set_f32_segments(ns)
+            try:
+                for form in (0, 1):
+                    tab = (X6 if form == 0 else G6)[:ns]
+                    want = torch.cat([pieces[i] for i in tab], 1).contiguous()
+                    cs = torch.zeros(cols, device=DEV) if (case % 3 == 0 and (ns == 6 or cols % 8 == 0)) else None
+                    got = K.split3(x.to(DEV), form, colsum=cs)
+                    assert torch.equal(got.cpu().view(torch.int16), want.view(torch.int16)), (case, ns, form, rows, cols, ld)
+                    if cs is not None:
+                        e, s = _err(cs, x.double().sum(0))
+                        assert e <= 2e-5 * s + 1e-6, (case, ns, e, s)
+                    want_t = torch.cat([pieces[i].t() for i in tab], 1).contiguous()
+                    got_t = K.split3(x.to(DEV), form, transpose=True)
+                    assert torch.equal(got_t.cpu().view(torch.int16), want_t.view(torch.int16)), (case, ns, form, 'T', rows, cols, ld)
+            finally:
+                K.set_f32_segments(prev)
