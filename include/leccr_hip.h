@@ -203,6 +203,10 @@ int leccr_layernorm_bwd_drop(const void* dy, const void* x_in, const float* gamm
 int leccr_layernorm_fwd_ex(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                            void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p,
                            uint64_t seed, void* y8, float* y8_site, int y8_fmt, int dtype, void* stream);
+/* fp32 path: the pass also writes y's bf16 (hi, lo) split copy y3 [rows, 3 d] (leccr_split3's layout, form 0 / 1) - the operand copy of the
+ * next product; y itself may be NULL when nothing else reads it.  f32 rows only. */
+int leccr_layernorm_fwd_s3(const void* x, const void* add, const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
+                           float* rstd, int64_t rows, int64_t d, float eps, float p, uint64_t seed, void* y3, int form, void* stream);
 int leccr_layernorm_bwd_ex(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
                            const void* dres, void* dx, float* dgamma, float* dbeta, void* dx_drop, float p, uint64_t seed,
                            void* g8, float* g8_site, int g8_fmt, int64_t rows, int64_t d, int dtype, void* stream);

@@ -49,6 +49,7 @@ _SIGS = {
     'leccr_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, i64, C.c_int, vp], C.c_int),
     'leccr_layernorm_fwd_drop': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, C.c_uint64, C.c_int, vp], C.c_int),
     'leccr_layernorm_bwd_drop': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, C.c_uint64, i64, i64, C.c_int, vp], C.c_int),
+    'leccr_layernorm_fwd_s3': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, C.c_uint64, vp, C.c_int, vp], C.c_int),
     'leccr_layernorm_fwd_ex': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, C.c_uint64, vp, vp, C.c_int, C.c_int, vp], C.c_int),
     'leccr_layernorm_bwd_ex': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, C.c_uint64, vp, vp, C.c_int, i64, i64, C.c_int, vp], C.c_int),
     'leccr_attn_fwd': ([vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64, i64, C.c_int, f32, C.c_uint64, vp], C.c_int),

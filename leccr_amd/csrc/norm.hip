@@ -11,7 +11,8 @@ namespace leccr {
 struct Q8Out {
     uint8_t* out;      // [rows, d] fp8, or nullptr: off
     float* site;       // {amax, scale, 1/scale, fmt}
-    int fmt;           // 0 e4m3, 1 e5m2
+    int fmt;           // 0 e4m3, 1 e5m2; 2 / 3 (f32 rows only, no site): `out` is the bf16 (hi, lo) split copy [rows, 3 d] of leccr_split3 in
+                       // form 0 (hi|hi|lo) / 1 (hi|lo|hi) - the operand copy of the fp32 path's next product (leccr_layernorm_fwd_s3)
 };
 __device__ __forceinline__ int q8_pack4(const Q8Out& q, float sc, float a, float b, float c, float d) {
     const float fmax = q.fmt ? 57344.f : 448.f;
@@ -90,15 +91,26 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         rstd[row] = rs;
     }
     [[maybe_unused]] float q8sc = 1.f, q8m = 0.f;
-    if constexpr (EX) q8sc = q8.out ? q8.site[1] : 1.f;
+    if constexpr (EX) q8sc = (q8.out && q8.fmt < 2) ? q8.site[1] : 1.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = (lane + 64 * i) * 4;
         if (c < d) {
             const f32x4 g = load4(gamma + c), b = load4(beta + c);
             const f32x4 o = (v[i] - mu) * rs * g + b;
-            store4(y + row * d + c, o);
-            if (EX && q8.out) {
+            if (y) store4(y + row * d + c, o);
+            if (EX && q8.out && q8.fmt >= 2) {       // the split copy of the fp32 path (a wave covers 256 consecutive columns per segment)
+                bf16x4 h4, l4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h4[j] = (bf16_t)to_f32(from_f32<T>(o[j]));
+                    l4[j] = (bf16_t)(to_f32(from_f32<T>(o[j])) - (float)h4[j]);
+                }
+                bf16_t* d3 = reinterpret_cast<bf16_t*>(q8.out) + row * 3 * d + c;
+                *reinterpret_cast<bf16x4*>(d3) = h4;
+                *reinterpret_cast<bf16x4*>(d3 + d) = q8.fmt == 2 ? h4 : l4;
+                *reinterpret_cast<bf16x4*>(d3 + 2 * d) = q8.fmt == 2 ? l4 : h4;
+            } else if (EX && q8.out) {
                 float r[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -109,7 +121,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
             }
         }
     }
-    if (EX && q8.out) q8_amax(q8, q8m);
+    if (EX && q8.out && q8.fmt < 2) q8_amax(q8, q8m);
 }
 
 // Backward.  Grid-stride over rows so each wave accumulates its dgamma/dbeta partials in registers; one LDS reduce
@@ -545,9 +557,15 @@ static int q8_check(const char* who, void* q8, float* site, int fmt, int64_t d) 
 static int ln_fwd_entry(const void* x, const void* add, const float* gamma, const float* beta, void* y, void* sum_out,
                         float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p, uint64_t seed, void* y8,
                         float* y8_site, int y8_fmt, int dtype, void* stream) {
-    if (int rc = q8_check("layernorm_fwd", y8, y8_site, y8_fmt, d)) return rc;
+    if (y8_fmt >= 2) {          // the bf16 split copy (leccr_layernorm_fwd_s3): f32 rows, 8-byte aligned copy, no site; y itself may be omitted
+        LECCR_REQUIRE(y8 && (y8_fmt == 2 || y8_fmt == 3) && dtype == LECCR_F32 && ((uintptr_t)y8 & 7) == 0, LECCR_EINVAL,
+                      "layernorm_fwd_s3: needs the copy's buffer (8-byte aligned), form 0 / 1, f32 rows");
+    } else {
+        if (int rc = q8_check("layernorm_fwd", y8, y8_site, y8_fmt, d)) return rc;
+        LECCR_REQUIRE(y, LECCR_EINVAL, "layernorm_fwd: null y");
+    }
     const Q8Out q8{(uint8_t*)y8, y8_site, y8_fmt};
-    LECCR_REQUIRE(x && gamma && beta && y && mean && rstd, LECCR_EINVAL, "layernorm_fwd: null pointer");
+    LECCR_REQUIRE(x && gamma && beta && mean && rstd, LECCR_EINVAL, "layernorm_fwd: null pointer");
     LECCR_REQUIRE(d > 0 && d <= 4096 && (d & 3) == 0, LECCR_EINVAL, "layernorm_fwd: d=%lld must be a multiple of 4, <= 4096", (long long)d);
     LECCR_REQUIRE(p >= 0.f && p < 1.f && (p == 0.f || rows * d < (1ll << 32)), LECCR_EINVAL,
                   "layernorm_fwd: dropout p in [0, 1); with dropout fewer than 2^32 elements (32-bit element counter of the mask)");
@@ -556,7 +574,7 @@ static int ln_fwd_entry(const void* x, const void* add, const float* gamma, cons
     DropCfg drop = make_drop(p, seed);
     if (p == 0.f) drop.thr = 0;
     const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
-    ProfScope prof(PROF_LN_FWD, (double)rows * d * (esz * (2 + (add ? 1 : 0) + (sum_out ? 1 : 0)) + (y8 ? 1.0 : 0.0)) + 8.0 * rows, st);
+    ProfScope prof(PROF_LN_FWD, (double)rows * d * (esz * (1 + (y ? 1 : 0) + (add ? 1 : 0) + (sum_out ? 1 : 0)) + (y8 ? (y8_fmt >= 2 ? 6.0 : 1.0) : 0.0)) + 8.0 * rows, st);
     DISPATCH_T(dtype, ln_fwd_dispatch<float>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, q8, st),
                ln_fwd_dispatch<bf16_t>(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, drop, q8, st));
 }
@@ -576,7 +594,17 @@ extern "C" int leccr_layernorm_fwd_drop(const void* x, const void* add, const fl
 extern "C" int leccr_layernorm_fwd_ex(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                                       void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p,
                                       uint64_t seed, void* y8, float* y8_site, int y8_fmt, int dtype, void* stream) {
+    LECCR_REQUIRE(!y8 || y8_fmt == 0 || y8_fmt == 1, LECCR_EINVAL, "layernorm_fwd_ex: fmt 0 (e4m3) / 1 (e5m2)");
     return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, p, seed, y8, y8_site, y8_fmt, dtype, stream);
+}
+
+// .. and, for f32 rows, the bf16 (hi, lo) split copy of y (leccr_split3's [rows, 3 d] layout, form 0 / 1) written by the pass itself - the
+// operand copy the fp32 path's next product reads; y may be NULL when nothing reads the f32 tensor (a pre-LN block's h1 / h2)
+extern "C" int leccr_layernorm_fwd_s3(const void* x, const void* add, const float* gamma, const float* beta, void* y, void* sum_out,
+                                      float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p, uint64_t seed, void* y3,
+                                      int form, void* stream) {
+    LECCR_REQUIRE(form == 0 || form == 1, LECCR_EINVAL, "layernorm_fwd_s3: form 0 (hi|hi|lo) or 1 (hi|lo|hi)");
+    return ln_fwd_entry(x, add, gamma, beta, y, sum_out, mean, rstd, rows, d, eps, p, seed, y3, nullptr, 2 + form, LECCR_F32, stream);
 }
 
 static int ln_bwd_entry(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,

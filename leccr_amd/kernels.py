@@ -190,11 +190,28 @@ def _q8_out(site, rows, d, device):
     return torch.empty(rows, d, device=device, dtype=site.torch_dtype), site.row, site.fmt
 
 
-def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None, q8_site=None):
+def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None, q8_site=None, s3_form=None, write_y=True):
     """drop = (p, seed): normalise dropout(x) (+ add) - the mask leccr_dropout(x, p, seed) would apply, inside this pass.
-    q8_site (an Fp8Site): also return y's fp8 copy under that site as a 5th value (None until the site is primed)."""
+    q8_site (an Fp8Site): also return y's fp8 copy under that site as a 5th value (None until the site is primed).
+    s3_form (f32 rows, 3-segment copies): also return y's bf16 (hi, lo) split copy [rows, 3 d] in that form as a 5th value, written by the
+    pass itself; write_y=False then leaves y itself unwritten (None) - for a tensor nothing else reads."""
     x2, rows, d, ld = _rows2d(x)
     assert ld == d
+    if s3_form is not None:
+        assert x.dtype == torch.float32 and q8_site is None and NS == 3 and s3_form in (FORM_X, FORM_G)
+        y = torch.empty_like(x2) if write_y else None
+        y3 = torch.empty(rows, 3 * d, device=x.device, dtype=torch.bfloat16)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        s = torch.empty_like(x2) if want_sum else None
+        if add is not None:
+            add = add.reshape(rows, d)
+            assert add.is_contiguous() and add.dtype == x.dtype
+        p_, seed_ = (float(drop[0]), int(drop[1])) if drop is not None else (0.0, 0)
+        check(lib().leccr_layernorm_fwd_s3(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd), rows, d, eps,
+                                           p_, seed_, ptr(y3), s3_form, stream()), 'leccr_layernorm_fwd_s3')
+        return (y.view(x.shape) if y is not None else None), mean, rstd, (s.view(x.shape) if s is not None else None), y3
+    assert write_y
     y = torch.empty_like(x2)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)

@@ -82,9 +82,14 @@ def _q8_site(on, rows, w, which):
     return getattr(w, which, None)
 
 
-def _ln_fwd(x, gamma, beta, eps, site=None, **kw):
+def _ln_fwd(x, gamma, beta, eps, site=None, x3_for=None, x3_only=False, **kw):
     """K.layernorm_fwd -> (y, mean, rstd, sum or None, y8 or None): with a site (fp8 mode) the pass also writes y's fp8 copy for the
-    product that consumes it - no quantise pass over y."""
+    product that consumes it - no quantise pass over y.  x3_for (mode X3: the Linear that consumes y): the pass writes y's X-form split
+    copy itself (5th value) when that Linear's products run on split copies; x3_only: y then stays unwritten (None) - a pre-LN block's
+    h1 / h2 are read by nothing else."""
+    if x3_for is not None and fuse_x3_copies and ln_x3_copies and K.NS == 3 and x.dtype == torch.float32 and x.is_contiguous() \
+            and _x3_lin_ok(x.numel() // x.shape[-1], x3_for):
+        return K.layernorm_fwd(x, gamma, beta, eps, s3_form=K.FORM_X, write_y=not x3_only, **kw)
     if site is None:
         return K.layernorm_fwd(x, gamma, beta, eps, **kw) + (None,)
     return K.layernorm_fwd(x, gamma, beta, eps, q8_site=site, **kw)
@@ -137,6 +142,7 @@ fp8_dw_launches = 0          # fp8 weight-gradient products launched (tests read
 # splitting (each product splits its own operands).
 X3 = 'x3'
 fuse_x3_copies = os.environ.get('LECCR_X3_FUSE', '1') != '0'      # the GEMM epilogues write the split copies of the 4d-wide MLP tensors
+ln_x3_copies = os.environ.get('LECCR_X3_LN', '1') != '0'       # .. and the encoder blocks' LayerNorm passes write h1 / h2 as split copies only
 
 
 def _x3_lin_ok(rows, w):
@@ -154,9 +160,11 @@ def x8_of(fp8, x2, w, x8=None):
     """The e4m3 copy of x2 that Linear `w` multiplies in fp8 mode (x8 if the producer wrote it), None when that product is bf16.
     Mode X3: the X-form split copy of the f32 x2."""
     if fp8 == X3:
-        if x2.dtype != torch.float32 or not _x3_lin_ok(x2.shape[0], w) or x2.stride(1) != 1:
+        if _is_x3(x8):              # written by the producer (LayerNorm pass / GEMM epilogue): x2 itself may not exist
+            return x8
+        if x2 is None or x2.dtype != torch.float32 or not _x3_lin_ok(x2.shape[0], w) or x2.stride(1) != 1:
             return None
-        return x8 if x8 is not None else K.split3(x2, K.FORM_X)
+        return K.split3(x2, K.FORM_X)
     if not (fp8 and getattr(w, '_q8', None) is not None and _fp8_ok(x2, w._q8)):
         return None
     return x8 if x8 is not None else w._xsite.quantize(x2)
@@ -189,6 +197,8 @@ def dw_keep(x2, x8, w):
     nothing else, so fp8 mode holds 1 byte per element of them instead of 2 (+1).
     Mode X3 (x8 = the bf16 split copy): the weight-gradient product reads only that copy - the f32 tensor is not kept."""
     if _is_x3(x8):          # (an empty tensor of its own: a zero-row VIEW of x2 would keep x2's storage alive)
+        if x2 is None:
+            return x8.new_empty((0, x8.shape[1] // K.NS), dtype=torch.float32)
         return x2.new_empty((0, x2.shape[1])) if (x2.dtype == torch.float32 and _x3_lin_ok(x8.shape[0], w)) else x2
     if (fp8_dw and x8 is not None and x2.shape[0] >= 2048 and x2.shape[1] % 256 == 0 and w._q8.shape[0] % 256 == 0
             and x8.stride(0) % 16 == 0 and x8.data_ptr() % 16 == 0):
@@ -635,10 +645,14 @@ class ViTBlockFn(torch.autograd.Function):
         b, N, d = x.shape
         M = b * N
         # (fp8: the LayerNorm passes also write the e4m3 copy their consumer multiplies - no quantise pass over h1 / h2)
+        # (mode X3: h1 / h2 are read only as split copies - the LayerNorm pass writes the copy and no f32 tensor)
+        x3 = blk.fp8 == X3
         h1, mean1, rstd1, _, h1_8 = _ln_fwd(x, blk.ln_1.weight.data, blk.ln_1.bias.data, 1e-5,
-                                            site=_q8_site(blk.fp8, M, blk.attn.in_proj_weight, '_xsite'))
-        h1_8 = x8_of(blk.fp8, _rows(h1), blk.attn.in_proj_weight, h1_8)
-        qkv = lin_fwd(_rows(h1), blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8, x8=h1_8).view(b, N, 3 * d)
+                                            site=_q8_site(blk.fp8, M, blk.attn.in_proj_weight, '_xsite'),
+                                            x3_for=blk.attn.in_proj_weight if x3 else None, x3_only=True)
+        h1r = _rows(h1) if h1 is not None else None
+        h1_8 = x8_of(blk.fp8, h1r, blk.attn.in_proj_weight, h1_8)
+        qkv = lin_fwd(h1r, blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8, x8=h1_8).view(b, N, 3 * d)
         # (fp8: the attention kernel writes the e4m3 copy of o that out_proj multiplies, the backward the e5m2 copy of dqkv for in_proj)
         o_site = _q8_site(blk.fp8, M, blk.attn.out_proj.weight, '_xsite')
         if getattr(blk, 'causal', False):              # CLIP's text transformer (clip/model.py:286, 328-334): key j <= query i
@@ -651,13 +665,15 @@ class ViTBlockFn(torch.autograd.Function):
             o_8 = x8_of(blk.fp8, _rows(o), blk.attn.out_proj.weight)
         x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, x8=o_8, residual=_rows(x)).view(b, N, d)
         h2, mean2, rstd2, _, h2_8 = _ln_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5,
-                                            site=_q8_site(blk.fp8, M, blk.mlp.c_fc.weight, '_xsite'))
+                                            site=_q8_site(blk.fp8, M, blk.mlp.c_fc.weight, '_xsite'),
+                                            x3_for=blk.mlp.c_fc.weight if x3 else None, x3_only=True)
+        h2r = _rows(h2) if h2 is not None else None
         pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
-        h2_8 = x8_of(blk.fp8, _rows(h2), blk.mlp.c_fc.weight, h2_8)
+        h2_8 = x8_of(blk.fp8, h2r, blk.mlp.c_fc.weight, h2_8)
         # (fp8: the activation's e4m3 copy for c_proj comes out of c_fc's epilogue - no quantise pass over the 4d-wide tensor)
         # (.. and when c_proj's forward and weight-gradient products both read that copy, the bf16 activation is not written at all)
         act_8only = blk.fp8 and h2_8 is not None and fp8_only_ok(M, blk.mlp.c_proj.weight, False)
-        act, act8 = lin_fwd(_rows(h2), blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, x8=h2_8, epilogue=EPI_QUICKGELU, aux_out=pre,
+        act, act8 = lin_fwd(h2r, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, fp8=blk.fp8, x8=h2_8, epilogue=EPI_QUICKGELU, aux_out=pre,
                             c8_site=_site(blk.mlp.c_proj.weight, '_xsite'), want8=True, c8_only=act_8only, c3_consumer=blk.mlp.c_proj.weight)
         if act is None:
             act = pre[:0]                                   # (the tail rows dw_keep would keep: none)
@@ -667,8 +683,8 @@ class ViTBlockFn(torch.autograd.Function):
             x2 = lin_fwd(act, blk.mlp.c_proj.weight, blk.mlp.c_proj.bias, fp8=blk.fp8, x8=act8, residual=_rows(x1)).view(b, N, d)
         # fp8: the e4m3 copies the forward products multiplied are the weight-gradient products' X operands, and the bf16 h1 / h2 / act
         # are kept for nothing else (dw_keep)
-        ctx.save_for_backward(x, dw_keep(_rows(h1), h1_8, blk.attn.in_proj_weight), mean1, rstd1, qkv, o, lse, x1,
-                              dw_keep(_rows(h2), h2_8, blk.mlp.c_fc.weight), mean2, rstd2, pre,
+        ctx.save_for_backward(x, dw_keep(h1r, h1_8, blk.attn.in_proj_weight), mean1, rstd1, qkv, o, lse, x1,
+                              dw_keep(h2r, h2_8, blk.mlp.c_fc.weight), mean2, rstd2, pre,
                               act if act.shape[0] == 0 else dw_keep(act, act8, blk.mlp.c_proj.weight),
                               *((h1_8, o_8, h2_8, act8) if fp8_dw else (None,) * 4))
         ctx.blk = blk

@@ -1275,6 +1275,29 @@ def test_split3_writes_hi_lo_segments(K, rows, cols, ld, form):
         assert e <= 2e-5 * s_, (e, s_)
 
 
+@pytest.mark.parametrize('rows,d', [(577 * 3, 768), (300, 1024), (64, 256), (1000, 3072), (7, 64)])
+@pytest.mark.parametrize('form', [0, 1])
+@pytest.mark.parametrize('variant', ['plain', 'add_sum', 'drop'])
+def test_layernorm_pass_writes_the_split_copy_of_its_output(K, rows, d, form, variant):
+    """leccr_layernorm_fwd_s3 (f32 rows): the split copy that comes out of the pass is bit for bit leccr_split3 of the y the plain pass
+    writes - with the residual add / fused dropout variants too - and with write_y=False y is not written while the copy, the
+    statistics and the residual sum stay the same."""
+    x, add = _rand((rows, d), torch.float32, 31).to(DEV), _rand((rows, d), torch.float32, 32).to(DEV)
+    g, b = (1 + 0.1 * _rand((d,), torch.float32, 33)).to(DEV), _rand((d,), torch.float32, 34, 0.1).to(DEV)
+    kw = {'plain': {}, 'add_sum': dict(add=add, want_sum=True), 'drop': dict(add=add, want_sum=True, drop=(0.1, 1234))}[variant]
+    y0, m0, r0, s0 = K.layernorm_fwd(x, g, b, 1e-5, **kw)[:4]
+    y1, m1, r1, s1, y3 = K.layernorm_fwd(x, g, b, 1e-5, s3_form=form, **kw)
+    assert torch.equal(y1, y0) and torch.equal(m1, m0) and torch.equal(r1, r0)
+    assert (s0 is None and s1 is None) or torch.equal(s1, s0)
+    want = K.split3(y0, form)
+    assert y3.shape == want.shape and torch.equal(y3.view(torch.int16), want.view(torch.int16))
+    y2, m2, r2, s2, y3b = K.layernorm_fwd(x, g, b, 1e-5, s3_form=form, write_y=False, **kw)
+    assert y2 is None and torch.equal(m2, m0) and torch.equal(r2, r0) and torch.equal(y3b.view(torch.int16), want.view(torch.int16))
+    assert (s0 is None and s2 is None) or torch.equal(s2, s0)
+    with pytest.raises((RuntimeError, AssertionError)):          # bf16 rows have no split copy
+        K.layernorm_fwd(x.bfloat16(), g, b, 1e-5, s3_form=form)
+
+
 @pytest.mark.parametrize('M,N,K_', [(577 * 2, 768, 768), (1154, 2304, 768), (4096, 3072, 768), (2048, 768, 3072), (300, 260, 192), (64, 256, 128)])
 @pytest.mark.parametrize('case', ['plain', 'res', 'act', 'gelu', 'dact', 'dx'])
 def test_gemm_f32_operands_run_as_bf16_splits_on_the_matrix_cores(K, M, N, K_, case, monkeypatch):
