@@ -37,6 +37,9 @@ constexpr int OPT = 32768;                        // bytes of one operand K-tile
 constexpr int SLOT = 2 * OPT, NTH = 256;
 constexpr int LDS_BYTES = 2 * SLOT;               // 131072: no epilogue staging
 constexpr int F_ASUM = 1;
+#ifndef T4_SCHED
+#define T4_SCHED 0            // bit ks: k-step ks of the bf16 kernel issues its fragment reads and DMA pieces in one burst ahead of its 16 MFMAs
+#endif
 
 struct Args {
     const bf16_t* A;
@@ -260,11 +263,16 @@ __global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
             // k-step KS: 16 MFMAs on buffer KS & 1; fill(i) behind MFMA i
             auto kstep = [&](auto ks_tag, auto&& fill) {
                 constexpr int KS = decltype(ks_tag)::value, cb = KS & 1;
+                constexpr bool BURST = ((T4_SCHED >> KS) & 1) != 0;      // the k-step's reads / DMA issues in one burst ahead of its MFMAs
+                if constexpr (BURST) {
+                    static_for<0, 16>([&](auto ic) { fill(ic); });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, mi = i >> 2, ni = i & 3;
                     acc[mi * 4 + ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[cb][mi], fb[cb][ni], acc[mi * 4 + ni], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    fill(ic);
+                    if constexpr (!BURST) fill(ic);
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if constexpr ((FLAGS & F_ASUM) != 0) {
@@ -356,7 +364,13 @@ __global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
 //     a lane half holds is immaterial as long as A and B agree (here k = 64 ks + 32 h + 8 j + e for read j, element e).
 //   * LDS image: 256-byte rows; the 8 rows of a read would share banks (row stride = the bank window), so the 32-byte group index of a
 //     chunk is XORed with k & 7: physical 16-byte chunk = logical ^ ((k & 7) << 1).
-//   * no fused bias sums (they must come from the unquantised dY: leccr_gemm runs its column-sum pass over the bf16 tensor instead).
+//   * the bias gradient asum[m] += alpha / scale_A * sum_k A8[k, m] (round 4: the column sums of the e5m2 copy - the values the product itself
+//     multiplies - in place of a pass over the bf16 tensor) is summed on the VALU from the A fragments already in registers: an e5m2 byte is the
+//     high byte of an f16, so a fragment word gives two packed-f16 pairs (v_and / v_perm) and v_dot2_f32_f16 against (1, 1) adds each pair
+//     into an f32 - 32 instructions per fragment, two of the wave's four m-tiles per wave column, spread behind the k-step's MFMAs; the sums of a
+//     tile row are taken by the items of its first tile column over their whole K range (one K loop per case, chosen per item).  (On the matrix pipe - the fragment as the first operand of a 16 x 16 x 128 MFMA against a 0 / 1
+//     selector - the 4-register accumulators do not fit beside the product's 256: hipcc moves acc[0] out of the AGPRs and back around every
+//     k-step; as inline assembly on VGPR accumulators with one straight-line K-tile body per case it spilled 269 registers.)
 typedef __attribute__((ext_vector_type(8))) int v8i_t;
 
 template <int IMM>
@@ -369,6 +383,22 @@ __device__ __forceinline__ v8i_t lds_tr8_quad(uint32_t addr) {       // 4 x 8 ro
     return v8i_t{r0[0], r0[1], r1[0], r1[1], r2[0], r2[1], r3[0], r3[1]};
 }
 
+typedef _Float16 __attribute__((ext_vector_type(2))) half2_t;
+
+// acc += the 8 e5m2 values in words w0, w0 + 1 of a fragment: byte b as an f16 is b << 8
+__device__ __forceinline__ float colsum8_bf8(const v8i_t& f, int w0, float acc) {
+    const half2_t one2 = {(_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int w = w0; w < w0 + 2; ++w) {
+        const uint32_t x = (uint32_t)f[w];
+        const uint32_t odd = x & 0xFF00FF00u;                               // bytes 1, 3
+        const uint32_t even = __builtin_amdgcn_perm(0u, x, 0x020C000Cu);     // bytes 0, 2 moved up: (b2 << 24) | (b0 << 8)
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, odd), one2, acc, false);
+        acc = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, even), one2, acc, false);
+    }
+    return acc;
+}
+
 struct Args8 {
     const uint8_t* A;
     const uint8_t* B;
@@ -377,8 +407,12 @@ struct Args8 {
     float alpha;
     const float* alpha_dev[2];
     int tiles_m, tiles_n, splits, nkt, ktiles, n_items;
+    float* asum;
 };
 constexpr int BK8 = 128;
+#ifndef T4_FP8_SCHED
+#define T4_FP8_SCHED 1        // bit ks: k-step ks issues its fragment reads and DMA pieces in one burst ahead of its 16 MFMAs instead of between them
+#endif
 
 struct Cursor8 {
     int j, kt, nkt;
@@ -434,6 +468,7 @@ __host__ __device__ constexpr int piece8_at(int ks, int i) {
     return ks == 1 ? i / 2 : 8 + i / 2;
 }
 
+template <int FLAGS>
 __global__ __launch_bounds__(NTH) void gemm256t4_fp8_kernel(Args8 a) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -459,6 +494,7 @@ __global__ __launch_bounds__(NTH) void gemm256t4_fp8_kernel(Args8 a) {
     }
     if (n_mine == 0) return;
     if (a.alpha_dev[0]) a.alpha *= *a.alpha_dev[0];          // 1 / (scale_A scale_B), both kept on the device
+    [[maybe_unused]] const float alpha_cs = a.alpha;          // the A sums carry A's scale only
     if (a.alpha_dev[1]) a.alpha *= *a.alpha_dev[1];
 
     const uint32_t smem_off = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -507,6 +543,12 @@ __global__ __launch_bounds__(NTH) void gemm256t4_fp8_kernel(Args8 a) {
     static_for<0, 8>([&](auto ic) { constexpr int i = decltype(ic)::value; RD_FRAG8(0, 0u, 0, i); });
     WAIT_FRAGS8(0);
 
+    // bias gradient (F_ASUM): the second operand of the row-sum MFMA - lane 16 g + n is column n, k group g: column 0 = 1.0 (e2m1: 0x2) in
+    // the even groups, column 1 in the odd ones, everything else 0
+    // bias gradient (F_ASUM): cs[u] = this lane's share (its k half) of the sum of column 32 (2 wc + u) + r of the wave's A rows
+    [[maybe_unused]] float cs[2] = {0.f, 0.f};
+    [[maybe_unused]] const bool cs_on = (FLAGS & F_ASUM) != 0 && a.asum != nullptr;
+
     int t = 0;
     for (int j = 0; j < n_mine; ++j) {
         f32x16 acc[16];
@@ -514,36 +556,64 @@ __global__ __launch_bounds__(NTH) void gemm256t4_fp8_kernel(Args8 a) {
         for (int i = 0; i < 16; ++i)
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-        for (int kt = 0; kt < cur.nkt; ++kt, ++t) {
-            const uint32_t sc = (t & 1) * SLOT, sn = SLOT - sc;
-            asm volatile("" : "+v"(la[0]), "+v"(la[1]), "+v"(la[2]), "+v"(la[3]), "+v"(lb[0]), "+v"(lb[1]), "+v"(lb[2]), "+v"(lb[3]));
-            auto kstep = [&](auto ks_tag, auto&& fill) {
-                constexpr int cb = decltype(ks_tag)::value & 1;
-                static_for<0, 16>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value, mi = i >> 2, ni = i & 3;
-                    // first operand = dY^T rows (e5m2: format 1), second = X columns (e4m3: format 0); block scales 2^0
-                    acc[mi * 4 + ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[cb][mi], fb[cb][ni], acc[mi * 4 + ni], 1, 0, 0,
-                                                                                       0x7F7F7F7F, 0, 0x7F7F7F7F);
-                    __builtin_amdgcn_sched_barrier(0);
-                    fill(ic);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            };
+        if constexpr ((FLAGS & F_ASUM) != 0) { cs[0] = 0.f; cs[1] = 0.f; }
+        // The K loop exists once per sum mode (0: no sums, 1 / 2: m-tiles (0, 1) / (2, 3) of the A fragments), chosen per ITEM: a branch
+        // inside the loop body splits its basic block and hipcc then sinks all 32 MFMAs of a K-tile below the fragment reads (seen in the
+        // listing).  The sums of a tile row's A panel are taken by its first tile column's items over their whole K range: the VALU work
+        // rides under the MFMAs.
+        auto kloop = [&](auto cs_tag) __attribute__((always_inline)) {
+            constexpr int CS = decltype(cs_tag)::value;
+            for (int kt = 0; kt < cur.nkt; ++kt, ++t) {
+                const uint32_t sc = (t & 1) * SLOT, sn = SLOT - sc;
+                asm volatile("" : "+v"(la[0]), "+v"(la[1]), "+v"(la[2]), "+v"(la[3]), "+v"(lb[0]), "+v"(lb[1]), "+v"(lb[2]), "+v"(lb[3]));
+                // the prefetch position after this K-tile's first k-step (K-tile t+2) is worked out HERE: the branches of advance8() between
+                // the two k-steps ended the first one's basic block, and hipcc sank its 16 MFMAs below them - behind all of its fragment
+                // reads and DMA issues instead of between them (round 4, seen in the listing: the matrix pipe idled through that burst)
+                Cursor8 cN = cB;
+                advance8(a, first_item, stride, n_mine, cN);
+                auto kstep = [&](auto ks_tag, auto&& fill) {
+                    constexpr int cb = decltype(ks_tag)::value & 1;
+                    constexpr bool BURST = ((T4_FP8_SCHED >> decltype(ks_tag)::value) & 1) != 0;      // the k-step's reads / DMA issues ahead of its MFMAs
+                    if constexpr (BURST) {
+                        static_for<0, 16>([&](auto ic) { fill(ic); });
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    static_for<0, 16>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value, mi = i >> 2, ni = i & 3;
+                        // first operand = dY^T rows (e5m2: format 1), second = X columns (e4m3: format 0); block scales 2^0
+                        acc[mi * 4 + ni] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[cb][mi], fb[cb][ni], acc[mi * 4 + ni], 1, 0, 0,
+                                                                                           0x7F7F7F7F, 0, 0x7F7F7F7F);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (!BURST) fill(ic);
+                        // (the sums of the fragments in use: a share behind each of the k-step's last eight MFMAs)
+                        if constexpr (CS != 0 && i >= 8) cs[(i >> 2) & 1] = colsum8_bf8(fa[cb][2 * (CS - 1) + ((i >> 2) & 1)], 2 * (i & 3), cs[(i >> 2) & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                };
 #define FILL8T(KSP, buf, S, RKS, slot)                                                        \
     [&](auto ic) {                                                                            \
         constexpr int i = decltype(ic)::value;                                                \
         if constexpr (i < 8) RD_FRAG8(buf, S, RKS, i);                                        \
         if constexpr (piece8_at(KSP, i) >= 0) ISSUE8(piece8_at(KSP, i), slot);                \
     }
-            // k-step 0 (buffer 0): reads k-step 1 of this slot; the rest (pieces 8-15) of K-tile t+1  -> wait; vmcnt(0); BARRIER
-            kstep(std::integral_constant<int, 0>{}, FILL8T(0, 1, sc, 1, sn));
-            advance8(a, first_item, stride, n_mine, cB);          // cB -> K-tile t+2
-            WAIT_FRAGS8(1);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            SEG_BARRIER();
-            // k-step 1 (buffer 1): reads k-step 0 of K-tile t+1; pieces 0-7 of K-tile t+2 into the slot the barrier freed
-            kstep(std::integral_constant<int, 1>{}, FILL8T(1, 0, sn, 0, sc));
-            WAIT_FRAGS8(0);
+                // k-step 0 (buffer 0): reads k-step 1 of this slot; the rest (pieces 8-15) of K-tile t+1  -> wait; vmcnt(0); BARRIER
+                kstep(std::integral_constant<int, 0>{}, FILL8T(0, 1, sc, 1, sn));
+                cB = cN;                                              // cB -> K-tile t+2
+                WAIT_FRAGS8(1);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                SEG_BARRIER();
+                // k-step 1 (buffer 1): reads k-step 0 of K-tile t+1; pieces 0-7 of K-tile t+2 into the slot the barrier freed
+                kstep(std::integral_constant<int, 1>{}, FILL8T(1, 0, sn, 0, sc));
+                WAIT_FRAGS8(0);
+            }
+        };
+        [[maybe_unused]] const bool cs_item = cs_on && cur.n0 == 0;
+        if constexpr ((FLAGS & F_ASUM) != 0) {
+            if (!cs_item) kloop(std::integral_constant<int, 0>{});
+            else if (wc == 0) kloop(std::integral_constant<int, 1>{});
+            else kloop(std::integral_constant<int, 2>{});
+        } else {
+            kloop(std::integral_constant<int, 0>{});
         }
         {
             const int64_t m0 = cur.m0 + wr * 128, n0 = cur.n0 + wc * 128;
@@ -558,6 +628,17 @@ __global__ __launch_bounds__(NTH) void gemm256t4_fp8_kernel(Args8 a) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) atomicAdd(cp + (int64_t)((i & 3) + 8 * (i >> 2)) * a.ldc, acc[mi * 4 + ni][i] * a.alpha);
                 }
+            if constexpr ((FLAGS & F_ASUM) != 0) {
+                // cs[u]: sum over this lane's k half of column m = m0 + 32 (2 wc + u) + r: add the two halves, one atomic per column
+                if (cs_item) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(cs[u]), __float_as_uint(cs[u]), false, false);
+                        const float tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+                        if (h == 0) atomicAdd(a.asum + m0 + 32 * (2 * wc + u) + r, tot * alpha_cs);
+                    }
+                }
+            }
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -586,7 +667,7 @@ static void launch_inst(const Args& a, int grid, hipStream_t st) {
 // fp8 weight-gradient products: A = dY e5m2 [K, M], B = X e4m3 [K, N] (ab_dtype LECCR_FP8_BF8A, trans_a = trans_b = 1), f32 C in place
 bool gemm256t4_fp8_legal(const leccr_gemm_params& p) {
     if (p.trans_a != 1 || p.trans_b != 1 || p.ab_dtype != LECCR_FP8_BF8A || p.c_dtype != LECCR_F32 || !p.accumulate) return false;
-    if (p.epilogue != LECCR_EPI_NONE || p.residual || p.aux || p.aux_out || p.bias || p.colsum || p.asum || p.c8) return false;
+    if (p.epilogue != LECCR_EPI_NONE || p.residual || p.aux || p.aux_out || p.bias || p.colsum || p.c8) return false;
     if (p.M < 256 || p.N < 256 || (p.M & 255) || (p.N & 255) || (p.K & 127) || (p.lda & 15) || (p.ldb & 15)) return false;
     if ((((uintptr_t)p.A | (uintptr_t)p.B) & 15) || p.lda >= (1 << 23) || p.ldb >= (1 << 23)) return false;
     return p.K >= 2048;
@@ -597,7 +678,7 @@ int gemm256t4_fp8_launch(const leccr_gemm_params& p, int cap, hipStream_t st) {
     Args8 a{};
     a.A = (const uint8_t*)p.A; a.B = (const uint8_t*)p.B; a.C = (float*)p.C;
     a.M = p.M; a.N = p.N; a.K = p.K; a.lda = p.lda; a.ldb = p.ldb; a.ldc = p.ldc;
-    a.alpha = p.alpha; a.alpha_dev[0] = p.alpha_dev[0]; a.alpha_dev[1] = p.alpha_dev[1];
+    a.alpha = p.alpha; a.alpha_dev[0] = p.alpha_dev[0]; a.alpha_dev[1] = p.alpha_dev[1]; a.asum = p.asum;
     a.tiles_m = (int)cdiv(p.M, BM); a.tiles_n = (int)cdiv(p.N, BN);
     const int64_t ktiles = p.K / BK8;
     const int tiles = a.tiles_m * a.tiles_n;
@@ -612,10 +693,12 @@ int gemm256t4_fp8_launch(const leccr_gemm_params& p, int cap, hipStream_t st) {
     const int grid = a.n_items < cap ? a.n_items : cap;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256t4_fp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm256t4_fp8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm256t4_fp8_kernel<F_ASUM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm256t4_fp8_kernel, dim3(grid), dim3(NTH), LDS_BYTES, st, a);
+    if (a.asum) hipLaunchKernelGGL(gemm256t4_fp8_kernel<F_ASUM>, dim3(grid), dim3(NTH), LDS_BYTES, st, a);
+    else hipLaunchKernelGGL(gemm256t4_fp8_kernel<0>, dim3(grid), dim3(NTH), LDS_BYTES, st, a);
     return check_launch("gemm256t4 fp8");
 }
 

@@ -23,6 +23,7 @@
 //     padding: 8 KiB per wave) so that a lane stores 16 bytes of one row; bias / activation (+ saved pre-activation) /
 //     derivative-activation (reading it) / residual as in gemm256.hip.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace leccr {
@@ -39,6 +40,10 @@ constexpr int F_RES = 2, F_AUXOUT = 4;
 constexpr int F_FP8 = 32, F_BF8A = 64;
 // F_Q8: additionally write an fp8 copy of C for the product that consumes it (leccr_gemm_params.c8): saves that operand's quantise pass
 constexpr int F_Q8 = 128, F_Q8_BF8 = 256;       // F_Q8_BF8: the copy is e5m2 (a gradient), else e4m3
+// F_BURST1 (fp8): K1 issues its eight fragment reads and eight DMA pieces in one burst AHEAD of its 16 MFMAs instead of one behind each.
+// Measured per shape on one box (profiles/r04_fp8_kstep_schedules.txt): faster for the short reductions (K = 768 / 1024: fc1 972 -> 934 us,
+// out 257 -> 251, B/16 fc1 501 -> 483), slower for the long ones (K = 3072 / 4096: fc2 705 -> 729) - chosen by K at launch.
+constexpr int F_BURST1 = 512;
 
 struct Args {
     const bf16_t* A;
@@ -293,14 +298,24 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                 //   K0 (buffer 0): reads k-step 1 of this slot; the rest (pieces 8-15) of K-tile t+1  -> wait; vmcnt(0); BARRIER
                 //   K1 (buffer 1): reads k-step 0 of K-tile t+1; pieces 0-7 of K-tile t+2 into the slot the barrier freed
                 constexpr int AFMT = (FLAGS & F_BF8A) != 0 ? 1 : 0;      // format of the activation / gradient operand: 0 e4m3, 1 e5m2
+                // the prefetch position after K0 (K-tile t+2) is worked out HERE, ahead of the K-tile's MFMAs: the branches of advance()
+                // between K0 and K1 ended K0's basic block, and hipcc sank its 16 MFMAs below them - behind all of K0's fragment reads and
+                // DMA issues instead of between them (round 4, seen in the listing)
+                Cursor cN = cB;
+                advance(a, first_item, stride, n_mine, cN);
                 auto kstep8 = [&](auto ks_tag, auto&& fill) {
                     constexpr int cb = decltype(ks_tag)::value & 1;
+                    constexpr bool BURST = decltype(ks_tag)::value == 1 && (FLAGS & F_BURST1) != 0;      // the k-step's reads / DMA issues ahead of its MFMAs
+                    if constexpr (BURST) {
+                        static_for<0, 16>([&](auto ic) { fill(ic); });
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     static_for<0, 16>([&](auto ic) {
                         constexpr int i = decltype(ic)::value, ni = i >> 2, mi = i & 3;
                         acc[ni * 4 + mi] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xb[cb][ni], xa[cb][mi], acc[ni * 4 + mi], 0, AFMT, 0,
                                                                                            0x7F7F7F7F, 0, 0x7F7F7F7F);
                         __builtin_amdgcn_sched_barrier(0);
-                        fill(ic);
+                        if constexpr (!BURST) fill(ic);
                         __builtin_amdgcn_sched_barrier(0);
                     });
                 };
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
         if constexpr (piece_at(KSP, i) >= 0) ISSUE_PN(piece_at(KSP, i), slot);                \
     }
                 kstep8(std::integral_constant<int, 0>{}, FILL8(0, 1, sc, 1, sn));
-                advance(a, first_item, stride, n_mine, cB);           // cB -> K-tile t+2
+                cB = cN;                                              // cB -> K-tile t+2
                 WAIT_FRAGS8(1);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of K-tile t+1 have landed
                 SEG_BARRIER();                                        // slot sc is free, slot sn is complete
@@ -591,6 +606,14 @@ bool gemm256w4_legal(const leccr_gemm_params& p) {
     return false;
 }
 
+namespace g4 {
+template <int EPI, int FLAGS>
+static void launch_fp8(const Args& a, int grid, hipStream_t st, bool burst1) {
+    if (burst1) launch_inst<EPI, FLAGS | F_BURST1>(a, grid, st);
+    else launch_inst<EPI, FLAGS>(a, grid, st);
+}
+}  // namespace g4
+
 int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st) {
     using namespace g4;
     Args a{};
@@ -605,27 +628,29 @@ int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st) {
     const int f = w4_flags(p);
     a.alpha_dev[0] = p.alpha_dev[0]; a.alpha_dev[1] = p.alpha_dev[1];
     if (p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A) {
+        static const int burst_env = [] { const char* e = getenv("LECCR_FP8_BURST1"); return e ? atoi(e) : -1; }();      // 0 never, 1 always
+        const bool b1 = burst_env < 0 ? p.K <= 1536 : burst_env != 0;          // F_BURST1: the short reductions
         // the bf16 problem with half the columns: byte-identical staging (see F_FP8)
         a.K = p.K / 2; a.lda = p.lda / 2; a.ldb = p.ldb / 2;
         a.nkt = (int)(a.K / BK);
         a.c8 = (uint8_t*)p.c8; a.ldc8 = p.ldc8; a.c8_site = p.c8_site; a.colsum = p.colsum;
         if (p.c8) {     // the C written is also the next product's fp8 operand: activation output (e4m3) / its gradient (e5m2)
-            if (p.ab_dtype == LECCR_FP8 && p.epilogue == LECCR_EPI_QUICKGELU) launch_inst<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st);
-            else if (p.ab_dtype == LECCR_FP8) launch_inst<LECCR_EPI_GELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st);
-            else if (p.epilogue == LECCR_EPI_DQUICKGELU) launch_inst<LECCR_EPI_DQUICKGELU, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st);
-            else launch_inst<LECCR_EPI_DGELU, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st);
+            if (p.ab_dtype == LECCR_FP8 && p.epilogue == LECCR_EPI_QUICKGELU) launch_fp8<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st, b1);
+            else if (p.ab_dtype == LECCR_FP8) launch_fp8<LECCR_EPI_GELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_DQUICKGELU) launch_fp8<LECCR_EPI_DQUICKGELU, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st, b1);
+            else launch_fp8<LECCR_EPI_DGELU, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st, b1);
             return check_launch("gemm256w4 fp8 q8");
         }
         if (p.ab_dtype == LECCR_FP8) {
-            if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_inst<LECCR_EPI_NONE, F_RES | F_FP8>(a, grid, st);
-            else if (p.epilogue == LECCR_EPI_NONE) launch_inst<LECCR_EPI_NONE, F_FP8>(a, grid, st);
-            else if (p.epilogue == LECCR_EPI_QUICKGELU) launch_inst<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8>(a, grid, st);
-            else launch_inst<LECCR_EPI_GELU, F_AUXOUT | F_FP8>(a, grid, st);
+            if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_fp8<LECCR_EPI_NONE, F_RES | F_FP8>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_NONE) launch_fp8<LECCR_EPI_NONE, F_FP8>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_QUICKGELU) launch_fp8<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8>(a, grid, st, b1);
+            else launch_fp8<LECCR_EPI_GELU, F_AUXOUT | F_FP8>(a, grid, st, b1);
         } else {
-            if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_inst<LECCR_EPI_NONE, F_RES | F_FP8 | F_BF8A>(a, grid, st);
-            else if (p.epilogue == LECCR_EPI_NONE) launch_inst<LECCR_EPI_NONE, F_FP8 | F_BF8A>(a, grid, st);
-            else if (p.epilogue == LECCR_EPI_DQUICKGELU) launch_inst<LECCR_EPI_DQUICKGELU, F_FP8 | F_BF8A>(a, grid, st);
-            else launch_inst<LECCR_EPI_DGELU, F_FP8 | F_BF8A>(a, grid, st);
+            if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_fp8<LECCR_EPI_NONE, F_RES | F_FP8 | F_BF8A>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_NONE) launch_fp8<LECCR_EPI_NONE, F_FP8 | F_BF8A>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_DQUICKGELU) launch_fp8<LECCR_EPI_DQUICKGELU, F_FP8 | F_BF8A>(a, grid, st, b1);
+            else launch_fp8<LECCR_EPI_DGELU, F_FP8 | F_BF8A>(a, grid, st, b1);
         }
         return check_launch("gemm256w4 fp8");
     }

@@ -133,6 +133,7 @@ def _fp8_ok(x2, w8):
 # forward, e5m2 dY of the dX product) on leccr_gemm's LECCR_FP8_BF8A trans_a = trans_b = 1 form.  LECCR_FP8_DW=0: bf16 dW as in round 2.
 fp8_dw = os.environ.get('LECCR_FP8_DW', '1') != '0'
 fp8_dw_launches = 0          # fp8 weight-gradient products launched (tests read it)
+fp8_bias_asum = os.environ.get('LECCR_FP8_BIAS_ASUM', '1') != '0'      # bias gradients summed inside those launches (from the e5m2 copy)
 
 
 # fp32 mode (compute_dtype 'fp32' with kernels.f32_mfma): the encoder blocks carry mode X3 in their `fp8` attribute and the SAME
@@ -482,14 +483,17 @@ def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None, bias_done=Fals
         # fp8 operands: whole 128-row K-tiles on the scaled-MFMA kernel, the (< 128-row) tail and the bias sums from the bf16 tensors
         global fp8_dw_launches
         fp8_dw_launches += 1
+        # (round 4: the bias gradient rides in the same launches - the column sums of the e5m2 copy, the values the weight gradient itself
+        #  is built from, in place of a pass over the bf16 tensor; LECCR_FP8_BIAS_ASUM=0: that pass again)
         rows = g8.shape[0] // 128 * 128
+        fused = fused and fp8_bias_asum
+        bsum = b._g.reshape(-1) if fused else None
         K.gemm(g8[:rows], x8[:rows], trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale,
-               alpha_dev=(w._gsite.inv_scale, w._xsite.inv_scale))
+               alpha_dev=(w._gsite.inv_scale, w._xsite.inv_scale), asum=bsum)
         if rows < g8.shape[0]:
             xt = x2[rows:] if x2.shape[0] == g8.shape[0] else x2          # full tensor, or the tail rows dw_keep kept
             assert xt.shape[0] == g8.shape[0] - rows
-            K.gemm(dy2[rows:], xt, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale)
-        fused = False
+            K.gemm(dy2[rows:], xt, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale, asum=bsum)
     else:
         K.gemm(dy2, x2, trans_a=True, trans_b=True, out=w._g, accumulate=True, alpha=scale,
                asum=b._g.reshape(-1) if fused else None)

@@ -1191,6 +1191,22 @@ def test_gemm_fp8_weight_gradient_operands(K, Kt, M, N, alpha):
     full = alpha * (dy.double().cpu().t() @ x.double().cpu())
     got = (out.double().cpu() - base.double()) / 2
     assert float((got - full).norm() / full.norm()) < 0.12
+    # asum (round 4): the bias gradient in the same launch - alpha / scale_A x the column sums of the e5m2 copy, accumulated into the
+    # vector; the product beside it is unchanged
+    bias0 = _rand((M,), torch.float32, 543, 1e-2)
+    bsum = bias0.clone().to(DEV)
+    out2 = base.clone().to(DEV)
+    K.gemm(g8, x8, trans_a=True, trans_b=True, out=out2, accumulate=True, alpha=alpha, alpha_dev=(sg.inv_scale, sx.inv_scale), asum=bsum)
+    assert _lib.lib().leccr_last_gemm_kernel() == 6
+    e, s = _err(out2, ref)
+    assert e <= 2e-5 * s + 1e-7, (e, s)
+    want = bias0.double() + alpha * gd.sum(0)
+    e = float((bsum.double().cpu() - want).abs().max())
+    assert e <= 2e-6 * float(gd.abs().sum(0).max()) * alpha + 1e-7, (e, float(gd.abs().sum(0).max()))
+    # .. and it is the bf16 tensor's column sum up to the e5m2 rounding noise (unbiased: ~ 2^-3 / sqrt(3) per element, averaged over K)
+    true = alpha * dy.double().cpu().sum(0)
+    noise = alpha * float(dy.double().cpu().pow(2).sum(0).sqrt().max())
+    assert float((bsum.double().cpu() - bias0.double() - true).abs().max()) <= 0.5 * noise
 
 
 @pytest.mark.parametrize('grad', [False, True])
