@@ -116,7 +116,9 @@ typedef struct leccr_gemm_params {
                                     the stored [K,M] matrix over the reduction index.  When the product is a weight gradient
                                     dW = dY^T X this is the bias gradient colsum(dY) (autograd of F.linear's bias: clip/model.py:
                                     175-191, HF BERT dense layers); the 256x256 kernel computes it on the matrix cores beside
-                                    the product (an all-ones B fragment), other paths run leccr_colsum over A */
+                                    the product (an all-ones B fragment), other paths run leccr_colsum over A.  With fp8 operands
+                                    (LECCR_FP8_BF8A, trans_a = trans_b = 1): alpha * alpha_dev[0] * the column sums of the e5m2
+                                    bytes - the bias gradient built from the same quantised dY as the weight gradient beside it */
     const float* alpha_dev[2];   /* optional device scalars multiplied into alpha when the kernel starts (fp8 operands: the two
                                     inverse quantisation scales live on the device, leccr_fp8_* below; no host read) */
     void* c8;                    /* optional fp8 copy of the C written, for the NEXT product that consumes it (fp8 operand kernels
