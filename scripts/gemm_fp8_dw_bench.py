@@ -8,6 +8,7 @@ from leccr_amd import kernels as K, _lib
 dev = 'cuda'
 ROWS = 256 * 257
 SH = [('dW qkv', 3072, 1024, ROWS), ('dW out', 1024, 1024, ROWS), ('dW fc1', 4096, 1024, ROWS), ('dW fc2', 1024, 4096, ROWS),
+      ('E dW qkv', 3072, 1024, 186880), ('E dW out', 1024, 1024, 186880), ('E dW fc1', 4096, 1024, 186880), ('E dW fc2', 1024, 4096, 186880),
       ('xlmr dW fc1', 4096, 1024, 16384), ('xlmr dW out', 1024, 1024, 16384), ('B16 dW fc1', 3072, 768, 256 * 577)]
 reps = int(os.environ.get('REPS', 5))
 sites = K.Fp8Sites(dev, 4)
@@ -18,8 +19,11 @@ for name, m, n, k in SH:
     g8, x8 = sg.quantize(dy), sx.quantize(x)
     out = torch.zeros(m, n, device=dev)
     res = []
+    bsum = torch.zeros(m, device=dev)
     for f in (lambda: K.gemm(dy, x, trans_a=True, trans_b=True, out=out, accumulate=True),
-              lambda: K.gemm(g8, x8, trans_a=True, trans_b=True, out=out, accumulate=True, alpha_dev=(sg.inv_scale, sx.inv_scale))):
+              lambda: K.gemm(g8, x8, trans_a=True, trans_b=True, out=out, accumulate=True, alpha_dev=(sg.inv_scale, sx.inv_scale)),
+              lambda: K.gemm(g8, x8, trans_a=True, trans_b=True, out=out, accumulate=True, alpha_dev=(sg.inv_scale, sx.inv_scale), asum=bsum),
+              lambda: K.colsum(dy, bsum)):
         for _ in range(2): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,4 +34,5 @@ for name, m, n, k in SH:
         res.append((ms, _lib.lib().leccr_last_gemm_kernel()))
     fl = 2 * m * n * k
     print(f'{name:12s} M={m:5d} N={n:5d} K={k:6d}  bf16 (kernel {res[0][1]}) {res[0][0]*1e3:8.1f} us {fl/res[0][0]/1e9:7.1f} TF/s   '
-          f'fp8 (kernel {res[1][1]}) {res[1][0]*1e3:8.1f} us {fl/res[1][0]/1e9:7.1f} TF/s   x{res[0][0]/res[1][0]:.2f}', flush=True)
+          f'fp8 (kernel {res[1][1]}) {res[1][0]*1e3:8.1f} us {fl/res[1][0]/1e9:7.1f} TF/s   x{res[0][0]/res[1][0]:.2f}   '
+          f'fp8 + bias sums {res[2][0]*1e3:8.1f} us   (bf16 colsum pass alone {res[3][0]*1e3:6.1f} us)', flush=True)
