@@ -27,6 +27,9 @@
 #include <type_traits>
 
 namespace leccr {
+#ifndef W4_SCHED
+#define W4_SCHED 0            // bit ks: bf16 k-step ks issues its fragment reads and DMA pieces in one burst ahead of its 16 MFMAs (experiment: see profiles/r04_fp8_kstep_schedules.txt)
+#endif
 namespace g4 {
 
 constexpr int BM = 256, BN = 256, BK = 64;
@@ -344,11 +347,16 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             // k-step KS: 16 MFMAs on buffer KS & 1; fill(i) after MFMA i
             auto kstep = [&](auto ks_tag, auto&& fill) {
                 constexpr int KS = decltype(ks_tag)::value, cb = KS & 1;
+                constexpr bool BURST = ((W4_SCHED >> KS) & 1) != 0;      // (experiment) the k-step's reads / DMA issues in one burst ahead of its MFMAs
+                if constexpr (BURST) {
+                    static_for<0, 16>([&](auto ic) { fill(ic); });
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 static_for<0, 16>([&](auto ic) {
                     constexpr int i = decltype(ic)::value, ni = i >> 2, mi = i & 3;
                     acc[ni * 4 + mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cb][ni], fa[cb][mi], acc[ni * 4 + mi], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    fill(ic);
+                    if constexpr (!BURST) fill(ic);
                     __builtin_amdgcn_sched_barrier(0);
                 });
             };
