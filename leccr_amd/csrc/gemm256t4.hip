@@ -37,8 +37,8 @@ constexpr int OPT = 32768;                        // bytes of one operand K-tile
 constexpr int SLOT = 2 * OPT, NTH = 256;
 constexpr int LDS_BYTES = 2 * SLOT;               // 131072: no epilogue staging
 constexpr int F_ASUM = 1;
-#ifndef T4_SCHED
-#define T4_SCHED 0            // bit ks: k-step ks of the bf16 kernel issues its fragment reads and DMA pieces in one burst ahead of its 16 MFMAs
+#ifndef T4_BURST
+#define T4_BURST 0            // (experiment) bit ks: k-step ks of the bf16 kernel issues its fragment reads and DMA pieces in one burst ahead of its 16 MFMAs
 #endif
 
 struct Args {
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
             // k-step KS: 16 MFMAs on buffer KS & 1; fill(i) behind MFMA i
             auto kstep = [&](auto ks_tag, auto&& fill) {
                 constexpr int KS = decltype(ks_tag)::value, cb = KS & 1;
-                constexpr bool BURST = ((T4_SCHED >> KS) & 1) != 0;      // the k-step's reads / DMA issues in one burst ahead of its MFMAs
+                constexpr bool BURST = ((T4_BURST >> KS) & 1) != 0;      // the k-step's reads / DMA issues in one burst ahead of its MFMAs
                 if constexpr (BURST) {
                     static_for<0, 16>([&](auto ic) { fill(ic); });
                     __builtin_amdgcn_sched_barrier(0);

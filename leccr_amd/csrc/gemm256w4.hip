@@ -27,8 +27,8 @@
 #include <type_traits>
 
 namespace leccr {
-#ifndef W4_SCHED
-#define W4_SCHED 0            // bit ks: bf16 k-step ks issues its fragment reads and DMA pieces in one burst ahead of its 16 MFMAs (experiment: see profiles/r04_fp8_kstep_schedules.txt)
+#ifndef W4_BURST
+#define W4_BURST 0            // bit ks: bf16 k-step ks issues its fragment reads and DMA pieces in one burst ahead of its 16 MFMAs (experiment: see profiles/r04_fp8_kstep_schedules.txt)
 #endif
 namespace g4 {
 
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
             // k-step KS: 16 MFMAs on buffer KS & 1; fill(i) after MFMA i
             auto kstep = [&](auto ks_tag, auto&& fill) {
                 constexpr int KS = decltype(ks_tag)::value, cb = KS & 1;
-                constexpr bool BURST = ((W4_SCHED >> KS) & 1) != 0;      // (experiment) the k-step's reads / DMA issues in one burst ahead of its MFMAs
+                constexpr bool BURST = ((W4_BURST >> KS) & 1) != 0;      // (experiment) the k-step's reads / DMA issues in one burst ahead of its MFMAs
                 if constexpr (BURST) {
                     static_for<0, 16>([&](auto ic) { fill(ic); });
                     __builtin_amdgcn_sched_barrier(0);
