@@ -71,3 +71,18 @@ def test_no_cpu_fallback():
             if f.endswith('.py'):
                 src += open(os.path.join(dirpath, f)).read()
     assert 'import oracle' not in src and 'from oracle' not in src      # the checker never ships in the product
+
+
+def test_kernel_sources_define_each_switch_once():
+    """Every compile-time switch of a kernel source (`#ifndef X / #define X default`) is defined once per file: a second block with the same
+    name further up silently replaces the default (round 4: an experiment's macro shadowed gemm256t4.hip's DMA-piece placement switch and cost
+    the bf16 weight-gradient kernel 10 % until an opcode diff found it)."""
+    import collections, glob, os, re
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'leccr_amd', 'csrc')
+    bad = {}
+    for f in sorted(glob.glob(os.path.join(src, '*.hip')) + glob.glob(os.path.join(src, '*.h'))):
+        names = collections.Counter(re.findall(r'^\s*#\s*ifndef\s+(\w+)\s*\n\s*#\s*define\s+\1\b', open(f).read(), re.M))
+        dup = sorted(n for n, c in names.items() if c > 1)
+        if dup:
+            bad[os.path.basename(f)] = dup
+    assert not bad, bad
