@@ -362,7 +362,8 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_d
     dy_bias: the tensor whose column sums are the bias gradient when it is not dy2 itself (an f32 head's incoming gradient,
     of which dy2 is the bf16 GEMM operand: the bias sum cancels heavily and is taken from the unrounded values).
     g8, x8 (fp8 mode): the e5m2 copy of dy2 and the e4m3 copy of x2 under w's gradient / activation sites - the product then runs on
-    the fp8 weight-gradient kernel (the bias sums still come from the bf16 dy2); x2 may then hold only the tail rows (dw_keep).
+    the fp8 weight-gradient kernel, the bias sums inside the same launch from the e5m2 copy (fp8_bias_asum; else a pass over the bf16 dy2);
+    x2 may then hold only the tail rows (dw_keep).
     dy2 None (fp8_only_ok): only the fp8 copy of the gradient exists - no tail rows, and the bias gradient was summed by the
     producing GEMM's epilogue (bias_done)."""
     global _wgrad_stream, _wgrad_join_queued, _wgrad_throttle
