@@ -1160,7 +1160,7 @@ def test_gemm_fp8_rejects_what_it_does_not_implement(K):
 
 
 @pytest.mark.parametrize('Kt,M,N,alpha', [(4096, 256, 256, 1.0), (128 * 77, 768, 1024, 1.0), (65792, 1024, 1024, 0.5), (16384, 4096, 1024, 1.0),
-                                          (128 * 129, 1024, 3072, 1.0), (2048, 512, 256, 2.0)])
+                                          (128 * 129, 1024, 3072, 1.0), (2048, 512, 256, 2.0), (2048, 4096, 8192, 1.0)])
 def test_gemm_fp8_weight_gradient_operands(K, Kt, M, N, alpha):
     """ab_dtype LECCR_FP8_BF8A with trans_a = trans_b = 1 (gemm256t4.hip, round 3): dW += alpha dY^T X from the e5m2 copy of dY [K, M]
     and the e4m3 copy of X [K, N] - the row-major copies the dX and forward products of the same Linear already use - read through
