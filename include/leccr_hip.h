@@ -265,6 +265,23 @@ int leccr_attn_bwd_q8(const void* q, const void* k, const void* v, const void* o
                       int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                       int dtype, float drop_p, uint64_t seed, void* dq8, void* dk8, void* dv8, int64_t ld8, float* site, void* stream);
 
+/* fp32 attention that writes the OPERAND COPIES of its outputs (round 4; leccr_amd/csrc/attention.hip, attention_x3.hip).  In the fp32 path
+ * (operands as bf16 hi / lo pairs, leccr_split3) o is read only as the X-form copy of out_proj's products and dq / dk / dv only as the G-form
+ * copy of in_proj's (clip/model.py:185-192: nn.MultiheadAttention, its output projection and packed in-projection); the pair-form kernels
+ * write those copies - [rows, 3 seg3] bf16, bit for bit leccr_split3 of the f32 tensor - and the f32 tensors are never written.
+ * leccr_attn_s3_takes: 1 when the problem runs on those kernels (f32, head size 64, no causal mask, row strides % 4 == 0, copy strides
+ * % 8 == 0, LECCR_ATTN_F32 != exact); otherwise use leccr_attn_fwd / _bwd and leccr_split3.
+ * Every copy pointer is at its tensor's column 0 inside segment 0; o3 (forward) is form 0 (hi | hi | lo), dq3 / dk3 / dv3 form 1 (hi | lo | hi). */
+int leccr_attn_s3_takes(int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv,
+                        int64_t ld3, int64_t seg3);
+int leccr_attn_fwd_s3(const void* q, const void* k, const void* v, void* o3, float* lse, const uint8_t* kmask,
+                      int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv,
+                      int64_t ld3, int64_t seg3, float drop_p, uint64_t seed, void* stream);
+int leccr_attn_bwd_s3(const void* q, const void* k, const void* v, const void* o3, int64_t ldo3, int64_t sego3, const void* dout,
+                      const float* lse, const uint8_t* kmask, void* dq3, void* dk3, void* dv3, float* delta,
+                      int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                      int64_t ld3, int64_t seg3, float drop_p, uint64_t seed, void* stream);
+
 /* ---- ViT input stage --------------------------------------------------------------------------------------
  * patchify: image [b,3,R,R] f32 NCHW -> patches [b*g*g, Kp] (T), g = floor(R/p) (the R % p edge pixels are dropped, as
  *   by the stride-p convolution: ViT-L/14 at 384), column order (c, py, px) = the

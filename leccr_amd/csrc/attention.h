@@ -50,9 +50,21 @@ int attn_f32_bwd(const void* q, const void* k, const void* v, const void* o, con
 
 // .. and the same problems with every operand as a bf16 (hi, lo) pair on v_mfma_f32_32x32x16_bf16 (attention_x3.hip): the default for f32
 bool attn_x3_wanted();
-int attn_x3_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const AttnDims& D, hipStream_t st);
+// operand copies written / read by the fp32 pair-form kernels themselves (attention_x3.hip: struct S3): every pointer at column 0 of its tensor
+// inside segment 0 of a [rows, 3 seg] bf16 copy (leccr_split3's layout); null = the f32 tensor
+struct AttnS3 {
+    void* o3 = nullptr;             // forward: the X-form (hi | hi | lo) copy of o
+    const void* o3_in = nullptr;    // backward: that copy in place of o
+    void* dq3 = nullptr;            // backward: G-form (hi | lo | hi) copies
+    void* dk3 = nullptr;
+    void* dv3 = nullptr;
+    int64_t ld3 = 0, seg = 0;       // layout of the output copies (o3 / dq3 / dk3 / dv3)
+    int64_t ldo3 = 0, sego3 = 0;    // layout of o3_in
+};
+int attn_x3_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const AttnDims& D, hipStream_t st,
+                const AttnS3* s3 = nullptr);
 int attn_x3_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const uint8_t* kmask,
-                void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st);
+                void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st, const AttnS3* s3 = nullptr);
 
 extern bool g_force_generic_attn;
 int attn_set_variant(int v);      // 0 = default (environment), 16 / 32 = queries per wave of the MFMA forward kernel; returns the one in effect

@@ -150,6 +150,65 @@ extern "C" int leccr_attn_bwd(const void* q, const void* k, const void* v, const
                          stream, nullptr, nullptr);
 }
 
+// ---- fp32 attention with the operand copies of its outputs (round 4).  In the fp32 path (operands as bf16 hi / lo pairs) o is read only as
+// the X-form copy of out_proj's products and dq / dk / dv only as the G-form copy of in_proj's: the pair-form kernels (attention_x3.hip) write
+// those copies - [rows, 3 seg] bf16 in leccr_split3's layout, bit for bit what leccr_split3 makes of the f32 tensor - from their registers, and
+// the f32 tensors are not written.  leccr_attn_s3_takes says whether a problem runs on those kernels (f32, head size 64, no causal mask, row
+// strides % 4 == 0, LECCR_ATTN_F32 != exact): callers fall back to leccr_attn_fwd / _bwd + leccr_split3 otherwise.
+extern "C" int leccr_attn_s3_takes(int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv,
+                                   int64_t ld3, int64_t seg3) {
+    AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldq, make_drop(0.f, 0), false};
+    if (b < 0 || heads <= 0 || Lq < 0 || Lk <= 0 || ldq < heads * hd || ldk < heads * hd || ldv < heads * hd) return 0;
+    if (seg3 < heads * hd || ld3 < 3 * seg3 || ((ld3 | seg3) & 7)) return 0;          // 16-byte rows and segments (the delta read takes 8 bf16 at a time)
+    return !g_force_generic_attn && attn_f32_supported(D, LECCR_F32, nullptr, 0) && attn_x3_wanted() ? 1 : 0;
+}
+
+// o3: the X-form (hi | hi | lo) copy of o, pointer at o's column 0 inside segment 0, row stride ld3, segment width seg3; o itself is not written
+extern "C" int leccr_attn_fwd_s3(const void* q, const void* k, const void* v, void* o3, float* lse, const uint8_t* kmask,
+                                 int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv,
+                                 int64_t ld3, int64_t seg3, float drop_p, uint64_t seed, void* stream) {
+    LECCR_REQUIRE(q && k && v && o3 && lse, LECCR_EINVAL, "attn_fwd_s3: null pointer");
+    LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_fwd_s3: drop_p must be in [0,1)");
+    LECCR_REQUIRE(b * heads * Lq * Lk < (1ll << 32) || drop_p == 0.f, LECCR_EINVAL, "attn_fwd_s3: dropout index space exceeds 2^32");
+    AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldq, make_drop(drop_p, seed), drop_p > 0.f};
+    const void* ptrs[4] = {q, k, v, o3};
+    LECCR_REQUIRE(leccr_attn_s3_takes(b, heads, Lq, Lk, hd, ldq, ldk, ldv, ld3, seg3) && attn_f32_supported(D, LECCR_F32, ptrs, 4), LECCR_EINVAL,
+                  "attn_fwd_s3: not a problem of the fp32 pair-form kernels (leccr_attn_s3_takes), or a pointer not 16-byte aligned");
+    if (b == 0 || Lq == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PROF_ATTN_FWD, 4.0 * (double)b * heads * Lq * Lk * hd, st);
+    AttnS3 s3;
+    s3.o3 = o3; s3.ld3 = ld3; s3.seg = seg3;
+    g_last_attn_kernel = 5;
+    return attn_x3_fwd(q, k, v, nullptr, lse, kmask, D, st, &s3);
+}
+
+// o3: the copy leccr_attn_fwd_s3 wrote (read back as hi + lo for delta = dO . O); dq3 / dk3 / dv3: the G-form (hi | lo | hi) copies of the three
+// gradients, each pointer at its tensor's column 0 inside segment 0 of a copy with row stride ld3 and segment width seg3 (one packed
+// [rows, 3 x 3 d] copy of dqkv: dq3 = base, dk3 = base + d, dv3 = base + 2 d, seg3 = 3 d); dout has row stride ldo
+extern "C" int leccr_attn_bwd_s3(const void* q, const void* k, const void* v, const void* o3, int64_t ldo3, int64_t sego3, const void* dout,
+                                 const float* lse, const uint8_t* kmask, void* dq3, void* dk3, void* dv3, float* delta,
+                                 int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                                 int64_t ld3, int64_t seg3, float drop_p, uint64_t seed, void* stream) {
+    LECCR_REQUIRE(q && k && v && o3 && dout && lse && dq3 && dk3 && dv3 && delta, LECCR_EINVAL, "attn_bwd_s3: null pointer");
+    LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_bwd_s3: drop_p must be in [0,1)");
+    LECCR_REQUIRE(sego3 >= heads * hd && ldo3 >= 3 * sego3 && ((ldo3 | sego3) & 7) == 0, LECCR_EINVAL,
+                  "attn_bwd_s3: the o copy needs sego3 >= heads * hd, ldo3 >= 3 sego3, both multiples of 8");
+    AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
+    const void* ptrs[8] = {q, k, v, o3, dout, dq3, dk3, dv3};
+    LECCR_REQUIRE(leccr_attn_s3_takes(b, heads, Lq, Lk, hd, ldq, ldk, ldv, ld3, seg3) && ldo >= heads * hd && attn_f32_supported(D, LECCR_F32, ptrs, 8),
+                  LECCR_EINVAL, "attn_bwd_s3: not a problem of the fp32 pair-form kernels (leccr_attn_s3_takes), or a pointer not 16-byte aligned");
+    if (b == 0 || Lq == 0) return LECCR_OK;
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PROF_ATTN_BWD, 10.0 * (double)b * heads * Lq * Lk * hd, st);
+    // (the o copy may have its own layout; the kernels take one (ld3, seg) pair for the outputs and read the o copy with ldo3 / sego3 -
+    //  passed through the same struct by pointing o3_in at the copy and keeping its strides beside it)
+    AttnS3 s3;
+    s3.o3_in = o3; s3.dq3 = dq3; s3.dk3 = dk3; s3.dv3 = dv3; s3.ld3 = ld3; s3.seg = seg3; s3.ldo3 = ldo3; s3.sego3 = sego3;
+    g_last_attn_kernel = 5;
+    return attn_x3_bwd(q, k, v, nullptr, dout, lse, kmask, nullptr, nullptr, nullptr, delta, D, st, &s3);
+}
+
 // .. and the e5m2 copies of dq / dk / dv (row stride ld8: the three column blocks of one packed [rows, 3 d] gradient, or separate
 // tensors) under ONE site, for the in_proj dX and weight-gradient products in fp8 mode
 extern "C" int leccr_attn_bwd_q8(const void* q, const void* k, const void* v, const void* o, const void* dout,

@@ -129,6 +129,39 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16_t* plane, int lane, int c, 
 
 __device__ __forceinline__ int slot_row(int half, int r) { return 8 * (r >> 2) + 4 * half + (r & 3); }
 
+// Operand copies written / read by the kernels themselves (round 4; leccr_attn_fwd_s3 / leccr_attn_bwd_s3).  The fp32 path's Linears read their
+// f32 operands as bf16 (hi, lo) copies in leccr_split3's layout - [rows, 3 seg], hi | hi | lo (form 0, activations) or hi | lo | hi (form 1,
+// gradients) - and o / dq / dk / dv are read by nothing else: the epilogues below write those copies from their registers (bit for bit what
+// leccr_split3 makes of the f32 tensor) and the f32 tensors are not written; the dQ kernel's delta = dO . O reads O back as hi + lo.
+// Every pointer is at column 0 of the tensor inside segment 0; a null pointer = the f32 tensor as before.
+struct S3 {
+    bf16_t* o3;            // forward: X-form copy of o
+    const bf16_t* o3_in;   // backward: that copy, in place of o
+    bf16_t* dq3;           // backward: G-form copies
+    bf16_t* dk3;
+    bf16_t* dv3;
+    int64_t ld3, seg;      // row stride and segment width of the output copies (elements)
+    int64_t ldo3, sego3;   // .. and of o3_in
+};
+
+template <int FORM>
+__device__ __forceinline__ void store_split4(bf16_t* __restrict__ p, int64_t seg, const f32x4& v) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        // the split of the ROUNDED f32 value, as leccr_split3 would read it from memory: without this fence hipcc contracts the epilogue's
+        // `acc * inv - hi` into one fma of the unrounded product and the lo halves differ from leccr_split3's in the last bit
+        float x = v[j];
+        asm volatile("" : "+v"(x));
+        bf16_t hh, ll;
+        split1(x, hh, ll);
+        h[j] = hh; l[j] = ll;
+    }
+    *reinterpret_cast<bf16x4*>(p) = h;
+    *reinterpret_cast<bf16x4*>(p + seg) = FORM == 0 ? h : l;
+    *reinterpret_cast<bf16x4*>(p + 2 * seg) = FORM == 0 ? l : h;
+}
+
 __device__ __forceinline__ uint32_t valid_bits(const uint8_t* __restrict__ mask_row, int64_t i0, int64_t n, int l32) {
     const int64_t i = i0 + l32;
     const bool ok = i < n && (mask_row == nullptr || mask_row[i] == 0);
@@ -139,7 +172,7 @@ __device__ __forceinline__ uint32_t valid_bits(const uint8_t* __restrict__ mask_
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                   float* __restrict__ o, float* __restrict__ lse, const uint8_t* __restrict__ kmask,
-                                                  AttnDims D, float scale) {
+                                                  AttnDims D, float scale, S3 s3) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][2 * PLANE];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[2][2 * PLANE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l32 = lane & 31;
@@ -233,11 +266,20 @@ __global__ __launch_bounds__(256, 2) void fwd_kernel(const float* __restrict__ q
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.f / l : 0.f;
     if (q_ok) {
-        float* op = o + (bb * D.Lq + qi) * D.ldo + h * 64 + 4 * half;
+        if (s3.o3) {            // the X-form operand copy of o instead of o (see S3)
+            bf16_t* op3 = s3.o3 + (bb * D.Lq + qi) * s3.ld3 + h * 64 + 4 * half;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-            *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            for (int g = 0; g < 4; ++g) {
+                store_split4<0>(op3 + 8 * g, s3.seg, f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv});
+                store_split4<0>(op3 + 32 + 8 * g, s3.seg, f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv});
+            }
+        } else {
+            float* op = o + (bb * D.Lq + qi) * D.ldo + h * 64 + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            }
         }
         if (half == 0) lse[row] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * kLn2 : INFINITY;
     }
@@ -248,7 +290,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                  const float* __restrict__ o, const float* __restrict__ dout, const float* __restrict__ lse,
                                                  const uint8_t* __restrict__ kmask, float* __restrict__ dq, float* __restrict__ delta,
-                                                 AttnDims D, float scale) {
+                                                 AttnDims D, float scale, S3 s3) {
     __shared__ __attribute__((aligned(16))) bf16_t Ks[2][2 * PLANE];
     __shared__ __attribute__((aligned(16))) bf16_t Vs[2][2 * PLANE];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l32 = lane & 31;
@@ -268,7 +310,17 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q,
     const float* dop = dout + (bb * D.Lq + qc) * D.ldo + h * 64 + half * 8;
     load_frags(dop, 1.f, gh, gl);
     float dl = 0.f;
-    {       // delta_i = dO_i . O_i in f32 (this lane: its half's columns of every k-step)
+    if (s3.o3_in) {       // delta_i = dO_i . O_i with O read back from its X-form copy (hi | hi | lo): O = hi + lo
+        const bf16_t* op3 = s3.o3_in + (bb * D.Lq + qc) * s3.ldo3 + h * 64 + half * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bf16x8 oh = *reinterpret_cast<const bf16x8*>(op3 + 16 * t), ol = *reinterpret_cast<const bf16x8*>(op3 + 2 * s3.sego3 + 16 * t);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(dop + 16 * t), d = *reinterpret_cast<const f32x4*>(dop + 16 * t + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                dl = fmaf((float)oh[e] + (float)ol[e], c[e], fmaf((float)oh[4 + e] + (float)ol[4 + e], d[e], dl));
+        }
+    } else {              // .. in f32 (this lane: its half's columns of every k-step)
         const float* op = o + (bb * D.Lq + qc) * D.ldo + h * 64 + half * 8;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -335,7 +387,8 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q,
         __syncthreads();
     }
     if (!active || !q_ok) return;
-    float* dp_ = dq + (bb * D.Lq + qi) * D.ldq + h * 64 + 4 * half;
+    float* dp_ = s3.dq3 ? nullptr : dq + (bb * D.Lq + qi) * D.ldq + h * 64 + 4 * half;
+    bf16_t* dp3 = s3.dq3 ? s3.dq3 + (bb * D.Lq + qi) * s3.ld3 + h * 64 + 4 * half : nullptr;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 a, b;
@@ -344,8 +397,13 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q,
             a[e] = dq0[4 * g + e] * scale;
             b[e] = dq1[4 * g + e] * scale;
         }
-        *reinterpret_cast<f32x4*>(dp_ + 8 * g) = a;
-        *reinterpret_cast<f32x4*>(dp_ + 32 + 8 * g) = b;
+        if (dp3) {              // the G-form operand copy of dq instead of dq (see S3)
+            store_split4<1>(dp3 + 8 * g, s3.seg, a);
+            store_split4<1>(dp3 + 32 + 8 * g, s3.seg, b);
+        } else {
+            *reinterpret_cast<f32x4*>(dp_ + 8 * g) = a;
+            *reinterpret_cast<f32x4*>(dp_ + 32 + 8 * g) = b;
+        }
     }
 }
 
@@ -354,7 +412,7 @@ template <bool DROP>
 __global__ __launch_bounds__(256, 2) void dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                   const float* __restrict__ dout, const float* __restrict__ lse,
                                                   const float* __restrict__ delta, const uint8_t* __restrict__ kmask,
-                                                  float* __restrict__ dk, float* __restrict__ dv, AttnDims D, float scale) {
+                                                  float* __restrict__ dk, float* __restrict__ dv, AttnDims D, float scale, S3 s3) {
     __shared__ __attribute__((aligned(16))) bf16_t Qs[2][2 * PLANE];
     __shared__ __attribute__((aligned(16))) bf16_t Os[2][2 * PLANE];       // dO tiles
     __shared__ __attribute__((aligned(16))) float Ls[2][32], Ds[2][32];
@@ -454,8 +512,11 @@ __global__ __launch_bounds__(256, 2) void dkv_kernel(const float* __restrict__ q
         __syncthreads();
     }
     if (!active || !k_in) return;
-    float* dkp = dk + (bb * D.Lk + ki) * D.ldk + h * 64 + 4 * half;
-    float* dvp = dv + (bb * D.Lk + ki) * D.ldv + h * 64 + 4 * half;
+    const bool to3 = s3.dk3 != nullptr;
+    float* dkp = to3 ? nullptr : dk + (bb * D.Lk + ki) * D.ldk + h * 64 + 4 * half;
+    float* dvp = to3 ? nullptr : dv + (bb * D.Lk + ki) * D.ldv + h * 64 + 4 * half;
+    bf16_t* dkp3 = to3 ? s3.dk3 + (bb * D.Lk + ki) * s3.ld3 + h * 64 + 4 * half : nullptr;
+    bf16_t* dvp3 = to3 ? s3.dv3 + (bb * D.Lk + ki) * s3.ld3 + h * 64 + 4 * half : nullptr;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 a, b, c, d;
@@ -466,10 +527,17 @@ __global__ __launch_bounds__(256, 2) void dkv_kernel(const float* __restrict__ q
             c[e] = dv0[4 * g + e];
             d[e] = dv1[4 * g + e];
         }
-        *reinterpret_cast<f32x4*>(dkp + 8 * g) = a;
-        *reinterpret_cast<f32x4*>(dkp + 32 + 8 * g) = b;
-        *reinterpret_cast<f32x4*>(dvp + 8 * g) = c;
-        *reinterpret_cast<f32x4*>(dvp + 32 + 8 * g) = d;
+        if (to3) {              // the G-form operand copies of dk / dv instead of dk / dv (see S3)
+            store_split4<1>(dkp3 + 8 * g, s3.seg, a);
+            store_split4<1>(dkp3 + 32 + 8 * g, s3.seg, b);
+            store_split4<1>(dvp3 + 8 * g, s3.seg, c);
+            store_split4<1>(dvp3 + 32 + 8 * g, s3.seg, d);
+        } else {
+            *reinterpret_cast<f32x4*>(dkp + 8 * g) = a;
+            *reinterpret_cast<f32x4*>(dkp + 32 + 8 * g) = b;
+            *reinterpret_cast<f32x4*>(dvp + 8 * g) = c;
+            *reinterpret_cast<f32x4*>(dvp + 32 + 8 * g) = d;
+        }
     }
 }
 
@@ -481,22 +549,35 @@ bool attn_x3_wanted() {
     return on;
 }
 
-int attn_x3_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const AttnDims& D, hipStream_t st) {
+static x3a::S3 to_s3(const AttnS3* p) {
+    x3a::S3 s{};
+    if (p) {
+        s.o3 = (bf16_t*)p->o3; s.o3_in = (const bf16_t*)p->o3_in;
+        s.dq3 = (bf16_t*)p->dq3; s.dk3 = (bf16_t*)p->dk3; s.dv3 = (bf16_t*)p->dv3;
+        s.ld3 = p->ld3; s.seg = p->seg; s.ldo3 = p->ldo3; s.sego3 = p->sego3;
+    }
+    return s;
+}
+
+int attn_x3_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const AttnDims& D, hipStream_t st,
+                const AttnS3* s3p) {
     const float scale = 1.f / sqrtf((float)D.hd);
     const dim3 grid((unsigned)(D.b * D.heads * ((D.Lq + 127) / 128)));
+    const x3a::S3 s3 = to_s3(s3p);
     if (D.dropout)
-        hipLaunchKernelGGL(x3a::fwd_kernel<true>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, kmask, D, scale);
+        hipLaunchKernelGGL(x3a::fwd_kernel<true>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, kmask, D, scale, s3);
     else
-        hipLaunchKernelGGL(x3a::fwd_kernel<false>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, kmask, D, scale);
+        hipLaunchKernelGGL(x3a::fwd_kernel<false>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, kmask, D, scale, s3);
     return check_launch("attn_x3_fwd");
 }
 
 int attn_x3_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse, const uint8_t* kmask,
-                void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st) {
+                void* dq, void* dk, void* dv, float* delta, const AttnDims& D, hipStream_t st, const AttnS3* s3p) {
     const float scale = 1.f / sqrtf((float)D.hd);
     const dim3 gq((unsigned)(D.b * D.heads * ((D.Lq + 127) / 128))), gk((unsigned)(D.b * D.heads * ((D.Lk + 127) / 128)));
-#define ARGS_Q (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)dout, lse, kmask, (float*)dq, delta, D, scale
-#define ARGS_K (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, (const float*)delta, kmask, (float*)dk, (float*)dv, D, scale
+    const x3a::S3 s3 = to_s3(s3p);
+#define ARGS_Q (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)dout, lse, kmask, (float*)dq, delta, D, scale, s3
+#define ARGS_K (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, (const float*)delta, kmask, (float*)dk, (float*)dv, D, scale, s3
     if (D.dropout) {
         hipLaunchKernelGGL(x3a::dq_kernel<true>, gq, dim3(256), 0, st, ARGS_Q);
         hipLaunchKernelGGL(x3a::dkv_kernel<true>, gk, dim3(256), 0, st, ARGS_K);

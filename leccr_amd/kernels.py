@@ -305,6 +305,47 @@ def attn_fwd(q, k, v, heads, kmask=None, drop_p=0.0, seed=0, q8_site=None, causa
     return o, lse
 
 
+def attn_s3_takes(q, k, v, heads):
+    """Whether attn_fwd_s3 / attn_bwd_s3 take the problem: f32 self-attention (packed qkv views, Lq == Lk) on the pair-form kernels - head size
+    64, no causal mask, copy rows 16-byte aligned (leccr_attn_s3_takes)."""
+    if q.dtype != torch.float32 or not q.is_cuda or NS != 3:
+        return False
+    b, Lq, Lk = _attn_args(q, k, v)
+    d = q.shape[2]
+    return Lq == Lk and d % heads == 0 and bool(lib().leccr_attn_s3_takes(b, heads, Lq, Lk, d // heads, q.stride(1), k.stride(1), v.stride(1), 9 * d, 3 * d)) \
+        and bool(lib().leccr_attn_s3_takes(b, heads, Lq, Lk, d // heads, q.stride(1), k.stride(1), v.stride(1), 3 * d, d))
+
+
+def attn_fwd_s3(q, k, v, heads, kmask=None, drop_p=0.0, seed=0):
+    """f32 attention whose output exists only as its X-form operand copy (leccr_split3's layout): -> (o3 [b * Lq, 3 d] bf16, lse)."""
+    b, Lq, Lk = _attn_args(q, k, v)
+    d = q.shape[2]
+    o3 = torch.empty(b * Lq, 3 * d, device=q.device, dtype=torch.bfloat16)
+    lse = torch.empty(b, heads, Lq, device=q.device, dtype=torch.float32)
+    if kmask is not None:
+        assert kmask.dtype == torch.uint8 and kmask.shape == (b, Lk) and kmask.is_contiguous()
+    check(lib().leccr_attn_fwd_s3(ptr(q), ptr(k), ptr(v), ptr(o3), ptr(lse), ptr(kmask), b, heads, Lq, Lk, d // heads,
+                                  q.stride(1), k.stride(1), v.stride(1), 3 * d, d, float(drop_p), int(seed), stream()), 'leccr_attn_fwd_s3')
+    return o3, lse
+
+
+def attn_bwd_s3(q, k, v, o3, dout, lse, heads, kmask=None, drop_p=0.0, seed=0):
+    """Backward of attn_fwd_s3 for self-attention on a packed qkv: reads o as its copy o3, writes the gradient of the packed [rows, 3 d] tensor
+    only as its G-form operand copy -> dqkv3 [b * L, 3 * 3 d] bf16 (segments hi | lo | hi, each [dq | dk | dv])."""
+    b, Lq, Lk = _attn_args(q, k, v)
+    d = q.shape[2]
+    assert Lq == Lk and dout.is_contiguous() and dout.shape == (b, Lq, d) and o3.shape == (b * Lq, 3 * d) and o3.is_contiguous()
+    dqkv3 = torch.empty(b * Lq, 9 * d, device=q.device, dtype=torch.bfloat16)
+    delta = torch.empty(2 * b * heads * ((Lq + 63) // 64 * 64), dtype=torch.float32, device=q.device)
+    if kmask is not None:
+        assert kmask.dtype == torch.uint8 and kmask.shape == (b, Lk) and kmask.is_contiguous()
+    check(lib().leccr_attn_bwd_s3(ptr(q), ptr(k), ptr(v), ptr(o3), 3 * d, d, ptr(dout), ptr(lse), ptr(kmask),
+                                  ptr(dqkv3), ptr(dqkv3[:, d:2 * d]), ptr(dqkv3[:, 2 * d:3 * d]), ptr(delta), b, heads, Lq, Lk, d // heads,
+                                  q.stride(1), k.stride(1), v.stride(1), dout.stride(1), 9 * d, 3 * d, float(drop_p), int(seed), stream()),
+          'leccr_attn_bwd_s3')
+    return dqkv3
+
+
 def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None, drop_p=0.0, seed=0, q8=None, causal=False):
     """q8 = (dq8, dk8, dv8, site): e5m2 copies of the three gradients (views of one packed [b, L, 3 d] byte tensor) under one primed site."""
     b, Lq, Lk = _attn_args(q, k, v)

@@ -144,6 +144,7 @@ fp8_bias_asum = os.environ.get('LECCR_FP8_BIAS_ASUM', '1') != '0'      # bias gr
 X3 = 'x3'
 fuse_x3_copies = os.environ.get('LECCR_X3_FUSE', '1') != '0'      # the GEMM epilogues write the split copies of the 4d-wide MLP tensors
 ln_x3_copies = os.environ.get('LECCR_X3_LN', '1') != '0'       # .. and the encoder blocks' LayerNorm passes write h1 / h2 as split copies only
+attn_x3_copies = os.environ.get('LECCR_X3_ATTN', '1') != '0'   # .. and the attention kernels write o / dqkv as the copies out_proj / in_proj read
 
 
 def _x3_lin_ok(rows, w):
@@ -665,10 +666,17 @@ class ViTBlockFn(torch.autograd.Function):
             o_8 = None
         elif o_site is not None and o_site.primed:
             o, lse, o_8 = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads, q8_site=o_site)
+        elif x3 and attn_x3_copies and fuse_x3_copies and _x3_lin_ok(M, blk.attn.out_proj.weight) and _x3_lin_ok(M, blk.attn.in_proj_weight) \
+                and K.attn_s3_takes(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads):
+            # mode X3: o is read only as out_proj's X-form copy (forward and weight-gradient product) and by the backward's delta = dO . O:
+            # the attention kernel writes that copy and no f32 tensor (the backward reads o back as hi + lo)
+            o_8, lse = K.attn_fwd_s3(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
+            o = None
         else:
             o, lse = K.attn_fwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], blk.heads)
             o_8 = x8_of(blk.fp8, _rows(o), blk.attn.out_proj.weight)
-        x1 = lin_fwd(_rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, x8=o_8, residual=_rows(x)).view(b, N, d)
+        x1 = lin_fwd(_rows(o) if o is not None else None, blk.attn.out_proj.weight, blk.attn.out_proj.bias, fp8=blk.fp8, x8=o_8,
+                     residual=_rows(x)).view(b, N, d)
         h2, mean2, rstd2, _, h2_8 = _ln_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5,
                                             site=_q8_site(blk.fp8, M, blk.mlp.c_fc.weight, '_xsite'),
                                             x3_for=blk.mlp.c_fc.weight if x3 else None, x3_only=True)
@@ -691,7 +699,7 @@ class ViTBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, dw_keep(h1r, h1_8, blk.attn.in_proj_weight), mean1, rstd1, qkv, o, lse, x1,
                               dw_keep(h2r, h2_8, blk.mlp.c_fc.weight), mean2, rstd2, pre,
                               act if act.shape[0] == 0 else dw_keep(act, act8, blk.mlp.c_proj.weight),
-                              *((h1_8, o_8, h2_8, act8) if fp8_dw else (None,) * 4))
+                              *((h1_8, o_8, h2_8, act8) if (fp8_dw or o is None) else (None,) * 4))
         ctx.blk = blk
         return x2
 
@@ -727,6 +735,18 @@ class ViTBlockFn(torch.autograd.Function):
         g1 = _rows(dx1)
         g1_8 = g8_of(blk.fp8, g1, blk.attn.out_proj.weight, g1_8, bias=blk.attn.out_proj.bias)
         do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8, g8=g1_8).view(b, N, d)
+        if o is None:
+            # mode X3 with the attention kernels' own operand copies (forward above): o exists as o_8 only, and the gradient of the packed qkv
+            # is written as in_proj's G-form copy only; in_proj's bias gradient = column sums of the copy's hi and lo segments
+            lin_dw(g1, o_8.new_empty((0, d), dtype=torch.float32), blk.attn.out_proj.weight, blk.attn.out_proj.bias, g8=g1_8, x8=o_8)
+            dqkv3 = K.attn_bwd_s3(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o_8, do, lse, blk.heads)
+            K.colsum(dqkv3[:, :3 * d], blk.attn.in_proj_bias._g.reshape(-1))
+            K.colsum(dqkv3[:, 3 * d:6 * d], blk.attn.in_proj_bias._g.reshape(-1))
+            _mark(blk.attn.in_proj_bias)
+            dqkv3._bias_done = True
+            dh1 = lin_dx(None, blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv3)
+            lin_dw(None, h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv3, x8=h1_8)
+            return ViTBlockFn._finish_backward(ctx, blk, b, N, d, dh1, x, mean1, rstd1, dx1)
         lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, g8=g1_8, x8=o_8)
         dqkv = torch.empty_like(qkv)
         g_site = _q8_site(blk.fp8, b * N, blk.attn.in_proj_weight, '_gsite')
@@ -739,6 +759,10 @@ class ViTBlockFn(torch.autograd.Function):
         dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight, None if dqkv8 is None else _rows(dqkv8), bias=blk.attn.in_proj_bias)
         dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)
         lin_dw(_rows(dqkv), h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
+        return ViTBlockFn._finish_backward(ctx, blk, b, N, d, dh1, x, mean1, rstd1, dx1)
+
+    @staticmethod
+    def _finish_backward(ctx, blk, b, N, d, dh1, x, mean1, rstd1, dx1):
         # (fp8: dx is the gradient the previous block's c_proj dX product consumes: its e5m2 copy goes with it)
         prev = getattr(blk, '_dx_consumer', (None,))[0]
         dx, _, dx_8 = _ln_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g, blk.ln_1.bias._g,

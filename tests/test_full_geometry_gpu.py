@@ -414,6 +414,43 @@ def test_persistent_gemm_paths_in_a_model_vs_oracle():
     assert blk.mlp.c_fc.bias.grad.abs().sum() > 0
 
 
+def test_fp32_attention_and_layernorm_written_copies_change_nothing(monkeypatch):
+    """fp32 path, ViT-B/16 @384 (one layer, b = 8: 4616 token rows, head size 64): with the operand copies written by their producers - the
+    LayerNorm passes (h1 / h2), the attention kernels (o, the gradient of the packed qkv) - every loss and every parameter gradient equals
+    the run in which each product splits its own f32 operand, to the pair form's own precision (the backward's delta reads o as hi + lo)."""
+    from leccr_amd import kernels as K, ops
+    from leccr_amd.synthetic import make_batch
+    model, _ = full_geometry_model('fp32', vision_layers=1, text_config=MID_BERT)
+    model = model.to(DEV).eval()
+    m = make_batch(8, vocab=500)
+    batch = dict(image=m['image'], ids_s=m['text'][0].input_ids, mask_s=m['text'][0].attention_mask, ids_t=m['text'][1].input_ids,
+                 mask_t=m['text'][1].attention_mask, ids_c=m['captions'].input_ids, mask_c=m['captions'].attention_mask, idx=m['idx'])
+    calls = {'fwd': 0, 'bwd': 0}
+    fwd_s3, bwd_s3 = K.attn_fwd_s3, K.attn_bwd_s3
+    monkeypatch.setattr(K, 'attn_fwd_s3', lambda *a, **k: (calls.__setitem__('fwd', calls['fwd'] + 1), fwd_s3(*a, **k))[1])
+    monkeypatch.setattr(K, 'attn_bwd_s3', lambda *a, **k: (calls.__setitem__('bwd', calls['bwd'] + 1), bwd_s3(*a, **k))[1])
+
+    def run(on):
+        monkeypatch.setattr(ops, 'attn_x3_copies', on)
+        monkeypatch.setattr(ops, 'ln_x3_copies', on)
+        losses = _forward(model, batch)
+        model.arena.zero_grad()
+        sum(losses).backward()
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    l1, g1 = run(True)
+    assert calls == {'fwd': 1, 'bwd': 1}                       # the one ViT block took the attention kernels' own copies
+    l0, g0 = run(False)
+    assert calls == {'fwd': 1, 'bwd': 1}
+    assert max(abs(a - b) for a, b in zip(l1, l0)) <= 1e-5
+    bad = []
+    for k in g0:
+        e, s_ = float((g1[k] - g0[k]).abs().max()), float(g0[k].abs().max())
+        if e > 5e-5 * s_ + 1e-9:
+            bad.append((k, e, s_))
+    assert len(g0) > 100 and not bad, bad[:8]
+
+
 def test_fp8_weight_copies_and_their_scale_stay_together_when_a_weight_grows():
     """A weight's fp8 copies are written once per optimizer step and read by every product until the next one, while the 1/scale of
     the product is read at kernel time: both must come from the SAME scale.  Round 2 requantised under the site's previous scale and
