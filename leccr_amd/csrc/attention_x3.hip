@@ -144,6 +144,50 @@ struct S3 {
     int64_t ldo3, sego3;   // .. and of o3_in
 };
 
+// The wave's 32 x 64 output tile (lane (row l32, half) holds columns 4 half + 8 g + e in a0[4 g + e] and 32 + the same in a1) -> the three
+// segments of its operand copy.  Straight from the registers a lane would write 24 eight-byte pieces of its own row (measured: the three
+// kernels 435 us slower per layer than with f32 outputs - most of what the removed split passes save); through a wave-private LDS tile
+// (two planes of 32 rows x RSB) the wave writes 16-byte pieces, eight lanes per 128-byte row.  `stage`: 2 * PLANE bf16 nobody else touches
+// any more (the kernel's operand buffers after its last barrier); `base`: the copy at the wave's first row, the tile's column 0, segment 0.
+template <int FORM>
+__device__ __forceinline__ void store_tile_s3(bf16_t* __restrict__ stage, bf16_t* __restrict__ base, int64_t ld3, int64_t seg, int rows_valid,
+                                              int lane, const float (&a0)[16], const float (&a1)[16]) {
+    const int l32 = lane & 31, half = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 h0, l0, h1, l1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // the split of the ROUNDED f32 value, as leccr_split3 would read it from memory (without the fence hipcc contracts the caller's
+            // `acc * inv - hi` into one fma of the unrounded product and the lo halves differ from leccr_split3's in the last bit)
+            float x = a0[4 * g + e], y = a1[4 * g + e];
+            asm volatile("" : "+v"(x), "+v"(y));
+            bf16_t hh, ll;
+            split1(x, hh, ll); h0[e] = hh; l0[e] = ll;
+            split1(y, hh, ll); h1[e] = hh; l1[e] = ll;
+        }
+        bf16_t* d = stage + l32 * RSB + 4 * half + 8 * g;
+        *reinterpret_cast<bf16x4*>(d) = h0;
+        *reinterpret_cast<bf16x4*>(d + 32) = h1;
+        *reinterpret_cast<bf16x4*>(d + PLANE) = l0;
+        *reinterpret_cast<bf16x4*>(d + PLANE + 32) = l1;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own LDS writes have landed (in-order LDS, one wave)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j, row = c >> 3, ch = c & 7;
+        const bf16x8 hv = *reinterpret_cast<const bf16x8*>(stage + row * RSB + 8 * ch);
+        const bf16x8 lv = *reinterpret_cast<const bf16x8*>(stage + PLANE + row * RSB + 8 * ch);
+        if (row < rows_valid) {
+            bf16_t* d = base + row * ld3 + 8 * ch;
+            *reinterpret_cast<bf16x8*>(d) = hv;
+            *reinterpret_cast<bf16x8*>(d + seg) = FORM == 0 ? hv : lv;
+            *reinterpret_cast<bf16x8*>(d + 2 * seg) = FORM == 0 ? lv : hv;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // .. and its reads have returned before the tile is staged again
+}
+
 template <int FORM>
 __device__ __forceinline__ void store_split4(bf16_t* __restrict__ p, int64_t seg, const f32x4& v) {
     bf16x4 h, l;
@@ -169,7 +213,7 @@ __device__ __forceinline__ uint32_t valid_bits(const uint8_t* __restrict__ mask_
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <bool DROP>
+template <bool DROP, bool S3OUT>
 __global__ __launch_bounds__(256, 2) void fwd_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                   float* __restrict__ o, float* __restrict__ lse, const uint8_t* __restrict__ kmask,
                                                   AttnDims D, float scale, S3 s3) {
@@ -265,28 +309,25 @@ __global__ __launch_bounds__(256, 2) void fwd_kernel(const float* __restrict__ q
     if (!active) return;
     l += __shfl_xor(l, 32, 64);
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    if (q_ok) {
-        if (s3.o3) {            // the X-form operand copy of o instead of o (see S3)
-            bf16_t* op3 = s3.o3 + (bb * D.Lq + qi) * s3.ld3 + h * 64 + 4 * half;
+    if constexpr (S3OUT) {  // the X-form operand copy of o instead of o (see S3), the wave's 32 rows through its LDS tile
+        float a0[16], a1[16];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                store_split4<0>(op3 + 8 * g, s3.seg, f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv});
-                store_split4<0>(op3 + 32 + 8 * g, s3.seg, f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv});
-            }
-        } else {
-            float* op = o + (bb * D.Lq + qi) * D.ldo + h * 64 + 4 * half;
+        for (int r = 0; r < 16; ++r) { a0[r] = o0[r] * inv; a1[r] = o1[r] * inv; }
+        const int rows_valid = (int)(D.Lq - q0 < 32 ? D.Lq - q0 : 32);
+        store_tile_s3<0>(wave < 2 ? &Ks[wave][0] : &Vs[wave - 2][0], s3.o3 + (bb * D.Lq + q0) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1);
+    } else if (q_ok) {
+        float* op = o + (bb * D.Lq + qi) * D.ldo + h * 64 + 4 * half;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-                *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
-            }
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<f32x4*>(op + 8 * g) = f32x4{o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+            *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = f32x4{o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
         }
-        if (half == 0) lse[row] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * kLn2 : INFINITY;
     }
+    if (q_ok && half == 0) lse[row] = l > 0.f ? (m + __builtin_amdgcn_logf(l)) * kLn2 : INFINITY;
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ (+ delta)
-template <bool DROP>
+template <bool DROP, bool S3OUT>
 __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                  const float* __restrict__ o, const float* __restrict__ dout, const float* __restrict__ lse,
                                                  const uint8_t* __restrict__ kmask, float* __restrict__ dq, float* __restrict__ delta,
@@ -310,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q,
     const float* dop = dout + (bb * D.Lq + qc) * D.ldo + h * 64 + half * 8;
     load_frags(dop, 1.f, gh, gl);
     float dl = 0.f;
-    if (s3.o3_in) {       // delta_i = dO_i . O_i with O read back from its X-form copy (hi | hi | lo): O = hi + lo
+    if constexpr (S3OUT) { // delta_i = dO_i . O_i with O read back from its X-form copy (hi | hi | lo): O = hi + lo
         const bf16_t* op3 = s3.o3_in + (bb * D.Lq + qc) * s3.ldo3 + h * 64 + half * 8;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -386,9 +427,17 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q,
         }
         __syncthreads();
     }
-    if (!active || !q_ok) return;
-    float* dp_ = s3.dq3 ? nullptr : dq + (bb * D.Lq + qi) * D.ldq + h * 64 + 4 * half;
-    bf16_t* dp3 = s3.dq3 ? s3.dq3 + (bb * D.Lq + qi) * s3.ld3 + h * 64 + 4 * half : nullptr;
+    if (!active) return;
+    if constexpr (S3OUT) {     // the G-form operand copy of dq instead of dq (see S3)
+        float a0[16], a1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = dq0[r] * scale; a1[r] = dq1[r] * scale; }
+        const int rows_valid = (int)(D.Lq - q0 < 32 ? D.Lq - q0 : 32);
+        store_tile_s3<1>(wave < 2 ? &Ks[wave][0] : &Vs[wave - 2][0], s3.dq3 + (bb * D.Lq + q0) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1);
+        return;
+    }
+    if (!q_ok) return;
+    float* dp_ = dq + (bb * D.Lq + qi) * D.ldq + h * 64 + 4 * half;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 a, b;
@@ -397,18 +446,13 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q,
             a[e] = dq0[4 * g + e] * scale;
             b[e] = dq1[4 * g + e] * scale;
         }
-        if (dp3) {              // the G-form operand copy of dq instead of dq (see S3)
-            store_split4<1>(dp3 + 8 * g, s3.seg, a);
-            store_split4<1>(dp3 + 32 + 8 * g, s3.seg, b);
-        } else {
-            *reinterpret_cast<f32x4*>(dp_ + 8 * g) = a;
-            *reinterpret_cast<f32x4*>(dp_ + 32 + 8 * g) = b;
-        }
+        *reinterpret_cast<f32x4*>(dp_ + 8 * g) = a;
+        *reinterpret_cast<f32x4*>(dp_ + 32 + 8 * g) = b;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-template <bool DROP>
+template <bool DROP, bool S3OUT>
 __global__ __launch_bounds__(256, 2) void dkv_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                   const float* __restrict__ dout, const float* __restrict__ lse,
                                                   const float* __restrict__ delta, const uint8_t* __restrict__ kmask,
@@ -511,12 +555,22 @@ __global__ __launch_bounds__(256, 2) void dkv_kernel(const float* __restrict__ q
         }
         __syncthreads();
     }
-    if (!active || !k_in) return;
-    const bool to3 = s3.dk3 != nullptr;
-    float* dkp = to3 ? nullptr : dk + (bb * D.Lk + ki) * D.ldk + h * 64 + 4 * half;
-    float* dvp = to3 ? nullptr : dv + (bb * D.Lk + ki) * D.ldv + h * 64 + 4 * half;
-    bf16_t* dkp3 = to3 ? s3.dk3 + (bb * D.Lk + ki) * s3.ld3 + h * 64 + 4 * half : nullptr;
-    bf16_t* dvp3 = to3 ? s3.dv3 + (bb * D.Lk + ki) * s3.ld3 + h * 64 + 4 * half : nullptr;
+    if (!active) return;
+    if constexpr (S3OUT) {     // the G-form operand copies of dk / dv instead of dk / dv (see S3): one after the other through the wave's LDS tile
+        bf16_t* stage = wave < 2 ? &Qs[wave][0] : &Os[wave - 2][0];
+        const int rows_valid = (int)(D.Lk - k0w < 32 ? D.Lk - k0w : 32);
+        float a0[16], a1[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = dk0[r] * scale; a1[r] = dk1[r] * scale; }
+        store_tile_s3<1>(stage, s3.dk3 + (bb * D.Lk + k0w) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = dv0[r]; a1[r] = dv1[r]; }
+        store_tile_s3<1>(stage, s3.dv3 + (bb * D.Lk + k0w) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1);
+        return;
+    }
+    if (!k_in) return;
+    float* dkp = dk + (bb * D.Lk + ki) * D.ldk + h * 64 + 4 * half;
+    float* dvp = dv + (bb * D.Lk + ki) * D.ldv + h * 64 + 4 * half;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 a, b, c, d;
@@ -527,17 +581,10 @@ __global__ __launch_bounds__(256, 2) void dkv_kernel(const float* __restrict__ q
             c[e] = dv0[4 * g + e];
             d[e] = dv1[4 * g + e];
         }
-        if (to3) {              // the G-form operand copies of dk / dv instead of dk / dv (see S3)
-            store_split4<1>(dkp3 + 8 * g, s3.seg, a);
-            store_split4<1>(dkp3 + 32 + 8 * g, s3.seg, b);
-            store_split4<1>(dvp3 + 8 * g, s3.seg, c);
-            store_split4<1>(dvp3 + 32 + 8 * g, s3.seg, d);
-        } else {
-            *reinterpret_cast<f32x4*>(dkp + 8 * g) = a;
-            *reinterpret_cast<f32x4*>(dkp + 32 + 8 * g) = b;
-            *reinterpret_cast<f32x4*>(dvp + 8 * g) = c;
-            *reinterpret_cast<f32x4*>(dvp + 32 + 8 * g) = d;
-        }
+        *reinterpret_cast<f32x4*>(dkp + 8 * g) = a;
+        *reinterpret_cast<f32x4*>(dkp + 32 + 8 * g) = b;
+        *reinterpret_cast<f32x4*>(dvp + 8 * g) = c;
+        *reinterpret_cast<f32x4*>(dvp + 32 + 8 * g) = d;
     }
 }
 
@@ -564,10 +611,11 @@ int attn_x3_fwd(const void* q, const void* k, const void* v, void* o, float* lse
     const float scale = 1.f / sqrtf((float)D.hd);
     const dim3 grid((unsigned)(D.b * D.heads * ((D.Lq + 127) / 128)));
     const x3a::S3 s3 = to_s3(s3p);
-    if (D.dropout)
-        hipLaunchKernelGGL(x3a::fwd_kernel<true>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, kmask, D, scale, s3);
-    else
-        hipLaunchKernelGGL(x3a::fwd_kernel<false>, grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, kmask, D, scale, s3);
+    const bool out3 = s3.o3 != nullptr;
+#define FWD(DROP_, S3_) hipLaunchKernelGGL((x3a::fwd_kernel<DROP_, S3_>), grid, dim3(256), 0, st, (const float*)q, (const float*)k, (const float*)v, (float*)o, lse, kmask, D, scale, s3)
+    if (D.dropout) { if (out3) FWD(true, true); else FWD(true, false); }
+    else { if (out3) FWD(false, true); else FWD(false, false); }
+#undef FWD
     return check_launch("attn_x3_fwd");
 }
 
@@ -578,13 +626,15 @@ int attn_x3_bwd(const void* q, const void* k, const void* v, const void* o, cons
     const x3a::S3 s3 = to_s3(s3p);
 #define ARGS_Q (const float*)q, (const float*)k, (const float*)v, (const float*)o, (const float*)dout, lse, kmask, (float*)dq, delta, D, scale, s3
 #define ARGS_K (const float*)q, (const float*)k, (const float*)v, (const float*)dout, lse, (const float*)delta, kmask, (float*)dk, (float*)dv, D, scale, s3
-    if (D.dropout) {
-        hipLaunchKernelGGL(x3a::dq_kernel<true>, gq, dim3(256), 0, st, ARGS_Q);
-        hipLaunchKernelGGL(x3a::dkv_kernel<true>, gk, dim3(256), 0, st, ARGS_K);
-    } else {
-        hipLaunchKernelGGL(x3a::dq_kernel<false>, gq, dim3(256), 0, st, ARGS_Q);
-        hipLaunchKernelGGL(x3a::dkv_kernel<false>, gk, dim3(256), 0, st, ARGS_K);
-    }
+    const bool out3 = s3.dq3 != nullptr;         // (leccr_attn_bwd_s3: the o copy in, the three gradient copies out - all or none)
+#define BWD(DROP_, S3_)                                                                      \
+    do {                                                                                     \
+        hipLaunchKernelGGL((x3a::dq_kernel<DROP_, S3_>), gq, dim3(256), 0, st, ARGS_Q);      \
+        hipLaunchKernelGGL((x3a::dkv_kernel<DROP_, S3_>), gk, dim3(256), 0, st, ARGS_K);     \
+    } while (0)
+    if (D.dropout) { if (out3) BWD(true, true); else BWD(true, false); }
+    else { if (out3) BWD(false, true); else BWD(false, false); }
+#undef BWD
 #undef ARGS_Q
 #undef ARGS_K
     return check_launch("attn_x3_bwd");
