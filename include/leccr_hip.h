@@ -280,7 +280,8 @@ int leccr_attn_fwd_s3(const void* q, const void* k, const void* v, void* o3, flo
 int leccr_attn_bwd_s3(const void* q, const void* k, const void* v, const void* o3, int64_t ldo3, int64_t sego3, const void* dout,
                       const float* lse, const uint8_t* kmask, void* dq3, void* dk3, void* dv3, float* delta,
                       int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                      int64_t ld3, int64_t seg3, float drop_p, uint64_t seed, void* stream);
+                      int64_t ld3, int64_t seg3, float* bias_sum /* optional [3 heads hd]: += column sums of [dq | dk | dv] */,
+                      float drop_p, uint64_t seed, void* stream);
 
 /* ---- ViT input stage --------------------------------------------------------------------------------------
  * patchify: image [b,3,R,R] f32 NCHW -> patches [b*g*g, Kp] (T), g = floor(R/p) (the R % p edge pixels are dropped, as

@@ -62,7 +62,7 @@ _SIGS = {
                            C.c_int, f32, C.c_uint64, vp, vp, vp, i64, vp, vp], C.c_int),
     'leccr_attn_s3_takes': ([i64] * 10, C.c_int),
     'leccr_attn_fwd_s3': ([vp] * 6 + [i64] * 10 + [f32, C.c_uint64, vp], C.c_int),
-    'leccr_attn_bwd_s3': ([vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp] + [i64] * 11 + [f32, C.c_uint64, vp], C.c_int),
+    'leccr_attn_bwd_s3': ([vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp] + [i64] * 11 + [vp, f32, C.c_uint64, vp], C.c_int),
     'leccr_patchify': ([vp, vp, i64, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_vit_assemble_fwd': ([vp, vp, vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),
     'leccr_vit_assemble_bwd': ([vp, vp, vp, vp, i64, i64, i64, C.c_int, vp], C.c_int),

@@ -60,6 +60,9 @@ struct AttnS3 {
     void* dv3 = nullptr;
     int64_t ld3 = 0, seg = 0;       // layout of the output copies (o3 / dq3 / dk3 / dv3)
     int64_t ldo3 = 0, sego3 = 0;    // layout of o3_in
+    float* bq = nullptr;            // optional [heads * hd] each: += column sums of dq / dk / dv (the in-projection's bias gradient)
+    float* bk = nullptr;
+    float* bv = nullptr;
 };
 int attn_x3_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, const AttnDims& D, hipStream_t st,
                 const AttnS3* s3 = nullptr);

@@ -185,11 +185,12 @@ extern "C" int leccr_attn_fwd_s3(const void* q, const void* k, const void* v, vo
 
 // o3: the copy leccr_attn_fwd_s3 wrote (read back as hi + lo for delta = dO . O); dq3 / dk3 / dv3: the G-form (hi | lo | hi) copies of the three
 // gradients, each pointer at its tensor's column 0 inside segment 0 of a copy with row stride ld3 and segment width seg3 (one packed
-// [rows, 3 x 3 d] copy of dqkv: dq3 = base, dk3 = base + d, dv3 = base + 2 d, seg3 = 3 d); dout has row stride ldo
+// [rows, 3 x 3 d] copy of dqkv: dq3 = base, dk3 = base + d, dv3 = base + 2 d, seg3 = 3 d); dout has row stride ldo; bias_sum (optional,
+// [3 heads hd] f32): += the column sums of [dq | dk | dv] - the packed in-projection's bias gradient, taken from the tiles as they are staged
 extern "C" int leccr_attn_bwd_s3(const void* q, const void* k, const void* v, const void* o3, int64_t ldo3, int64_t sego3, const void* dout,
                                  const float* lse, const uint8_t* kmask, void* dq3, void* dk3, void* dv3, float* delta,
                                  int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                                 int64_t ld3, int64_t seg3, float drop_p, uint64_t seed, void* stream) {
+                                 int64_t ld3, int64_t seg3, float* bias_sum, float drop_p, uint64_t seed, void* stream) {
     LECCR_REQUIRE(q && k && v && o3 && dout && lse && dq3 && dk3 && dv3 && delta, LECCR_EINVAL, "attn_bwd_s3: null pointer");
     LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_bwd_s3: drop_p must be in [0,1)");
     LECCR_REQUIRE(sego3 >= heads * hd && ldo3 >= 3 * sego3 && ((ldo3 | sego3) & 7) == 0, LECCR_EINVAL,
@@ -205,6 +206,7 @@ extern "C" int leccr_attn_bwd_s3(const void* q, const void* k, const void* v, co
     //  passed through the same struct by pointing o3_in at the copy and keeping its strides beside it)
     AttnS3 s3;
     s3.o3_in = o3; s3.dq3 = dq3; s3.dk3 = dk3; s3.dv3 = dv3; s3.ld3 = ld3; s3.seg = seg3; s3.ldo3 = ldo3; s3.sego3 = sego3;
+    if (bias_sum) { s3.bq = bias_sum; s3.bk = bias_sum + heads * hd; s3.bv = bias_sum + 2 * heads * hd; }
     g_last_attn_kernel = 5;
     return attn_x3_bwd(q, k, v, nullptr, dout, lse, kmask, nullptr, nullptr, nullptr, delta, D, st, &s3);
 }

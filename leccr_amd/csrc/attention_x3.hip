@@ -141,6 +141,9 @@ struct S3 {
     bf16_t* dk3;
     bf16_t* dv3;
     int64_t ld3, seg;      // row stride and segment width of the output copies (elements)
+    float* bq;             // optional [heads * 64] f32 each: += the column sums of dq / dk / dv (the in-projection's bias gradient), summed
+    float* bk;             //   from the staged tiles (hi + lo) - one atomic per column and wave tile
+    float* bv;
     int64_t ldo3, sego3;   // .. and of o3_in
 };
 
@@ -151,7 +154,7 @@ struct S3 {
 // any more (the kernel's operand buffers after its last barrier); `base`: the copy at the wave's first row, the tile's column 0, segment 0.
 template <int FORM>
 __device__ __forceinline__ void store_tile_s3(bf16_t* __restrict__ stage, bf16_t* __restrict__ base, int64_t ld3, int64_t seg, int rows_valid,
-                                              int lane, const float (&a0)[16], const float (&a1)[16]) {
+                                              int lane, const float (&a0)[16], const float (&a1)[16], float* __restrict__ colsum = nullptr) {
     const int l32 = lane & 31, half = lane >> 5;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -173,6 +176,12 @@ __device__ __forceinline__ void store_tile_s3(bf16_t* __restrict__ stage, bf16_t
         *reinterpret_cast<bf16x4*>(d + PLANE + 32) = l1;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own LDS writes have landed (in-order LDS, one wave)
+    if (colsum) {           // column `lane` of the tile, its valid rows, hi + lo (the values the copy's readers see): one atomic per column
+        float t = 0.f;
+        for (int row = 0; row < rows_valid; ++row)
+            t += static_cast<float>(stage[row * RSB + lane]) + static_cast<float>(stage[PLANE + row * RSB + lane]);
+        atomicAdd(colsum + lane, t);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int c = lane + 64 * j, row = c >> 3, ch = c & 7;
@@ -433,7 +442,8 @@ __global__ __launch_bounds__(256, 2) void dq_kernel(const float* __restrict__ q,
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = dq0[r] * scale; a1[r] = dq1[r] * scale; }
         const int rows_valid = (int)(D.Lq - q0 < 32 ? D.Lq - q0 : 32);
-        store_tile_s3<1>(wave < 2 ? &Ks[wave][0] : &Vs[wave - 2][0], s3.dq3 + (bb * D.Lq + q0) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1);
+        store_tile_s3<1>(wave < 2 ? &Ks[wave][0] : &Vs[wave - 2][0], s3.dq3 + (bb * D.Lq + q0) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1,
+                         s3.bq ? s3.bq + h * 64 : nullptr);
         return;
     }
     if (!q_ok) return;
@@ -562,10 +572,10 @@ __global__ __launch_bounds__(256, 2) void dkv_kernel(const float* __restrict__ q
         float a0[16], a1[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = dk0[r] * scale; a1[r] = dk1[r] * scale; }
-        store_tile_s3<1>(stage, s3.dk3 + (bb * D.Lk + k0w) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1);
+        store_tile_s3<1>(stage, s3.dk3 + (bb * D.Lk + k0w) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1, s3.bk ? s3.bk + h * 64 : nullptr);
 #pragma unroll
         for (int r = 0; r < 16; ++r) { a0[r] = dv0[r]; a1[r] = dv1[r]; }
-        store_tile_s3<1>(stage, s3.dv3 + (bb * D.Lk + k0w) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1);
+        store_tile_s3<1>(stage, s3.dv3 + (bb * D.Lk + k0w) * s3.ld3 + h * 64, s3.ld3, s3.seg, rows_valid, lane, a0, a1, s3.bv ? s3.bv + h * 64 : nullptr);
         return;
     }
     if (!k_in) return;
@@ -602,6 +612,7 @@ static x3a::S3 to_s3(const AttnS3* p) {
         s.o3 = (bf16_t*)p->o3; s.o3_in = (const bf16_t*)p->o3_in;
         s.dq3 = (bf16_t*)p->dq3; s.dk3 = (bf16_t*)p->dk3; s.dv3 = (bf16_t*)p->dv3;
         s.ld3 = p->ld3; s.seg = p->seg; s.ldo3 = p->ldo3; s.sego3 = p->sego3;
+        s.bq = p->bq; s.bk = p->bk; s.bv = p->bv;
     }
     return s;
 }

@@ -329,19 +329,21 @@ def attn_fwd_s3(q, k, v, heads, kmask=None, drop_p=0.0, seed=0):
     return o3, lse
 
 
-def attn_bwd_s3(q, k, v, o3, dout, lse, heads, kmask=None, drop_p=0.0, seed=0):
+def attn_bwd_s3(q, k, v, o3, dout, lse, heads, kmask=None, drop_p=0.0, seed=0, bias_sum=None):
     """Backward of attn_fwd_s3 for self-attention on a packed qkv: reads o as its copy o3, writes the gradient of the packed [rows, 3 d] tensor
-    only as its G-form operand copy -> dqkv3 [b * L, 3 * 3 d] bf16 (segments hi | lo | hi, each [dq | dk | dv])."""
+    only as its G-form operand copy -> dqkv3 [b * L, 3 * 3 d] bf16 (segments hi | lo | hi, each [dq | dk | dv]).  bias_sum ([3 d] f32): += the
+    column sums of that gradient (the packed in-projection's bias gradient), summed inside the kernels."""
     b, Lq, Lk = _attn_args(q, k, v)
     d = q.shape[2]
     assert Lq == Lk and dout.is_contiguous() and dout.shape == (b, Lq, d) and o3.shape == (b * Lq, 3 * d) and o3.is_contiguous()
+    assert bias_sum is None or (bias_sum.dtype == torch.float32 and bias_sum.numel() == 3 * d and bias_sum.is_contiguous())
     dqkv3 = torch.empty(b * Lq, 9 * d, device=q.device, dtype=torch.bfloat16)
     delta = torch.empty(2 * b * heads * ((Lq + 63) // 64 * 64), dtype=torch.float32, device=q.device)
     if kmask is not None:
         assert kmask.dtype == torch.uint8 and kmask.shape == (b, Lk) and kmask.is_contiguous()
     check(lib().leccr_attn_bwd_s3(ptr(q), ptr(k), ptr(v), ptr(o3), 3 * d, d, ptr(dout), ptr(lse), ptr(kmask),
                                   ptr(dqkv3), ptr(dqkv3[:, d:2 * d]), ptr(dqkv3[:, 2 * d:3 * d]), ptr(delta), b, heads, Lq, Lk, d // heads,
-                                  q.stride(1), k.stride(1), v.stride(1), dout.stride(1), 9 * d, 3 * d, float(drop_p), int(seed), stream()),
+                                  q.stride(1), k.stride(1), v.stride(1), dout.stride(1), 9 * d, 3 * d, ptr(bias_sum), float(drop_p), int(seed), stream()),
           'leccr_attn_bwd_s3')
     return dqkv3
 

@@ -737,11 +737,10 @@ class ViTBlockFn(torch.autograd.Function):
         do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8, g8=g1_8).view(b, N, d)
         if o is None:
             # mode X3 with the attention kernels' own operand copies (forward above): o exists as o_8 only, and the gradient of the packed qkv
-            # is written as in_proj's G-form copy only; in_proj's bias gradient = column sums of the copy's hi and lo segments
+            # is written as in_proj's G-form copy only; in_proj's bias gradient is summed by the same kernels from the tiles they stage
             lin_dw(g1, o_8.new_empty((0, d), dtype=torch.float32), blk.attn.out_proj.weight, blk.attn.out_proj.bias, g8=g1_8, x8=o_8)
-            dqkv3 = K.attn_bwd_s3(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o_8, do, lse, blk.heads)
-            K.colsum(dqkv3[:, :3 * d], blk.attn.in_proj_bias._g.reshape(-1))
-            K.colsum(dqkv3[:, 3 * d:6 * d], blk.attn.in_proj_bias._g.reshape(-1))
+            dqkv3 = K.attn_bwd_s3(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o_8, do, lse, blk.heads,
+                                  bias_sum=blk.attn.in_proj_bias._g.reshape(-1))
             _mark(blk.attn.in_proj_bias)
             dqkv3._bias_done = True
             dh1 = lin_dx(None, blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv3)

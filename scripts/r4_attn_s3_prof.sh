@@ -7,6 +7,6 @@ for m in 1 0; do
 done
 cd $R
 for m in 1 0; do
-  python3 scripts/steady_stats.py $(find gpurun_out/prof_s3_$m -name "*kernel_trace.csv" | head -1) "X3_ATTN=$m" "-" > gpurun_out/prof_s3_$m.md
+  python3 scripts/steady_stats.py $(find gpurun_out/prof_s3_$m -name "*kernel_trace.csv" | head -1) "fp32 step, LECCR_X3_ATTN=$m" "scripts/r4_attn_s3_prof.sh" > gpurun_out/prof_s3_$m.md
   grep -i "x3a\|split3\|colsum\|steady-state" gpurun_out/prof_s3_$m.md | cut -c1-140
 done

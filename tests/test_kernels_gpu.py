@@ -1461,6 +1461,14 @@ def test_attention_f32_writes_the_operand_copies_of_its_outputs(K, b, heads, L, 
         assert e <= 3e-5 * s_, (name, e, s_)            # delta from hi + lo of o (2^-17) and the copy's own 2^-17
     # rows a key-padding mask removes entirely and the copy's layout: hi = bf16(x) exactly where the plain gradient is finite
     assert torch.equal(hi.float()[torch.isfinite(ref)].bfloat16().view(torch.int16), hi[torch.isfinite(ref)].view(torch.int16))
+    # bias_sum: += the column sums of [dq | dk | dv] as the copy's readers see them (hi + lo), summed inside the kernels; same copy beside it
+    bias0 = _rand((3 * d,), torch.float32, 213).to(DEV)
+    bsum = bias0.clone()
+    g3b = K.attn_bwd_s3(q, k, v, o3, do, lse, heads, kmask, drop_p=drop, seed=78, bias_sum=bsum)
+    assert torch.equal(g3b.view(torch.int16), g3.view(torch.int16))
+    want_b = bias0.double() + got.double().sum(0)
+    e, s_ = float((bsum.double() - want_b).abs().max()), float(got.double().abs().sum(0).max())
+    assert e <= 2e-6 * s_ + 1e-7, (e, s_)
     # not a problem of these kernels: other head sizes
     assert not K.attn_s3_takes(qkv[..., :heads * 32], qkv[..., heads * 32:heads * 64], qkv[..., heads * 64:heads * 96], heads)
 
