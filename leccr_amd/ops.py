@@ -145,6 +145,7 @@ X3 = 'x3'
 fuse_x3_copies = os.environ.get('LECCR_X3_FUSE', '1') != '0'      # the GEMM epilogues write the split copies of the 4d-wide MLP tensors
 ln_x3_copies = os.environ.get('LECCR_X3_LN', '1') != '0'       # .. and the encoder blocks' LayerNorm passes write h1 / h2 as split copies only
 attn_x3_copies = os.environ.get('LECCR_X3_ATTN', '1') != '0'   # .. and the attention kernels write o / dqkv as the copies out_proj / in_proj read
+share_x3_copies = os.environ.get('LECCR_X3_SHARE', '1') != '0'   # .. and the Linears outside the blocks make one copy per operand for all their products
 
 
 def _x3_lin_ok(rows, w):
@@ -233,6 +234,7 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
     it).  want8: return (y, y8 or None) instead of y.  c8_only (fp8_only_ok): y itself is not written, (None, y8) comes back."""
     if fp8 == X3 and _is_x3(x8):              # f32 operands as bf16 hi / lo splits: x8 = X-form copy of x2, the weight split in G form
         w3 = K.split3(w._lp, K.FORM_G)
+        K.f32_split_launches += 1             # (counted like the products kernels.gemm splits by itself)
         if want8 and c3_consumer is not None and fuse_x3_copies and K.NS == 3 and _x3_lin_ok(x8.shape[0], c3_consumer):
             # the Linear that consumes this output reads only its X-form split copy (forward and weight-gradient product): the GEMM's
             # epilogue writes that copy from its registers, and where the 256 x 256 kernel takes the shape the f32 output is not
@@ -259,6 +261,7 @@ def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False,
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
     if fp8 == X3 and _is_x3(g8):              # G-form copy of dY against the X-form split of W^T ([in, 3 out], K-contiguous)
         w3t = K.split3(w._lp, K.FORM_X, transpose=True)
+        K.f32_split_launches += 1
         if want8 and c3_consumer is not None and fuse_x3_copies and K.NS == 3 and _x3_lin_ok(g8.shape[0], c3_consumer) \
                 and K.gemm256_takes(g8.shape[0], w3t.shape[0], w3t.shape[1]):
             # the gradient this product writes is read only through its G-form copy (dX and weight-gradient product of the consumer):
@@ -478,6 +481,7 @@ def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None, bias_done=Fals
     if _is_x3(g8):
         # f32 operands as bf16 hi / lo splits: the [rows, 3 cols] copies read as [3 rows, cols], one TN launch over 3 x rows
         rows = g8.shape[0]
+        K.f32_split_launches += 1
         K.gemm(g8.view(K.NS * rows, g8.shape[1] // K.NS), x8.view(K.NS * rows, x8.shape[1] // K.NS), trans_a=True, trans_b=True, out=w._g,
                accumulate=True, alpha=scale)
         fused = False           # (the split copy's own column sums would count hi twice: colsum over the f32 gradient below)
@@ -545,17 +549,31 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, wgrad_scale, out_f32):
         x2 = x if x.dim() == 2 else _rows(x)
-        y = lin_fwd(x2, weight, bias, out_dtype=torch.float32 if out_f32 else None)
-        ctx.save_for_backward(x2)
+        # fp32 path, a Linear large enough for the split-operand kernels (the projections over all image tokens): one X-form copy of x
+        # serves the forward and the weight-gradient product, one G-form copy of dy the dX and the weight-gradient product (each
+        # product splitting its own operands made four passes of these two)
+        x8 = x8_of(X3, x2, weight) if (share_x3_copies and x2.dtype == torch.float32) else None
+        if x8 is not None:
+            y = lin_fwd(x2, weight, bias, fp8=X3, x8=x8)
+        else:
+            y = lin_fwd(x2, weight, bias, out_dtype=torch.float32 if out_f32 else None)
+        ctx.save_for_backward(x2, x8)
         ctx.w, ctx.b, ctx.shape, ctx.scale = weight, bias, x.shape, wgrad_scale
         return y.view(*x.shape[:-1], y.shape[-1])
 
     @staticmethod
     def backward(ctx, dy):
-        (x2,) = ctx.saved_tensors
+        x2, x8 = ctx.saved_tensors
         dy2 = dyf = _rows(dy.contiguous())
         if dy2.dtype != x2.dtype:               # f32 head output: the GEMM operands share the compute dtype
             dy2 = dy2.to(x2.dtype)
+        g8 = None
+        if x8 is not None:
+            g8 = g8_of(X3, dy2, ctx.w, bias=ctx.b if ctx.scale == 1.0 else None)
+        if g8 is not None:
+            dx = lin_dx(dy2, ctx.w, fp8=X3, g8=g8).view(ctx.shape) if ctx.needs_input_grad[0] else None
+            lin_dw(dy2, x2, ctx.w, ctx.b, ctx.scale, g8=g8, x8=x8)
+            return dx, None, None, None, None
         dx = lin_dx(dy2, ctx.w).view(ctx.shape) if ctx.needs_input_grad[0] else None
         lin_dw(dy2, x2, ctx.w, ctx.b, ctx.scale, dy_bias=None if dyf is dy2 else dyf)
         return dx, None, None, None, None
@@ -781,21 +799,33 @@ class LnProjFn(torch.autograd.Function):
         b, N, d = x.shape
         h, mean, rstd, _ = K.layernorm_fwd(x, ln_w.data, ln_b.data, 1e-5)
         # proj [d, vw]: B(n, k) = proj[k, n]  -> the [vw, d] K-contiguous copy is proj._lpt
-        y = K.gemm(_rows(h), proj._lpt) if proj._lpt is not None else K.gemm(_rows(h), proj._lp, trans_b=True)
-        ctx.save_for_backward(x, h, mean, rstd)
+        h3 = None
+        if share_x3_copies and proj._lpt is None and K._split_plan(_rows(h), proj._lp, False, True, None, False, None) is not None and K.NS == 3:
+            h3 = K.split3(_rows(h), K.FORM_X)          # fp32 path: one copy of h for this product and for dproj = H^T dY
+        if h3 is not None:
+            y = K.gemm(_rows(h), proj._lp, trans_b=True, a3=(h3, K.FORM_X))
+        else:
+            y = K.gemm(_rows(h), proj._lpt) if proj._lpt is not None else K.gemm(_rows(h), proj._lp, trans_b=True)
+        ctx.save_for_backward(x, h, mean, rstd, h3)
         ctx.p = (ln_w, ln_b, proj)
         return y.view(b, N, -1)
 
     @staticmethod
     def backward(ctx, dy):
-        x, h, mean, rstd = ctx.saved_tensors
+        x, h, mean, rstd, h3 = ctx.saved_tensors
         ln_w, ln_b, proj = ctx.p
         _fire(ln_w, 'on_late_backward_start')
         _fire(ln_w, 'on_early_grads_final')
         b, N, d = x.shape
         dy2 = _rows(dy.contiguous())
-        dh = K.gemm(dy2, proj._lp)                                    # dH = dY @ proj^T : B(n=d, k=vw) = proj[n, k]
-        K.gemm(_rows(h), dy2, trans_a=True, trans_b=True, out=proj._g, accumulate=True)   # dproj[d,vw] = H^T dY
+        if h3 is not None and dy2.dtype == torch.float32 and K._split_plan(dy2, proj._lp, False, False, None, False, None) is not None \
+                and K._split_plan(_rows(h), dy2, True, True, proj._g, True, None) is not None:
+            dy3 = K.split3(dy2, K.FORM_G)              # .. and one copy of dY for dH and dproj
+            dh = K.gemm(dy2, proj._lp, a3=(dy3, K.FORM_G))
+            K.gemm(_rows(h), dy2, trans_a=True, trans_b=True, out=proj._g, accumulate=True, a3=(h3, K.FORM_X), b3=(dy3, K.FORM_G))
+        else:
+            dh = K.gemm(dy2, proj._lp)                                    # dH = dY @ proj^T : B(n=d, k=vw) = proj[n, k]
+            K.gemm(_rows(h), dy2, trans_a=True, trans_b=True, out=proj._g, accumulate=True)   # dproj[d,vw] = H^T dY
         _mark(proj)
         dx = K.layernorm_bwd(dh.view(b, N, d), x, ln_w.data, mean, rstd, ln_w._g, ln_b._g)
         _mark(ln_w)
@@ -947,28 +977,40 @@ class CrossAttnLayerFn(torch.autograd.Function):
         seeds = (_next_seed(), _next_seed(), _next_seed())
         wq, wkv = _Slice(mha.in_proj_weight, 0, d), _Slice(mha.in_proj_weight, d, 3 * d)
         bq, bkv = _Slice(mha.in_proj_bias, 0, d), _Slice(mha.in_proj_bias, d, 3 * d)
-        q = lin_fwd(_rows(tgt), wq, bq).view(b, Lq, d)
-        kv = lin_fwd(_rows(memory), wkv, bkv).view(b, Lk, 2 * d)
+        # fp32 path (m = X3): a Linear large enough for the split-operand kernels - the ones over all image tokens - makes ONE X-form copy of
+        # its input for the forward and the weight-gradient product (and one G-form copy of its incoming gradient in the backward)
+        m = X3 if (share_x3_copies and tgt.dtype == torch.float32) else False
+        tq8 = x8_of(m, _rows(tgt), wq)
+        q = lin_fwd(_rows(tgt), wq, bq, fp8=m, x8=tq8).view(b, Lq, d)
+        mem8 = x8_of(m, _rows(memory), wkv)
+        kv = lin_fwd(_rows(memory), wkv, bkv, fp8=m, x8=mem8).view(b, Lk, 2 * d)
         o, lse = K.attn_fwd(q, kv[..., :d], kv[..., d:], layer.heads, kmask, pd, seeds[0])
-        a = lin_fwd(_rows(o), mha.out_proj.weight, mha.out_proj.bias)
+        o8 = x8_of(m, _rows(o), mha.out_proj.weight)
+        a = lin_fwd(_rows(o), mha.out_proj.weight, mha.out_proj.bias, fp8=m, x8=o8)
         pre = torch.empty_like(a)
-        h = lin_fwd(a, layer.linear1.weight, layer.linear1.bias, epilogue=EPI_GELU, aux_out=pre)
+        a8 = x8_of(m, a, layer.linear1.weight)
+        h = lin_fwd(a, layer.linear1.weight, layer.linear1.bias, fp8=m, x8=a8, epilogue=EPI_GELU, aux_out=pre)
         if pd > 0:
             K.dropout(h, pd, seeds[1], out=h)
-            l2 = lin_fwd(h, layer.linear2.weight, layer.linear2.bias)
+            h8 = x8_of(m, h, layer.linear2.weight)
+            l2 = lin_fwd(h, layer.linear2.weight, layer.linear2.bias, fp8=m, x8=h8)
             y, mean, rstd, s = K.layernorm_fwd(l2.view(b, Lq, d), layer.norm2.weight.data, layer.norm2.bias.data, 1e-5,
                                                add=tgt.contiguous(), want_sum=True, drop=(pd, seeds[2]))
         else:
-            s = lin_fwd(h, layer.linear2.weight, layer.linear2.bias, residual=_rows(tgt)).view(b, Lq, d)
+            h8 = x8_of(m, h, layer.linear2.weight)
+            s = lin_fwd(h, layer.linear2.weight, layer.linear2.bias, fp8=m, x8=h8, residual=_rows(tgt)).view(b, Lq, d)
             y, mean, rstd, _ = K.layernorm_fwd(s, layer.norm2.weight.data, layer.norm2.bias.data, 1e-5)
-        ctx.save_for_backward(tgt, memory, kmask, q, kv, o, lse, a, pre, h, s, mean, rstd)
+        # (a and h are read by nothing but their Linear's weight-gradient product: with a copy at hand the f32 tensors are not kept)
+        ctx.save_for_backward(tgt, memory, kmask, q, kv, o, lse, dw_keep(a, a8, layer.linear1.weight), pre, dw_keep(h, h8, layer.linear2.weight),
+                              s, mean, rstd, tq8, mem8, o8, a8, h8)
         ctx.layer, ctx.drop = layer, (pd, seeds)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        tgt, memory, kmask, q, kv, o, lse, a, pre, h, s, mean, rstd = ctx.saved_tensors
+        tgt, memory, kmask, q, kv, o, lse, a, pre, h, s, mean, rstd, tq8, mem8, o8, a8, h8 = ctx.saved_tensors
         layer = ctx.layer
+        mode = lambda x8: X3 if _is_x3(x8) else False          # (a Linear whose forward ran on its input's split copy)
         pd, seeds = ctx.drop
         mha = layer.multihead_attn
         b, Lq, d = tgt.shape
@@ -980,22 +1022,27 @@ class CrossAttnLayerFn(torch.autograd.Function):
         _mark(layer.norm2.weight)
         _mark(layer.norm2.bias)
         gs, gd = (_rows(ds[0]), _rows(ds[1])) if pd > 0 else (_rows(ds), _rows(ds))
-        dpre = lin_dx(gd, layer.linear2.weight, epilogue=EPI_DGELU, aux=pre)      # (g W2) * gelu'(pre) ...
+        g8 = g8_of(mode(h8), gd, layer.linear2.weight, bias=layer.linear2.bias)
+        dpre = lin_dx(gd, layer.linear2.weight, fp8=mode(h8), g8=g8, epilogue=EPI_DGELU, aux=pre)      # (g W2) * gelu'(pre) ...
         if pd > 0:
             K.dropout(dpre, pd, seeds[1], out=dpre)                               # ... * dropout mask (both elementwise)
-        lin_dw(gd, h, layer.linear2.weight, layer.linear2.bias)
-        da = lin_dx(dpre, layer.linear1.weight)
-        lin_dw(dpre, a, layer.linear1.weight, layer.linear1.bias)
-        do = lin_dx(da, mha.out_proj.weight).view(b, Lq, d)
-        lin_dw(da, _rows(o), mha.out_proj.weight, mha.out_proj.bias)
+        lin_dw(gd, h, layer.linear2.weight, layer.linear2.bias, g8=g8, x8=h8)
+        g8 = g8_of(mode(a8), dpre, layer.linear1.weight, bias=layer.linear1.bias)
+        da = lin_dx(dpre, layer.linear1.weight, fp8=mode(a8), g8=g8)
+        lin_dw(dpre, a, layer.linear1.weight, layer.linear1.bias, g8=g8, x8=a8)
+        g8 = g8_of(mode(o8), da, mha.out_proj.weight, bias=mha.out_proj.bias)
+        do = lin_dx(da, mha.out_proj.weight, fp8=mode(o8), g8=g8).view(b, Lq, d)
+        lin_dw(da, _rows(o), mha.out_proj.weight, mha.out_proj.bias, g8=g8, x8=o8)
         dq = torch.empty_like(q)
         dkv = torch.empty_like(kv)
         K.attn_bwd(q, kv[..., :d], kv[..., d:], o, do, lse, layer.heads, kmask, dq=dq, dk=dkv[..., :d],
                    dv=dkv[..., d:], drop_p=pd, seed=seeds[0])
-        dtgt = lin_dx(_rows(dq), wq, residual=gs).view(b, Lq, d) if ctx.needs_input_grad[0] else None
-        lin_dw(_rows(dq), _rows(tgt), wq, bq)
-        dmem = lin_dx(_rows(dkv), wkv).view(b, Lk, d) if ctx.needs_input_grad[1] else None
-        lin_dw(_rows(dkv), _rows(memory), wkv, bkv)
+        g8 = g8_of(mode(tq8), _rows(dq), wq, bias=bq)
+        dtgt = lin_dx(_rows(dq), wq, fp8=mode(tq8), g8=g8, residual=gs).view(b, Lq, d) if ctx.needs_input_grad[0] else None
+        lin_dw(_rows(dq), _rows(tgt), wq, bq, g8=g8, x8=tq8)
+        g8 = g8_of(mode(mem8), _rows(dkv), wkv, bias=bkv)
+        dmem = lin_dx(_rows(dkv), wkv, fp8=mode(mem8), g8=g8).view(b, Lk, d) if ctx.needs_input_grad[1] else None
+        lin_dw(_rows(dkv), _rows(memory), wkv, bkv, g8=g8, x8=mem8)
         return (dtgt, dmem, None, None) + (None,) * len(ctx.needs_input_grad[4:])
 
 

@@ -416,7 +416,8 @@ def test_persistent_gemm_paths_in_a_model_vs_oracle():
 
 def test_fp32_attention_and_layernorm_written_copies_change_nothing(monkeypatch):
     """fp32 path, ViT-B/16 @384 (one layer, b = 8: 4616 token rows, head size 64): with the operand copies written by their producers - the
-    LayerNorm passes (h1 / h2), the attention kernels (o, the gradient of the packed qkv) - every loss and every parameter gradient equals
+    LayerNorm passes (h1 / h2), the attention kernels (o, the gradient of the packed qkv), one shared copy per operand in the Linears over all
+    image tokens outside the blocks (ln_post + proj, the caption interaction, vproj) - every loss and every parameter gradient equals
     the run in which each product splits its own f32 operand, to the pair form's own precision (the backward's delta reads o as hi + lo)."""
     from leccr_amd import kernels as K, ops
     from leccr_amd.synthetic import make_batch
@@ -433,6 +434,7 @@ def test_fp32_attention_and_layernorm_written_copies_change_nothing(monkeypatch)
     def run(on):
         monkeypatch.setattr(ops, 'attn_x3_copies', on)
         monkeypatch.setattr(ops, 'ln_x3_copies', on)
+        monkeypatch.setattr(ops, 'share_x3_copies', on)         # .. and one copy per operand in the Linears outside the blocks
         losses = _forward(model, batch)
         model.arena.zero_grad()
         sum(losses).backward()
@@ -443,12 +445,13 @@ def test_fp32_attention_and_layernorm_written_copies_change_nothing(monkeypatch)
     l0, g0 = run(False)
     assert calls == {'fwd': 1, 'bwd': 1}
     assert max(abs(a - b) for a, b in zip(l1, l0)) <= 1e-5
-    bad = []
-    for k in g0:
-        e, s_ = float((g1[k] - g0[k]).abs().max()), float(g0[k].abs().max())
-        if e > 5e-5 * s_ + 1e-9:
-            bad.append((k, e, s_))
-    assert len(g0) > 100 and not bad, bad[:8]
+    # two evaluation orders of the same pair-form arithmetic (2^-17 per product term; the bias sums taken from hi + lo instead of the f32
+    # tensor): measured worst 8e-5 of a tensor's largest gradient (class_embedding, out_proj.bias), held to 2e-4.  The packed in-projection
+    # biases get 1e-3: their key third is a sum that cancels exactly in exact arithmetic (softmax does not see a constant added to every
+    # key), i.e. pure rounding noise of whichever order summed it - measured 3.1e-4 of the tensor's largest entry.
+    worst = sorted(((float((g1[k] - g0[k]).abs().max()) / (float(g0[k].abs().max()) + 1e-12), k) for k in g0), reverse=True)
+    bad = [(r, k) for r, k in worst if r > (1e-3 if k.endswith('in_proj_bias') else 2e-4)]
+    assert len(g0) > 100 and not bad, (bad[:5], worst[:5])
 
 
 def test_fp8_weight_copies_and_their_scale_stay_together_when_a_weight_grows():
