@@ -86,3 +86,17 @@ def test_kernel_sources_define_each_switch_once():
         if dup:
             bad[os.path.basename(f)] = dup
     assert not bad, bad
+
+
+def test_attn_s3_takes_is_a_host_side_answer():
+    """leccr_attn_s3_takes decides without touching a device which attention problems the copy-writing fp32 kernels run (ops.ViTBlockFn asks it
+    before every block): head size 64, row strides % 4 == 0, copy rows and segments 16-byte aligned, segments at least heads * hd wide."""
+    from leccr_amd._lib import lib
+    t = lib().leccr_attn_s3_takes
+    d = 12 * 64
+    assert t(4, 12, 577, 577, 64, 3 * d, 3 * d, 3 * d, 9 * d, 3 * d) == 1          # packed qkv, the gradient's copy
+    assert t(4, 12, 577, 577, 64, 3 * d, 3 * d, 3 * d, 3 * d, d) == 1              # .. and o's copy
+    assert t(4, 12, 577, 577, 32, 3 * 384, 3 * 384, 3 * 384, 9 * 384, 3 * 384) == 0      # head size 32
+    assert t(4, 12, 577, 577, 64, 3 * d + 2, 3 * d, 3 * d, 9 * d, 3 * d) == 0      # a row stride that is not a multiple of 4
+    assert t(4, 12, 577, 577, 64, 3 * d, 3 * d, 3 * d, 9 * d + 4, 3 * d) == 0      # copy rows not 16-byte aligned
+    assert t(4, 12, 577, 577, 64, 3 * d, 3 * d, 3 * d, 3 * d, d - 64) == 0         # a segment narrower than the heads need
