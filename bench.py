@@ -667,9 +667,10 @@ def _main(args, real_stdout):
                      'bf16': {'launches_per_step': bf_n // max(1, leg), 'ms_per_step': round(bf_ms / max(1, leg), 3),
                               'tflops': round(bf_fl / (bf_ms * 1e-3) / 1e12, 1) if bf_ms > 0 else None, 'peak': MFMA_BF16_PEAK_TFLOPS}}
         traffic, traffic_src = None, None
-        tj = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_gemm256_hbm_traffic.json') for r in (4, 3, 2, 1))
+        suf = '' if args.dtype == 'bf16' else '_' + args.dtype
+        tj = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_gemm256_hbm_traffic{suf}.json') for r in (4, 3, 2, 1))
                    if os.path.exists(p)), '')
-        if tj and args.model == 'image' and args.clip == 'ViT-B/16' and args.batch == 256 and args.dtype == 'bf16':
+        if tj and args.model == 'image' and args.clip == 'ViT-B/16' and args.batch == 256 and args.dtype in ('bf16', 'fp32'):
             with open(tj) as fh:        # PMC counters cannot be read from inside the run: the committed rocprofv3 passes
                 tr = json.load(fh)      # of this same command (FETCH_SIZE x2 + WRITE_SIZE, per launch) are reported
             traffic, traffic_src = round(tr['hbm_bytes_per_launch']), 'profiles/' + os.path.basename(tj)
