@@ -256,7 +256,10 @@ int leccr_attn_bwd_causal(const void* q, const void* k, const void* v, const voi
  * them, under `site` = {amax, scale, 1/scale, fmt} with the contract of leccr_fp8_quantize (quantised from the f32 values, site.amax
  * accumulates max |value|): o8 [b*Lq, heads*hd] e4m3 (the out_proj input), dq8 / dk8 / dv8 e5m2 under ONE site (the three column
  * blocks of the packed in_proj gradient; row stride ld8 bytes).  Written by the attention kernels' own epilogues where the variant that
- * runs has them (MFMA head-64 kernels: the 32-query forward kernels, every backward), by quantise passes otherwise. */
+ * runs has them (MFMA head-64 kernels: the 32-query forward kernels, every backward), by quantise passes otherwise.
+ * leccr_attn_bwd_q8 with dq = dk = dv = NULL (round 4): only the e5m2 copies are written - for the fp8 step, where the in_proj dX and
+ * weight-gradient products (and the bias sums inside the latter) read nothing else and the bf16 gradient is 2/3 of the kernels' output
+ * bytes; accepted where the head-64 bf16 MFMA kernels run the problem (else LECCR_EINVAL). */
 int leccr_attn_fwd_q8(const void* q, const void* k, const void* v, void* o, float* lse, const uint8_t* kmask, int64_t b,
                       int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                       int dtype, float drop_p, uint64_t seed, void* o8, int64_t ldo8, float* site, void* stream);

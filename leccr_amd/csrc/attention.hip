@@ -103,11 +103,17 @@ static int attn_bwd_impl(const void* q, const void* k, const void* v, const void
                          int64_t b, int64_t heads, int64_t Lq, int64_t Lk, int64_t hd, int64_t ldq, int64_t ldk,
                          int64_t ldv, int64_t ldo, int dtype, float drop_p, uint64_t seed, void* stream, const AttnQ8* q8, bool* fused,
                          bool causal = false) {
-    LECCR_REQUIRE(q && k && v && o && dout && lse && dq && dk && dv && delta, LECCR_EINVAL, "attn_bwd: null pointer");
+    // (leccr_attn_bwd_q8: dq = dk = dv = NULL asks for the e5m2 copies alone - the head-64 MFMA kernels write them from their registers)
+    const bool only8 = !dq && !dk && !dv && q8 && q8->dq8 && q8->dk8 && q8->dv8;
+    LECCR_REQUIRE(q && k && v && o && dout && lse && ((dq && dk && dv) || only8) && delta, LECCR_EINVAL, "attn_bwd: null pointer");
     LECCR_REQUIRE(drop_p >= 0.f && drop_p < 1.f, LECCR_EINVAL, "attn_bwd: drop_p must be in [0,1)");
     AttnDims D{b, heads, Lq, Lk, hd, ldq, ldk, ldv, ldo, make_drop(drop_p, seed), drop_p > 0.f};
     D.causal = causal;
     if (int rc = check_dims("attn_bwd", D, dtype)) return rc;
+    if (only8)
+        LECCR_REQUIRE(!causal && !g_force_generic_attn && attn_mfma_supported(D, dtype) && !(thin_first() && attn_thin_kind(D, dtype)) &&
+                          (q8->ld8 & 3) == 0 && (((uintptr_t)q8->dq8 | (uintptr_t)q8->dk8 | (uintptr_t)q8->dv8) & 3) == 0,
+                      LECCR_EINVAL, "attn_bwd_q8: the copies alone (null dq / dk / dv) exist on the head-64 bf16 MFMA kernels only (4-byte aligned copies)");
     if (b == 0 || Lq == 0) return LECCR_OK;
     hipStream_t st = as_stream(stream);
     ProfScope prof(PROF_ATTN_BWD, 10.0 * (double)b * heads * Lq * Lk * hd, st);

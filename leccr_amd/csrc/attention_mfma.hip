@@ -1552,10 +1552,12 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
         if (key[g] < p.Lk) {
             bf16_t* dkp = p.dk + (b * p.Lk + key[g]) * p.ldk + head * HD;
             bf16_t* dvp = p.dv + (b * p.Lk + key[g]) * p.ldv + head * HD;
+            if (p.dk) {             // (null: only the e5m2 copies below are wanted)
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) {
-                store4(dkp + nd * 16 + 4 * h4, dk[g][nd] * p.scale);
-                store4(dvp + nd * 16 + 4 * h4, dv[g][nd]);
+                for (int nd = 0; nd < 4; ++nd) {
+                    store4(dkp + nd * 16 + 4 * h4, dk[g][nd] * p.scale);
+                    store4(dvp + nd * 16 + 4 * h4, dv[g][nd]);
+                }
             }
             if (q8) {
                 uint8_t* dk8 = p.dk8 + (b * p.Lk + key[g]) * p.ld8 + head * HD;
@@ -1780,8 +1782,10 @@ __global__ __launch_bounds__(NW * 64, (DROP || KG == 2) ? 2 : BWD_WPE) void flas
     for (int g = 0; g < KG; ++g) {
         if (qi[g] < p.Lq) {
             bf16_t* dqp = p.dq + (b * p.Lq + qi[g]) * p.ldq + head * HD;
+            if (p.dq) {             // (null: only the e5m2 copy below is wanted - fp8 mode, where nothing reads the bf16 gradient: leccr_attn_bwd_q8)
 #pragma unroll
-            for (int nd = 0; nd < 4; ++nd) store4(dqp + nd * 16 + 4 * h4, dq[g][nd] * p.scale);
+                for (int nd = 0; nd < 4; ++nd) store4(dqp + nd * 16 + 4 * h4, dq[g][nd] * p.scale);
+            }
             if (q8) {
                 uint8_t* dq8 = p.dq8 + (b * p.Lq + qi[g]) * p.ld8 + head * HD;
 #pragma unroll

@@ -348,17 +348,21 @@ def attn_bwd_s3(q, k, v, o3, dout, lse, heads, kmask=None, drop_p=0.0, seed=0, b
     return dqkv3
 
 
-def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None, drop_p=0.0, seed=0, q8=None, causal=False):
-    """q8 = (dq8, dk8, dv8, site): e5m2 copies of the three gradients (views of one packed [b, L, 3 d] byte tensor) under one primed site."""
+def attn_bwd(q, k, v, o, dout, lse, heads, kmask=None, dq=None, dk=None, dv=None, drop_p=0.0, seed=0, q8=None, causal=False, write_bf16=True):
+    """q8 = (dq8, dk8, dv8, site): e5m2 copies of the three gradients (views of one packed [b, L, 3 d] byte tensor) under one primed site.
+    write_bf16=False (with q8, head size 64, bf16): only those copies are written -> (None, None, None)."""
     b, Lq, Lk = _attn_args(q, k, v)
     d = q.shape[2]
     hd = d // heads
     assert o.is_contiguous() and dout.is_contiguous() and dout.shape == o.shape
     # gradients must have the strides of their inputs (the model passes views of one packed dqkv buffer)
-    dq = torch.empty_strided(q.shape, q.stride(), device=q.device, dtype=q.dtype) if dq is None else dq
-    dk = torch.empty_strided(k.shape, k.stride(), device=q.device, dtype=q.dtype) if dk is None else dk
-    dv = torch.empty_strided(v.shape, v.stride(), device=q.device, dtype=q.dtype) if dv is None else dv
-    assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    if write_bf16:
+        dq = torch.empty_strided(q.shape, q.stride(), device=q.device, dtype=q.dtype) if dq is None else dq
+        dk = torch.empty_strided(k.shape, k.stride(), device=q.device, dtype=q.dtype) if dk is None else dk
+        dv = torch.empty_strided(v.shape, v.stride(), device=q.device, dtype=q.dtype) if dv is None else dv
+        assert dq.stride(1) == q.stride(1) and dk.stride(1) == k.stride(1) and dv.stride(1) == v.stride(1)
+    else:
+        assert q8 is not None and not causal and dq is None and dk is None and dv is None
     # workspace: two rows of constants per (b, head, query), queries padded to a multiple of 64 (see leccr_hip.h)
     delta = torch.empty(2 * b * heads * ((Lq + 63) // 64 * 64), dtype=torch.float32, device=q.device)
     if causal:

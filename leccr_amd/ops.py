@@ -134,6 +134,7 @@ def _fp8_ok(x2, w8):
 fp8_dw = os.environ.get('LECCR_FP8_DW', '1') != '0'
 fp8_dw_launches = 0          # fp8 weight-gradient products launched (tests read it)
 fp8_bias_asum = os.environ.get('LECCR_FP8_BIAS_ASUM', '1') != '0'      # bias gradients summed inside those launches (from the e5m2 copy)
+attn_q8_only = os.environ.get('LECCR_FP8_ATTN_COPY_ONLY', '1') != '0'      # the ViT attention backward writes only the e5m2 copy of dqkv where nothing reads the bf16 one
 
 
 # fp32 mode (compute_dtype 'fp32' with kernels.f32_mfma): the encoder blocks carry mode X3 in their `fp8` attribute and the SAME
@@ -385,7 +386,7 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_d
     if _is_x3(g8):
         bias_done = bias_done or getattr(g8, '_bias_done', False)
     elif dy2 is None:
-        assert g8.shape[0] % 128 == 0 and (b is None or bias_done)
+        assert g8.shape[0] % 128 == 0 and (b is None or bias_done or (fp8_bias_asum and fuse_bias_grad and scale == 1.0 and dy_bias is None))
     ref = dy2 if dy2 is not None else g8
     # fp32 path: the weight-gradient products stay on the main stream.  Their launches are long (reduction over 3 x rows) persistent
     # kernels that hold every CU, and the fp32 step's main chain is full of short HBM-bound launches (split passes, LayerNorm) that then
@@ -765,17 +766,27 @@ class ViTBlockFn(torch.autograd.Function):
             lin_dw(None, h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv3, x8=h1_8)
             return ViTBlockFn._finish_backward(ctx, blk, b, N, d, dh1, x, mean1, rstd1, dx1)
         lin_dw(g1, _rows(o), blk.attn.out_proj.weight, blk.attn.out_proj.bias, g8=g1_8, x8=o_8)
-        dqkv = torch.empty_like(qkv)
         g_site = _q8_site(blk.fp8, b * N, blk.attn.in_proj_weight, '_gsite')
         dqkv8 = None
         if g_site is not None and g_site.primed and not getattr(blk, 'causal', False):
             dqkv8 = torch.empty(qkv.shape, device=qkv.device, dtype=g_site.torch_dtype)
+        # fp8: when in_proj's dX and weight-gradient products both read the e5m2 copy (and the bias sums ride in the latter), nothing reads
+        # the bf16 gradient of the packed qkv: the attention kernels write the copy alone - a third of their output bytes
+        only8 = (dqkv8 is not None and attn_q8_only and fp8_bias_asum and fuse_bias_grad and d // blk.heads == 64 and h1_8 is not None
+                 and fp8_only_ok(b * N, blk.attn.in_proj_weight, True))
+        dqkv = None if only8 else torch.empty_like(qkv)
         K.attn_bwd(qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:], o, do, lse, blk.heads,
-                   dq=dqkv[..., :d], dk=dqkv[..., d:2 * d], dv=dqkv[..., 2 * d:], causal=getattr(blk, 'causal', False),
+                   dq=None if only8 else dqkv[..., :d], dk=None if only8 else dqkv[..., d:2 * d], dv=None if only8 else dqkv[..., 2 * d:],
+                   causal=getattr(blk, 'causal', False), write_bf16=not only8,
                    q8=None if dqkv8 is None else (dqkv8[..., :d], dqkv8[..., d:2 * d], dqkv8[..., 2 * d:], g_site))
-        dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight, None if dqkv8 is None else _rows(dqkv8), bias=blk.attn.in_proj_bias)
-        dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)
-        lin_dw(_rows(dqkv), h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
+        if only8:
+            dqkv8 = _rows(dqkv8)
+            dh1 = lin_dx(dqkv8, blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)
+            lin_dw(None, h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
+        else:
+            dqkv8 = g8_of(blk.fp8, _rows(dqkv), blk.attn.in_proj_weight, None if dqkv8 is None else _rows(dqkv8), bias=blk.attn.in_proj_bias)
+            dh1 = lin_dx(_rows(dqkv), blk.attn.in_proj_weight, fp8=blk.fp8, g8=dqkv8)
+            lin_dw(_rows(dqkv), h1, blk.attn.in_proj_weight, blk.attn.in_proj_bias, g8=dqkv8, x8=h1_8)
         return ViTBlockFn._finish_backward(ctx, blk, b, N, d, dh1, x, mean1, rstd1, dx1)
 
     @staticmethod

@@ -1138,6 +1138,14 @@ def test_attention_writes_the_fp8_copies_its_consumers_need(K, b, L, heads, kmas
     assert float((got - want).abs().gt(0).float().mean()) < 0.2
     amax = float(dqkv.float().abs().max())
     assert abs(float(sg.row[0]) - amax) <= 8e-3 * amax
+    # the copies alone (round 4: the fp8 step reads nothing else of this gradient): same bytes, no bf16 tensor
+    dqkv8b = torch.zeros(b, L, 3 * d, device=DEV, dtype=torch.float8_e5m2)
+    r = K.attn_bwd(q, k, v, o, do, lse, heads, km, q8=(dqkv8b[..., :d], dqkv8b[..., d:2 * d], dqkv8b[..., 2 * d:], sg), write_bf16=False)
+    assert r == (None, None, None) and torch.equal(dqkv8b.view(torch.uint8), dqkv8.view(torch.uint8))
+    with pytest.raises(RuntimeError):                   # other head sizes have no kernel that writes the copies itself
+        q3 = qkv[..., :heads * 32]
+        K.attn_bwd(q3, q3, q3, o[..., :heads * 32].contiguous(), do[..., :heads * 32].contiguous(), lse, heads, km,
+                   q8=(dqkv8b[..., :heads * 32], dqkv8b[..., :heads * 32], dqkv8b[..., :heads * 32], sg), write_bf16=False)
 
 
 def test_gemm_fp8_rejects_what_it_does_not_implement(K):
