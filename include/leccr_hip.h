@@ -201,7 +201,8 @@ int leccr_layernorm_bwd_drop(const void* dy, const void* x_in, const float* gamm
  * consumes it (compute_dtype 'fp8', "fp8 GEMM operands" below): y8 / g8 [rows, d] bytes (8-byte aligned, d % 8 == 0), quantised under
  * `site` = {amax, scale, 1/scale, fmt} exactly as leccr_fp8_quantize would quantise the tensor just written (fwd: y, e4m3 activations;
  * bwd: dx_drop if given else dx, e5m2 gradients), |value| folded into the site's running amax - the separate quantise pass over the
- * tensor is not needed.  NULL y8 / g8: off. */
+ * tensor is not needed.  NULL y8 / g8: off. 
+ * leccr_layernorm_fwd_ex with y = NULL (round 4): only the fp8 copy is written (a pre-LN block's h1 / h2 in the fp8 step are read by nothing else). */
 int leccr_layernorm_fwd_ex(const void* x, const void* add, const float* gamma, const float* beta, void* y,
                            void* sum_out, float* mean, float* rstd, int64_t rows, int64_t d, float eps, float p,
                            uint64_t seed, void* y8, float* y8_site, int y8_fmt, int dtype, void* stream);

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd16_kernel(const bf16_t* __re
             o[j] = (v[s][j] - mm) * rr * g0[j] + b0[j];
             o[4 + j] = (v[s][4 + j] - mm) * rr * g1[j] + b1[j];
         }
-        store8f(y + row * d + m.col[s], o);
+        if (y) store8f(y + row * d + m.col[s], o);          // (null: only the fp8 copy is wanted - leccr_layernorm_fwd_ex)
         if (EX && q8.out) {
             float r[8];
 #pragma unroll
@@ -562,7 +562,7 @@ static int ln_fwd_entry(const void* x, const void* add, const float* gamma, cons
                       "layernorm_fwd_s3: needs the copy's buffer (8-byte aligned), form 0 / 1, f32 rows");
     } else {
         if (int rc = q8_check("layernorm_fwd", y8, y8_site, y8_fmt, d)) return rc;
-        LECCR_REQUIRE(y, LECCR_EINVAL, "layernorm_fwd: null y");
+        LECCR_REQUIRE(y || y8, LECCR_EINVAL, "layernorm_fwd: null y (it may be omitted only beside its fp8 copy)");
     }
     const Q8Out q8{(uint8_t*)y8, y8_site, y8_fmt};
     LECCR_REQUIRE(x && gamma && beta && mean && rstd, LECCR_EINVAL, "layernorm_fwd: null pointer");

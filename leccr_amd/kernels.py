@@ -192,7 +192,8 @@ def _q8_out(site, rows, d, device):
 
 def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None, q8_site=None, s3_form=None, write_y=True):
     """drop = (p, seed): normalise dropout(x) (+ add) - the mask leccr_dropout(x, p, seed) would apply, inside this pass.
-    q8_site (an Fp8Site): also return y's fp8 copy under that site as a 5th value (None until the site is primed).
+    q8_site (an Fp8Site): also return y's fp8 copy under that site as a 5th value (None until the site is primed); write_y=False (primed site):
+    only that copy is written, y comes back None.
     s3_form (f32 rows, 3-segment copies): also return y's bf16 (hi, lo) split copy [rows, 3 d] in that form as a 5th value, written by the
     pass itself; write_y=False then leaves y itself unwritten (None) - for a tensor nothing else reads."""
     x2, rows, d, ld = _rows2d(x)
@@ -211,8 +212,7 @@ def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None, q8_s
         check(lib().leccr_layernorm_fwd_s3(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd), rows, d, eps,
                                            p_, seed_, ptr(y3), s3_form, stream()), 'leccr_layernorm_fwd_s3')
         return (y.view(x.shape) if y is not None else None), mean, rstd, (s.view(x.shape) if s is not None else None), y3
-    assert write_y
-    y = torch.empty_like(x2)
+    y = torch.empty_like(x2) if write_y else None          # (write_y=False: beside a fused fp8 copy only - checked below)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty_like(mean)
     s = torch.empty_like(x2) if want_sum else None
@@ -221,11 +221,13 @@ def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None, q8_s
         assert add.is_contiguous() and add.dtype == x.dtype
     if q8_site is not None:
         y8, site_row, fmt = _q8_out(q8_site, rows, d, x.device)
+        assert write_y or y8 is not None, 'write_y=False needs a primed site (the fp8 copy is then the only output)'
         p_, seed_ = (float(drop[0]), int(drop[1])) if drop is not None else (0.0, 0)
         check(lib().leccr_layernorm_fwd_ex(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd),
                                            rows, d, eps, p_, seed_, ptr(y8), ptr(site_row), fmt, dtype_code(x), stream()),
               'leccr_layernorm_fwd_ex')
-        return y.view(x.shape), mean, rstd, (s.view(x.shape) if s is not None else None), y8
+        return (y.view(x.shape) if y is not None else None), mean, rstd, (s.view(x.shape) if s is not None else None), y8
+    assert write_y
     if drop is not None and drop[0] > 0:
         check(lib().leccr_layernorm_fwd_drop(ptr(x2), ptr(add), ptr(gamma), ptr(beta), ptr(y), ptr(s), ptr(mean), ptr(rstd),
                                              rows, d, eps, float(drop[0]), int(drop[1]), dtype_code(x), stream()),

@@ -82,17 +82,19 @@ def _q8_site(on, rows, w, which):
     return getattr(w, which, None)
 
 
-def _ln_fwd(x, gamma, beta, eps, site=None, x3_for=None, x3_only=False, **kw):
+def _ln_fwd(x, gamma, beta, eps, site=None, x3_for=None, x3_only=False, q8_only=False, **kw):
     """K.layernorm_fwd -> (y, mean, rstd, sum or None, y8 or None): with a site (fp8 mode) the pass also writes y's fp8 copy for the
     product that consumes it - no quantise pass over y.  x3_for (mode X3: the Linear that consumes y): the pass writes y's X-form split
     copy itself (5th value) when that Linear's products run on split copies; x3_only: y then stays unwritten (None) - a pre-LN block's
-    h1 / h2 are read by nothing else."""
+    h1 / h2 are read by nothing else.  q8_only: the same for the fp8 copy (see below)."""
     if x3_for is not None and fuse_x3_copies and ln_x3_copies and K.NS == 3 and x.dtype == torch.float32 and x.is_contiguous() \
             and _x3_lin_ok(x.numel() // x.shape[-1], x3_for):
         return K.layernorm_fwd(x, gamma, beta, eps, s3_form=K.FORM_X, write_y=not x3_only, **kw)
     if site is None:
         return K.layernorm_fwd(x, gamma, beta, eps, **kw) + (None,)
-    return K.layernorm_fwd(x, gamma, beta, eps, q8_site=site, **kw)
+    # q8_only (fp8 mode, fp8_only_ok for the consuming Linear): forward and weight-gradient product both read the e4m3 copy and nothing
+    # reads the bf16 y of a pre-LN block - the pass writes the copy alone (2 of its 5 bytes per element)
+    return K.layernorm_fwd(x, gamma, beta, eps, q8_site=site, write_y=not (q8_only and ln_q8_only and site.primed and x.shape[-1] % 8 == 0), **kw)
 
 
 def _ln_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, site=None, drop=None, **kw):
@@ -135,6 +137,7 @@ fp8_dw = os.environ.get('LECCR_FP8_DW', '1') != '0'
 fp8_dw_launches = 0          # fp8 weight-gradient products launched (tests read it)
 fp8_bias_asum = os.environ.get('LECCR_FP8_BIAS_ASUM', '1') != '0'      # bias gradients summed inside those launches (from the e5m2 copy)
 attn_q8_only = os.environ.get('LECCR_FP8_ATTN_COPY_ONLY', '1') != '0'      # the ViT attention backward writes only the e5m2 copy of dqkv where nothing reads the bf16 one
+ln_q8_only = os.environ.get('LECCR_FP8_LN_COPY_ONLY', '1') != '0'          # the ViT blocks' LayerNorm passes write only the e4m3 copy of h1 / h2 where nothing reads the bf16 one
 
 
 # fp32 mode (compute_dtype 'fp32' with kernels.f32_mfma): the encoder blocks carry mode X3 in their `fp8` attribute and the SAME
@@ -674,8 +677,9 @@ class ViTBlockFn(torch.autograd.Function):
         x3 = blk.fp8 == X3
         h1, mean1, rstd1, _, h1_8 = _ln_fwd(x, blk.ln_1.weight.data, blk.ln_1.bias.data, 1e-5,
                                             site=_q8_site(blk.fp8, M, blk.attn.in_proj_weight, '_xsite'),
-                                            x3_for=blk.attn.in_proj_weight if x3 else None, x3_only=True)
-        h1r = _rows(h1) if h1 is not None else None
+                                            x3_for=blk.attn.in_proj_weight if x3 else None, x3_only=True,
+                                            q8_only=bool(blk.fp8) and not x3 and fp8_only_ok(M, blk.attn.in_proj_weight, False))
+        h1r = _rows(h1) if h1 is not None else (None if x3 else h1_8)          # (fp8: the copy stands in for the tensor's shape)
         h1_8 = x8_of(blk.fp8, h1r, blk.attn.in_proj_weight, h1_8)
         qkv = lin_fwd(h1r, blk.attn.in_proj_weight, blk.attn.in_proj_bias, fp8=blk.fp8, x8=h1_8).view(b, N, 3 * d)
         # (fp8: the attention kernel writes the e4m3 copy of o that out_proj multiplies, the backward the e5m2 copy of dqkv for in_proj)
@@ -698,8 +702,9 @@ class ViTBlockFn(torch.autograd.Function):
                      residual=_rows(x)).view(b, N, d)
         h2, mean2, rstd2, _, h2_8 = _ln_fwd(x1, blk.ln_2.weight.data, blk.ln_2.bias.data, 1e-5,
                                             site=_q8_site(blk.fp8, M, blk.mlp.c_fc.weight, '_xsite'),
-                                            x3_for=blk.mlp.c_fc.weight if x3 else None, x3_only=True)
-        h2r = _rows(h2) if h2 is not None else None
+                                            x3_for=blk.mlp.c_fc.weight if x3 else None, x3_only=True,
+                                            q8_only=bool(blk.fp8) and not x3 and fp8_only_ok(M, blk.mlp.c_fc.weight, False))
+        h2r = _rows(h2) if h2 is not None else (None if x3 else h2_8)
         pre = torch.empty(M, 4 * d, device=x.device, dtype=x.dtype)
         h2_8 = x8_of(blk.fp8, h2r, blk.mlp.c_fc.weight, h2_8)
         # (fp8: the activation's e4m3 copy for c_proj comes out of c_fc's epilogue - no quantise pass over the 4d-wide tensor)

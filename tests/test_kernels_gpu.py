@@ -981,6 +981,11 @@ def test_layernorm_passes_write_the_fp8_copy_their_consumer_needs(K, rows, d):
     assert y8.dtype == torch.float8_e4m3fn and torch.equal(y8.view(torch.uint8), want.view(torch.uint8))
     sx2.quantize(y0)
     assert float(sx.row[0]) == float(sx2.row[0]) > 0          # the same amax recorded for the next step's scale
+    # the copy alone (round 4: a pre-LN block's h1 / h2 in the fp8 step are read by nothing else): same bytes, statistics and sum; no y
+    yn, mean2, rstd2, s2, y8b = K.layernorm_fwd(x, g, b, 1e-5, add=add, want_sum=True, drop=(p, seed), q8_site=sx, write_y=False)
+    assert yn is None and torch.equal(y8b.view(torch.uint8), want.view(torch.uint8)) and torch.equal(s2, s0) and torch.equal(mean2, mean)
+    with pytest.raises(AssertionError):                       # .. only beside a copy: a site without a scale writes none
+        K.layernorm_fwd(x, g, b, 1e-5, q8_site=sites.new(0), write_y=False)
     # backward: (dx, dropout(dx), e5m2 copy of dropout(dx)); without dropout the copy is of dx
     dy, dres = _rand((rows, d), dt, 44).to(DEV), _rand((rows, d), dt, 45).to(DEV)
     dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
