@@ -363,6 +363,14 @@ bool gemm256t4_legal(const leccr_gemm_params& p);
 int gemm256t4_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
 bool gemm256t4_fp8_legal(const leccr_gemm_params& p);
 int gemm256t4_fp8_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
+bool gemm256n4_legal(const leccr_gemm_params& p);
+int gemm256n4_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
+// Forward / dX (NT) products with whole 256 x 256 tiles: the 4-wave 16x16x32 kernel of gemm256n4.hip (round 5; LECCR_GEMM_N4=0: the 8-wave
+// kernel of gemm256.hip instead).  leccr_set_gemm_variant(5) / (2) force one or the other for A/B runs and tests.
+static int n4_default() {
+    static const int v = [] { const char* e = getenv("LECCR_GEMM_N4"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
 // Weight-gradient (TN) products: the 4-wave kernel of gemm256t4.hip wherever it is legal (default; LECCR_GEMM_TN4=0: the 8-wave TN
 // instantiation of gemm256.hip instead).  leccr_set_gemm_variant(4) / (2) force one or the other for A/B runs and tests.
 // Measured on the step's shapes (scripts/gemm_bench.py, same box): dW qkv 834 -> 1010 TFLOP/s, out 757 -> 818, fc1 960 -> 1076,
@@ -414,6 +422,10 @@ static int gemm_dispatch(const leccr_gemm_params& p, hipStream_t st, bool* colsu
         if (g_gemm_variant == 3 && gemm256w4_legal(p)) {
             g_last_kernel = 3;
             return gemm256w4_launch(p, st);
+        }
+        if ((g_gemm_variant == 5 || (g_gemm_variant == 0 && n4_default() && gemm256_wanted(p))) && gemm256n4_legal(p)) {
+            g_last_kernel = 7;
+            return gemm256n4_launch(p, gemm256_max_blocks(), st);
         }
         if ((g_gemm_variant == 4 || (g_gemm_variant == 0 && tn4_default())) && gemm256t4_legal(p)) {
             g_last_kernel = 5;

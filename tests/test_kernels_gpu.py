@@ -634,6 +634,68 @@ def test_gemm256_w4(K, M, N, K_, case):
         assert e <= 1.2e-2 * s
 
 
+@pytest.mark.parametrize('M,N,K_', [(512, 512, 128), (256, 256, 192), (1024, 768, 768), (256 * 9, 2304, 768), (256 * 40, 3072, 768), (256 * 37, 768, 3072),
+                                    (256 * 300, 768, 64 * 3), (256 * 7, 1024, 64 * 17), (256 * 50, 256, 128)])
+@pytest.mark.parametrize('case', ['plain', 'nobias', 'res', 'act', 'gelu', 'dact', 'dgelu'])
+def test_gemm256_n4(K, M, N, K_, case):
+    """gemm256n4.hip (round 5): the 4-wave 16x16x32 NT kernel with the four-stage LDS ring (forward / dX products, bf16 out, whole tiles)
+    against f64, every epilogue it is compiled for; 1 .. 1200 items over the persistent grid (one item per block, several items per
+    block with the stage stream running across items), 4 .. 96 stages per item (even and odd K-tile counts).  Twice into the same
+    output: nothing is left behind in the ring."""
+    from leccr_amd import _lib
+    a, b = _rand((M, K_), torch.bfloat16, 590), _rand((N, K_), torch.bfloat16, 591, 0.05)
+    bias, extra = _rand((N,), torch.float32, 592), _rand((M, N), torch.bfloat16, 593)
+    u = a.double() @ b.double().t() + (0 if case == 'nobias' else bias.double())
+    kw, pre = {}, None
+    if case == 'res':
+        kw, ref = dict(residual=extra.to(DEV)), u + extra.double()
+    elif case in ('act', 'gelu'):
+        epi = 1 if case == 'act' else 2
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        kw, ref = dict(epilogue=epi, aux_out=pre), ACT[epi](u)
+    elif case == 'dact':
+        x = extra.double()
+        sg = torch.sigmoid(1.702 * x)
+        kw, ref = dict(epilogue=3, aux=extra.to(DEV)), u * (sg * (1 + 1.702 * x * (1 - sg)))
+    elif case == 'dgelu':
+        x = extra.double()
+        cdf = 0.5 * (1 + torch.erf(x / 2 ** 0.5))
+        kw, ref = dict(epilogue=4, aux=extra.to(DEV)), u * (cdf + x * torch.exp(-x * x / 2) / (2 * torch.pi) ** 0.5)
+    else:
+        ref = u
+    lib = _lib.lib()
+    lib.leccr_set_gemm_variant(5)
+    try:
+        ad, bd = a.to(DEV), b.to(DEV)
+        out = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device=DEV)
+        for _ in range(2):
+            K.gemm(ad, bd, bias=None if case == 'nobias' else bias.to(DEV), out=out, **kw)
+        assert lib.leccr_last_gemm_kernel() == 7
+    finally:
+        lib.leccr_set_gemm_variant(0)
+    e, s = _err(out, ref)
+    assert e <= 1.2e-2 * s, (e, s)
+    if pre is not None:
+        e, s = _err(pre, u)
+        assert e <= 1.2e-2 * s
+
+
+def test_gemm256_n4_takes_whole_tiles_only(K):
+    """Shapes with tails, f32 outputs and the fused copies stay on the 8-wave kernel even when the variant is forced."""
+    from leccr_amd import _lib
+    lib = _lib.lib()
+    lib.leccr_set_gemm_variant(5)
+    try:
+        for M, N, K_ in [(1154, 768, 768), (512, 520, 128), (512, 512, 96)]:
+            a, b = _rand((M, K_), torch.bfloat16, 594), _rand((N, K_), torch.bfloat16, 595, 0.05)
+            out = K.gemm(a.to(DEV), b.to(DEV))
+            assert lib.leccr_last_gemm_kernel() != 7
+            e, s = _err(out, a.double() @ b.double().t())
+            assert e <= 1.2e-2 * s
+    finally:
+        lib.leccr_set_gemm_variant(0)
+
+
 @pytest.mark.parametrize('M,N,K_', [(1154, 768, 256), (2000, 1024, 128), (300, 260, 64), (40, 24, 16)])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 def test_gemm_fused_colsum(K, dtype, M, N, K_):
