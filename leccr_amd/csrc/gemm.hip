@@ -365,10 +365,13 @@ bool gemm256t4_fp8_legal(const leccr_gemm_params& p);
 int gemm256t4_fp8_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
 bool gemm256n4_legal(const leccr_gemm_params& p);
 int gemm256n4_launch(const leccr_gemm_params& p, int cap, hipStream_t st);
-// Forward / dX (NT) products with whole 256 x 256 tiles: the 4-wave 16x16x32 kernel of gemm256n4.hip (round 5; LECCR_GEMM_N4=0: the 8-wave
-// kernel of gemm256.hip instead).  leccr_set_gemm_variant(5) / (2) force one or the other for A/B runs and tests.
+// Forward / dX (NT) products with whole 256 x 256 tiles and K >= 768 CAN run on the 4-wave 16x16x32 kernel of gemm256n4.hip (round 5):
+// LECCR_GEMM_N4=1, or leccr_set_gemm_variant(5) for A/B runs and tests.  It is parity-green on every epilogue and carries the whole model, but
+// measured on one box inside the step it is 3 % behind the 8-wave kernel (GEMM family 99.0 against 96.2 ms per step, 131.4 against 130.2 ms per
+// step: profiles/r05_gemm_n4_step_ab.txt) - both structures end on the same per-CU L2 -> LDS path (profiles/r05_gemm_n4_v2.txt) - so the
+// 8-wave kernel stays the default.
 static int n4_default() {
-    static const int v = [] { const char* e = getenv("LECCR_GEMM_N4"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int v = [] { const char* e = getenv("LECCR_GEMM_N4"); return (e && e[0] == '1') ? 1 : 0; }();
     return v;
 }
 // Weight-gradient (TN) products: the 4-wave kernel of gemm256t4.hip wherever it is legal (default; LECCR_GEMM_TN4=0: the 8-wave TN

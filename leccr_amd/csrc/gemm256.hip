@@ -32,6 +32,18 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// The output tiles of the forward / dX products leave by NON-TEMPORAL stores (round 5): a launch writes 0.2 - 0.9 GB that nothing re-reads before
+// it has left every cache, and written with the default policy the stream evicts the weight panels and A rows the K loops are re-reading from
+// the 4 MiB L2 of each XCD (scripts/r5_n4_e.sh: the 4-wave kernel's fc1 launch 745 -> 680 us, out 205 -> 193).  G256_NT=0 builds the old stores.
+#ifndef G256_NT
+#define G256_NT 1
+#endif
+#if G256_NT
+#define G256_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define G256_STORE(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace leccr {
 namespace g256 {
 
@@ -724,7 +736,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                                 bf16x8 pv;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { pv[r] = (bf16_t)v0[r]; pv[4 + r] = (bf16_t)v1[r]; }
-                                if (ok) *reinterpret_cast<bf16x8*>(optr) = pv;
+                                if (ok) G256_STORE(reinterpret_cast<bf16x8*>(optr), pv);
                                 optr += step8;
                             }
                             if constexpr (EPI != LECCR_EPI_NONE) {
@@ -750,7 +762,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
 #ifdef G256_EXP_NOSTORE
                             asm volatile("" ::"v"(ov));            // diagnostic build: the epilogue without its C stores (wrong results)
 #else
-                            if (ok) *reinterpret_cast<bf16x8*>(cptr) = ov;
+                            if (ok) G256_STORE(reinterpret_cast<bf16x8*>(cptr), ov);
 #endif
                             cptr += step8;
                         }
@@ -868,9 +880,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                                 l8[4 + r] = (bf16_t)(vv[2 * hp + 1][r] - (float)h8[4 + r]);
                             }
                             bf16_t* d3 = a.c3 + m * 3 * a.N + ncol;
-                            *reinterpret_cast<bf16x8*>(d3) = h8;
-                            *reinterpret_cast<bf16x8*>(d3 + a.N) = a.c3_form == 0 ? h8 : l8;
-                            *reinterpret_cast<bf16x8*>(d3 + 2 * a.N) = a.c3_form == 0 ? l8 : h8;
+                            G256_STORE(reinterpret_cast<bf16x8*>(d3), h8);
+                            G256_STORE(reinterpret_cast<bf16x8*>(d3 + a.N), a.c3_form == 0 ? h8 : l8);
+                            G256_STORE(reinterpret_cast<bf16x8*>(d3 + 2 * a.N), a.c3_form == 0 ? l8 : h8);
                         }
                     }
                 }

@@ -634,14 +634,14 @@ def test_gemm256_w4(K, M, N, K_, case):
         assert e <= 1.2e-2 * s
 
 
-@pytest.mark.parametrize('M,N,K_', [(512, 512, 128), (256, 256, 192), (1024, 768, 768), (256 * 9, 2304, 768), (256 * 40, 3072, 768), (256 * 37, 768, 3072),
-                                    (256 * 300, 768, 64 * 3), (256 * 7, 1024, 64 * 17), (256 * 50, 256, 128)])
+@pytest.mark.parametrize('M,N,K_', [(512, 512, 768), (256, 256, 832), (1024, 768, 768), (256 * 9, 2304, 768), (256 * 40, 3072, 768), (256 * 37, 768, 3072),
+                                    (256 * 300, 768, 768), (256 * 7, 1024, 64 * 17), (256 * 50, 256, 1024), (256 * 130, 512, 768)])
 @pytest.mark.parametrize('case', ['plain', 'nobias', 'res', 'act', 'gelu', 'dact', 'dgelu'])
 def test_gemm256_n4(K, M, N, K_, case):
-    """gemm256n4.hip (round 5): the 4-wave 16x16x32 NT kernel with the four-stage LDS ring (forward / dX products, bf16 out, whole tiles)
-    against f64, every epilogue it is compiled for; 1 .. 1200 items over the persistent grid (one item per block, several items per
-    block with the stage stream running across items), 4 .. 96 stages per item (even and odd K-tile counts).  Twice into the same
-    output: nothing is left behind in the ring."""
+    """gemm256n4.hip (round 5): the 4-wave 16x16x32 NT kernel (forward / dX products, bf16 out, whole tiles, K >= 768) against f64, every
+    epilogue it is compiled for; 1 .. 1200 items over the persistent grid (one item per block; several items per block, the K-tile stream and
+    the previous item's parked output tile running across item boundaries and tile rows), 12 .. 48 K-tiles per item (12 = the unrolled head
+    alone).  Twice into the same NaN-filled output: every element is written, nothing is left behind in the LDS slots or the parked registers."""
     from leccr_amd import _lib
     a, b = _rand((M, K_), torch.bfloat16, 590), _rand((N, K_), torch.bfloat16, 591, 0.05)
     bias, extra = _rand((N,), torch.float32, 592), _rand((M, N), torch.bfloat16, 593)
@@ -686,7 +686,7 @@ def test_gemm256_n4_takes_whole_tiles_only(K):
     lib = _lib.lib()
     lib.leccr_set_gemm_variant(5)
     try:
-        for M, N, K_ in [(1154, 768, 768), (512, 520, 128), (512, 512, 96)]:
+        for M, N, K_ in [(1154, 768, 768), (512, 520, 768), (512, 512, 800), (512, 512, 704)]:
             a, b = _rand((M, K_), torch.bfloat16, 594), _rand((N, K_), torch.bfloat16, 595, 0.05)
             out = K.gemm(a.to(DEV), b.to(DEV))
             assert lib.leccr_last_gemm_kernel() != 7
