@@ -14,8 +14,10 @@ all-reduce + fused AdamW + LR schedule on one synthetic Multi30K-shaped batch th
 batch is all-gathered across ranks).  Prints ONE JSON line on rank 0 with the metric, a `roofline` object for the
 dominant kernel family (bf16 MFMA GEMMs, timed with hipEvents on the launch stream in legs run AFTER the timed region - the timed
 region itself runs with the event profiler off), an `hbm_kernels` list (achieved TB/s of the bandwidth-bound launches), a `parity`
-object (the same weights on a 16-row slice against the CPU oracle: features, logits, losses, ground-truth ranks) and a
-`cpu_baseline` object (the CPU oracle timed on this host: BASELINE config A, bounded sample).
+object (the same weights on a 16-row slice against the CPU oracle: features, logits, losses, ground-truth ranks), a
+`cpu_baseline` object (the CPU oracle timed on this host: BASELINE config A, bounded sample) and - default bf16 image line only - a
+`reference_precision` object: the same workload re-run at the reference's fp32 precision (pairs/s, ms/step, logits error against the
+oracle, ground-truth ranks, its own roofline), the one path inside north_star's 1e-3.
 
 Other workloads (not the headline line): --model video (the reference's MSR-VTT geometry: 4096-wide frame features, F = 8)
 and --model video_vit (BASELINE configs[3] as worded: 8 frames x ViT-B/16 -> vid_encoder, vw 512).
@@ -63,6 +65,8 @@ def parse():
     ap.add_argument('--eval-no-regroup', action='store_true', help='run every loader batch through the towers as it is yielded (the reference '
                     'loop); default: evaluation_coarse regroups them to 256 images / 1024 texts per forward - same scores')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-reference-precision', action='store_true', help='skip the fp32 (reference-precision) leg of the default bf16 image line')
+    ap.add_argument('--ref-steps', type=int, default=10, help='timed steps of the reference-precision leg')
     ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--parity-rows', type=int, default=16, help='rows of the batch the parity probe runs through the CPU oracle (config E: 4 keeps it to minutes)')
     ap.add_argument('--roofline-steps', type=int, default=3, help='extra single-stream steps after the timed region that time every launch on its own')
@@ -323,6 +327,67 @@ def parity_probe(args, cfg, model, batch, fwd, rows=16, with_losses=True):
     out['ok'] = bool(ok)
     out['what'] = (f'{args.dtype} HIP path (eval mode) vs CPU oracle fp32, same weights (after the timed steps) and inputs, full '
                    f'{args.clip}@384 + {args.text} geometry; north_star bound: logits within 1e-3 in fp32')
+    return out
+
+
+def reference_precision_leg(args, device, rank):
+    """The same workload at the REFERENCE's precision (fp32: models/xvlm.py:88 `clip_encoder.float()`; the path a reference YAML gets here, on
+    the matrix cores as bf16 hi / lo operand splits - DESIGN.md section 4a): the only path inside north_star's "logits within 1e-3", so its
+    throughput belongs in the driver-run line beside the bf16 headline (round-4 verdict).  Run after the bf16 model has been freed: a fresh
+    model of the same seed, --ref-steps timed steps after 2 warm-ups (same barriers, profiler off), 2 single-stream steps for the GEMM family's
+    rate, then the 16-row parity probe against the CPU oracle."""
+    import argparse as _ap
+    import ctypes as C
+
+    import torch
+    from leccr_amd import _lib, ops
+    from leccr_amd.optim import create_optimizer
+    from leccr_amd.parallel import attach_grad_sync
+    from leccr_amd.scheduler import create_scheduler
+    a32 = _ap.Namespace(**vars(args))
+    a32.dtype = 'fp32'
+    torch.cuda.reset_peak_memory_stats()
+    model, cfg, batch, fwd, what = build_workload(a32, device, rank)
+    opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model)).enable_backward_fusion()
+    sched = create_scheduler(dict(cfg['schedular'], step_per_epoch=1000), opt)
+    sched.step()
+    for _ in range(2):
+        train_step(model, batch, fwd, opt, sched)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.ref_steps):
+        losses = train_step(model, batch, fwd, opt, sched)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib = _lib.lib()
+    NK = 14
+    ms, work, n = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
+    overlap, ops.wgrad_overlap, ops.text_overlap = (ops.wgrad_overlap, ops.text_overlap), False, False
+    fusion, opt.backward_fusion = opt.backward_fusion, False
+    lib.leccr_prof_enable(1)
+    for _ in range(2):
+        train_step(model, batch, fwd, opt, sched)
+    torch.cuda.synchronize()
+    lib.leccr_prof_enable(0)
+    lib.leccr_prof_read_n(NK, ms, work, n)
+    ops.wgrad_overlap, ops.text_overlap = overlap
+    opt.backward_fusion = fusion
+    gemm_ms, gemm_fl = ms[0] + ms[1], work[0] + work[1]
+    issued = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    par = parity_probe(a32, cfg, model, batch, fwd, rows=args.parity_rows, with_losses=True)
+    out = {'dtype': 'fp32', 'what': 'the reference\'s own precision (models/xvlm.py:88) on the matrix cores: fp32 operands as bf16 hi / lo splits, f32 accumulation, '
+                                    'statistics and losses; same workload, batch and step as the headline line',
+           'pairs_s': round(args.batch * args.ref_steps / dt, 2), 'ms_per_step': round(dt / args.ref_steps * 1e3, 3), 'steps': args.ref_steps, 'warmup': 2,
+           'losses': [round(float(l.detach()), 4) for l in losses],
+           'max_abs_logits_err': par.get('max_abs_logits_err'), 'max_abs_feature_err': par.get('max_abs_feature_err'),
+           'logits_tolerance': par.get('logits_tolerance'), 'gt_ranks': par.get('gt_ranks_equal_to_oracle_encoders'),
+           'max_abs_loss_err': par.get('max_abs_loss_err'), 'parity_ok': par['ok'],
+           'roofline': {'bound': 'mfma', 'kernel': 'gemm256 family, fp32 operands as bf16 splits: achieved = fp32-product flops / time, peak = bf16 MFMA peak / 3',
+                        'mfma_issued_tflops': round(issued, 1), 'achieved': round(issued / 3.0, 1), 'peak': round(MFMA_BF16_PEAK_TFLOPS / 3.0, 1),
+                        'unit': 'TFLOP/s', 'frac': round(issued / MFMA_BF16_PEAK_TFLOPS, 4), 'gemm_ms_per_step': round(gemm_ms / 2, 3),
+                        'attn_fwd_ms_per_step': round(ms[3] / 2, 3), 'attn_bwd_ms_per_step': round(ms[4] / 2, 3),
+                        'split_ms_per_step': round(ms[13] / 2, 3)},
+           'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
     return out
 
 
@@ -634,6 +699,7 @@ def _main(args, real_stdout):
                 print(f'bench.py: stage timers of the other ranks unavailable ({e})', file=sys.stderr)
     parity = None
     retrieval = None
+    ref_prec = None
     if not args.no_parity and (world == 1 or (rank == 0 and args.model == 'image')):
         # W > 1: the model's forward gathers across ranks, so rank 0 runs only the collective-free part on its own rows (encoders ->
         # features -> logits against the oracle); the five losses are compared on one rank only
@@ -737,6 +803,15 @@ def _main(args, real_stdout):
             out['retrieval'] = retrieval
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args, cfg, model)
+        if world == 1 and args.model == 'image' and args.dtype == 'bf16' and not args.no_reference_precision:
+            # the reference-precision line of the same workload (after everything that needs the bf16 model: its memory is handed back first)
+            del model, opt, sched, batch, fwd, losses
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            ref_prec = reference_precision_leg(args, device, rank)
+            out['reference_precision'] = ref_prec
         print(json.dumps(out), file=real_stdout, flush=True)
     if world > 1:
         dist.barrier()
@@ -745,6 +820,8 @@ def _main(args, real_stdout):
         raise SystemExit(f'bench.py: parity probe outside its tolerance: {parity}')
     if retrieval is not None and not retrieval['ranks_bit_exact_vs_oracle']:
         raise SystemExit(f'bench.py: device ranking differs from the oracle: {retrieval}')
+    if ref_prec is not None and not ref_prec['parity_ok']:
+        raise SystemExit(f'bench.py: reference-precision parity probe outside its tolerance: {ref_prec}')
 
 
 if __name__ == '__main__':

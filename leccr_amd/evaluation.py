@@ -78,6 +78,20 @@ def _gather_rows_varlen(rows, index, total):
     return out
 
 
+def eval_group_sizes(config, n_images, num_text, world):
+    """Rows per forward of the two evaluation loops (config['eval_group_images'] / ['eval_group_texts'], default 256 / 1024; 0 = as the loader
+    yields them).  The groups are also the unit of the rank sharding (group c -> rank c % world), so under W > 1 they are capped at a 1 / W
+    share of the set: the 1000 images / 1000 - 5000 texts of the Multi30K / MSCOCO-1k test sets then give EVERY rank of an 8-GPU node a group
+    (at 256 / 1024 rows there were 4 image groups and 1 - 5 text chunks - half the ranks or more encoded nothing)."""
+    gi, gt = int(config.get('eval_group_images', 256)), int(config.get('eval_group_texts', 1024))
+    if world > 1:
+        if gi > 0 and n_images > 0:
+            gi = max(1, min(gi, -(-n_images // world)))
+        if gt > 0 and num_text > 0:
+            gt = max(1, min(gt, -(-num_text // world)))
+    return gi, gt
+
+
 @torch.no_grad()
 def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True):
     """image_Retrieval_caption.py:83-163: text features in chunks of batch_size_test_text, image features through the
@@ -99,7 +113,11 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
     # GEMM, a launch-bound pass on this chip.  Nothing in eval mode depends on how the rows are batched, so several loader batches are run
     # through the towers together (config['eval_group_images'] / ['eval_group_texts'], default 256 / 1024 rows per forward; 0 = as the
     # loader yields them): same scores, same ranks, 5.8 x the images per second (958 as yielded, 4224 at 64 / 256, 5100 at 128 / 512, 5543).
-    gi, gt = int(config.get('eval_group_images', 256)), int(config.get('eval_group_texts', 1024))
+    try:
+        n_images = len(data_loader.dataset)
+    except TypeError:
+        n_images = 0
+    gi, gt = eval_group_sizes(config, n_images, num_text, world)
     text_bs = max(config['batch_size_test_text'], gt)
     text_embeds, text_rows = [], []
     for c, i in enumerate(range(0, num_text, text_bs)):

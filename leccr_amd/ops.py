@@ -380,6 +380,8 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_d
     elif _is_x3(g8) or _is_x3(x8):
         if dy2 is None or x2.shape[0] != dy2.shape[0]:
             raise RuntimeError('lin_dw: a split copy without its partner and without the f32 operands')
+        if _is_x3(g8):          # the copy is dropped, not what its producer already did: bias sums taken in its split pass are not taken again
+            bias_done = bias_done or getattr(g8, '_bias_done', False)
         g8 = x8 = None
     elif not (fp8_dw and g8 is not None and x8 is not None and _fp8_dw_ok(g8, x8)):
         if dy2 is None or x2.shape[0] != dy2.shape[0]:
@@ -723,7 +725,7 @@ class ViTBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, dw_keep(h1r, h1_8, blk.attn.in_proj_weight), mean1, rstd1, qkv, o, lse, x1,
                               dw_keep(h2r, h2_8, blk.mlp.c_fc.weight), mean2, rstd2, pre,
                               act if act.shape[0] == 0 else dw_keep(act, act8, blk.mlp.c_proj.weight),
-                              *((h1_8, o_8, h2_8, act8) if (fp8_dw or o is None) else (None,) * 4))
+                              *((h1_8, o_8, h2_8, act8) if (fp8_dw or o is None or blk.fp8 == X3) else (None,) * 4))
         ctx.blk = blk
         return x2
 
@@ -928,7 +930,9 @@ class BertLayerFn(torch.autograd.Function):
         ctx.save_for_backward(dw_keep(_rows(x), x_8, layer._qkv_w), kmask, qkv, o, lse, s1, mean1, rstd1,
                               dw_keep(_rows(x1), x1_8, layer.intermediate.dense.weight), pre,
                               pre[:0] if h is h8 else dw_keep(h, h8, out.dense.weight), s2, mean2, rstd2,
-                              *((x_8, o_8, x1_8, h8) if fp8_dw else (None,) * 4))          # fp8: the weight-gradient products' X operands
+                              *((x_8, o_8, x1_8, h8) if (fp8_dw or layer.fp8 == X3) else (None,) * 4))   # fp8 / X3: the weight-gradient products' X operands
+        # (X3 keeps them whatever LECCR_FP8_DW says: dw_keep() has already dropped the f32 tensors these copies stand for - with the fp8 switch
+        # off the fp32 step used to die in lin_dw: "a split copy without its partner")
         ctx.layer, ctx.drop = layer, (ph, pa, seeds)
         return x2
 

@@ -381,3 +381,19 @@ def test_fp32_split_path_host_decisions():
     assert not diag.enabled
     diag.begin('x'); diag.end('x')
     assert diag._spans == {} and diag._open == {}
+
+
+def test_sharded_evaluation_gives_every_rank_of_a_node_a_group():
+    """evaluation_coarse regroups the loader's batches to 256 images / 1024 texts per forward AND shards those groups over the ranks (group c ->
+    rank c % world).  On the Multi30K / MSCOCO-1k test sets (1000 images, 1000 - 5000 texts; image_Retrieval_caption.py:83-163) that left 4 image
+    groups and 1 - 5 text chunks for 8 ranks (round-4 advisor finding): the group is capped at a 1 / world share of the set."""
+    from leccr_amd.evaluation import eval_group_sizes
+    for world in (2, 4, 8):
+        for n_img, n_txt in ((1000, 1000), (1000, 5000), (29, 145)):
+            gi, gt = eval_group_sizes({}, n_img, n_txt, world)
+            groups_i, groups_t = -(-n_img // gi), -(-n_txt // gt)
+            assert groups_i >= world and groups_t >= world, (world, n_img, n_txt, gi, gt)
+            assert gi <= 256 and gt <= 1024
+    assert eval_group_sizes({}, 1000, 5000, 1) == (256, 1024)                                       # one rank: the measured group sizes stay
+    assert eval_group_sizes({'eval_group_images': 0, 'eval_group_texts': 0}, 1000, 1000, 8) == (0, 0)   # 0 = as the loader yields them
+    assert eval_group_sizes({'eval_group_images': 64, 'eval_group_texts': 100}, 1000, 1000, 4) == (64, 100)
