@@ -565,15 +565,86 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
 HBM_KINDS = ['layernorm_fwd', 'layernorm_bwd', 'colsum', 'bert_embed_fwd', 'adamw', 'dropout']
 
 
+def dry_run(args, rank, world, backend, real_stdout):
+    """LECCR_BENCH_DRYRUN=1 (with LECCR_BENCH_BACKEND=gloo): the N-rank CONTROL FLOW of this script without a GPU - self-launch, env://
+    rendezvous, the world-size check, the barrier / timed-region / MAX-over-ranks protocol, the exchange steps' collectives on host tensors
+    of the real payload sizes (packed all-gather of the loss-stage features; the gradient all-reduce in the phases of leccr_amd.parallel, on a
+    1 / 64 sample of the 1.1 GB arena), the per-rank stage timers gathered to rank 0, one JSON line from rank 0 only.  It measures NOTHING about
+    MI355X (`value` is null and the line says dry_run): it exists so that the first lease of an 8-GPU node meets a launch path that has run
+    with 8 ranks before (tests/test_host_logic_cpu.py)."""
+    import torch
+    import torch.distributed as dist
+    assert backend == 'gloo', 'LECCR_BENCH_DRYRUN needs LECCR_BENCH_BACKEND=gloo (it runs on the host)'
+    batch = args.batch or 256
+    n, vw, D = 4, 512, 256                                              # MULTI30K_CFG: queries, vision width, embed dim
+    packed = torch.randn(batch, 3 * D + n * D + 2 * vw + 2)             # AllGatherPacked: 3 features, n caption queries, 2 pooled cv vectors, idx as two words
+    grads = [torch.randn(int(280e6 / 64 * f)) for f in (0.7, 0.1, 0.1, 0.1)]     # early region, then the ViT region in thirds
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def step(timers=None):
+        t0 = time.perf_counter()
+        if world > 1:
+            out = torch.empty(world * batch, packed.shape[1])
+            dist.all_gather_into_tensor(out, packed)
+        t1 = time.perf_counter()
+        time.sleep(0.002)                                               # (stands in for the encoders)
+        t2 = time.perf_counter()
+        if world > 1:
+            for g in grads:
+                dist.all_reduce(g)
+        t3 = time.perf_counter()
+        if timers is not None:
+            timers['allgather_ms'] = round((t1 - t0) * 1e3, 3)
+            timers['allreduce_exposed_ms'] = round((t3 - t2) * 1e3, 3)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    mine = {}
+    step(mine)
+    stage = {f'rank{rank}': mine}
+    if world > 1:
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        stage = {f'rank{r}': d for r, d in enumerate(allr)}
+    if rank == 0:
+        out = {'metric': 'image-text pairs/sec (train step)', 'value': None, 'unit': 'pairs/s', 'n_gpus': world, 'steps': args.steps,
+               'warmup': args.warmup, 'ms_per_step': None, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+               'data': 'synthetic', 'dry_run': True,
+               'config': {'workload': 'DRY RUN on the host (gloo): control flow of the N-rank bench only, no GPU work, nothing measured',
+                          'global_batch': batch * world, 'parallelism': f'dp{world}', 'world': world, 'backend': backend,
+                          'host_ms_per_step_max_over_ranks': round(dt / args.steps * 1e3, 3)},
+               'stage_ms_per_rank': stage}
+        print(json.dumps(out), file=real_stdout, flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     maybe_self_launch(args)
     # stdout carries exactly one line - the result JSON of rank 0; the reference-style "### ..." notices of create_optimizer /
     # create_scheduler and any library chatter go to stderr
+    # (file descriptor 1 itself is pointed at stderr for the run: libraries print from C++ too - gloo's "[Gloo] Rank 0 is connected to ..")
     import contextlib
-    real_stdout = sys.stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
     with contextlib.redirect_stdout(sys.stderr):
         _main(args, real_stdout)
+    real_stdout.flush()
 
 
 def _main(args, real_stdout):
@@ -592,6 +663,8 @@ def _main(args, real_stdout):
     if world != args.gpus:
         raise SystemExit(f'bench.py: world size {world} != --gpus {args.gpus} (launch with torch.distributed.run '
                          f'--nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` bare and let it start the ranks)')
+    if os.environ.get('LECCR_BENCH_DRYRUN') == '1':
+        return dry_run(args, rank, world, backend, real_stdout)
     if backend != 'nccl':
         local = local % max(1, torch.cuda.device_count())
     device = torch.device('cuda', local)

@@ -135,7 +135,12 @@ def _fp8_ok(x2, w8):
 # forward, e5m2 dY of the dX product) on leccr_gemm's LECCR_FP8_BF8A trans_a = trans_b = 1 form.  LECCR_FP8_DW=0: bf16 dW as in round 2.
 fp8_dw = os.environ.get('LECCR_FP8_DW', '1') != '0'
 fp8_dw_launches = 0          # fp8 weight-gradient products launched (tests read it)
-fp8_bias_asum = os.environ.get('LECCR_FP8_BIAS_ASUM', '1') != '0'      # bias gradients summed inside those launches (from the e5m2 copy)
+# Bias gradients summed inside those launches from the e5m2 copy of dY (round 4, then the default; worth 2 % of the fp8 step, and the switch the
+# copy-only producers below depend on).  OFF by default since round 5: the A/B the round-4 advisor asked for (tests/test_full_geometry_gpu.py::
+# test_fp8_bias_gradients_from_the_e5m2_copy_against_the_unquantised_sums, profiles/r05_fp8_bias_asum_ab.txt) shows out_proj / c_fc / c_proj bias
+# gradients moving by 0.5 - 0.7 of their norm and their error against the fp32 oracle growing (0.43 -> 0.82 at worst): these column sums cancel
+# to ~1/10 of a random walk's size, and e5m2 rounding (2 mantissa bits) does not.  LECCR_FP8_BIAS_ASUM=1 turns it back on.
+fp8_bias_asum = os.environ.get('LECCR_FP8_BIAS_ASUM', '0') == '1'
 attn_q8_only = os.environ.get('LECCR_FP8_ATTN_COPY_ONLY', '1') != '0'      # the ViT attention backward writes only the e5m2 copy of dqkv where nothing reads the bf16 one
 ln_q8_only = os.environ.get('LECCR_FP8_LN_COPY_ONLY', '1') != '0'          # the ViT blocks' LayerNorm passes write only the e4m3 copy of h1 / h2 where nothing reads the bf16 one
 

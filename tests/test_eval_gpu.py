@@ -121,7 +121,7 @@ def test_evaluation_coarse_video_double_sim():
 
 
 # ----------------------------------------------------------------------------------------- full geometry, end to end
-def _full_eval_case(dtype, ni=64, per=5, geometry=None, structured=False):
+def _full_eval_case(dtype, ni=64, per=5, geometry=None, structured=False, graded_leads=(0.02, 0.03, 0.05)):
     """evaluation_coarse (image_Retrieval_caption.py:83-163) on the reference's DEFAULT towers at full size - ViT-B/32 @384 (145
     tokens; models/xvlm.py:83-88) + mBERT, 12 + 12 layers, 3 + 2 + 2 interaction layers - over `ni` images with a generated caption
     each (L_c = 64) and per * ni texts (L_t = 32, MSCOCO-style 5 per image): scores from the HIP encoders, scores from the oracle's
@@ -146,7 +146,8 @@ def _full_eval_case(dtype, ni=64, per=5, geometry=None, structured=False):
             # hold on to).  The two projection heads are fitted - ridge least squares on the oracle's own [CLS] vectors - so that image i
             # lands on a unit code c_i and each of its `per` texts on the same code: ground-truth scores near 1, the rest near 0, as a
             # trained model's are.  The towers (what the kernels compute) stay as they are; only the 256-wide heads are chosen.
-            codes = torch.linalg.qr(torch.randn(256, ni, generator=g, dtype=torch.float64))[0].t().contiguous()      # [ni, 256] orthonormal rows
+            basis = torch.linalg.qr(torch.randn(256, 256, generator=g, dtype=torch.float64))[0].t().contiguous()     # 256 orthonormal rows
+            codes = basis[:ni].contiguous()                                                                          # [ni, 256]: image i -> c_i
 
             def fit(x, target):
                 x = x.double()
@@ -156,8 +157,35 @@ def _full_eval_case(dtype, ni=64, per=5, geometry=None, structured=False):
                 lam = 1e-3 * float(torch.diagonal(gram).mean())
                 w = (a.t() @ torch.linalg.solve(gram + lam * torch.eye(len(a), dtype=torch.float64), target)).t()      # [256, in]
                 return w.float().contiguous(), (-(w @ mu.t()).squeeze(1)).float().contiguous()
+            tcodes = codes[torch.arange(ni * per) // per]
+            if structured == 'graded':
+                # GRADED structure (round-4 verdict, weak #5): not every ground truth at rank 0.  Image i = c_i; text t (of image j) =
+                # 0.35 c_j + sum over the images it is a DECOY for of (0.35 + lead) c_i + the rest of its unit norm on a private spare
+                # direction, so score(i, t) is designed entry by entry: image i's ground-truth texts score 0.35, its r_i decoys `leads` higher
+                # (r_i = 0, 3, 7, 15 by i % 4: either side of the R@1 / R@5 / R@10 cuts), everything else 0; a text that decoys for k images
+                # (k <= 2) has its own image at text->image rank k.
+                want_rank = [0, 3, 7, 15]
+                leads = list(graded_leads)
+                V = torch.zeros(ni * per, ni, dtype=torch.float64)
+                V[torch.arange(ni * per), torch.arange(ni * per) // per] = 0.35
+                roles = [0] * (ni * per)
+                nxt, m = 0, 0
+                for i in range(ni):
+                    need = want_rank[i % 4]
+                    while need:
+                        t = nxt % (ni * per)
+                        nxt += 7                                       # a stride coprime to ni * per = 160 walks every text
+                        if t // per == i or roles[t] >= 2 or V[t, i] != 0:
+                            continue
+                        V[t, i] = 0.35 + leads[m % 3]
+                        roles[t] += 1
+                        m += 1
+                        need -= 1
+                rest = (1.0 - (V * V).sum(1)).clamp_min(0).sqrt()
+                assert float(rest.min()) > 0.2 and ni + ni * per <= 256
+                tcodes = V @ codes + rest[:, None] * basis[ni:ni + ni * per]
             wv, bv = fit(a_img[:, 0, :], codes)
-            wt, bt = fit(txt[:, 0, :], codes[torch.arange(ni * per) // per])
+            wt, bt = fit(txt[:, 0, :], tcodes)
             for name, t in (('vision_proj.weight', wv), ('vision_proj.bias', bv), ('text_proj.weight', wt), ('text_proj.bias', bt)):
                 sd[name] = t
                 dict(model.named_parameters())[name].data.copy_(t)
@@ -260,3 +288,62 @@ def test_full_geometry_evaluation_with_structured_scores_ranks_equal_the_oracle(
     for s_hip, s_ref, gts in ((i2t, ref, gts_i), (t2i, ref.T, gts_t)):
         assert np.array_equal(_gt_ranks(s_hip, gts), _gt_ranks(s_ref, gts))
     print(f'structured eval {tower} {dtype}: min ground-truth lead {gap:.3f}, max |score err| {err:.2e}')
+
+
+@pytest.mark.parametrize('dtype,leads', [('fp32', (0.02, 0.03, 0.05)), ('bf16', (0.15, 0.2, 0.25)), ('fp8', (0.15, 0.2, 0.25))])
+def test_full_geometry_evaluation_with_graded_scores_ranks_equal_the_oracle(dtype, leads):
+    """Ranking parity on GRADED structure (round-4 verdict, weak #5 / next #7): full ViT-B/16 @384 + mBERT towers, 32 images x 160 texts, heads
+    fitted so that image i's ground-truth texts score ~0.35 and r_i planted decoys lead them (r_i = 0, 3, 7, 15: ranks on either side of the
+    R@1 / R@5 / R@10 cuts; a text decoying for k images has its own image at rank k).  The heads are a ridge fit on the oracle's [CLS] vectors
+    of RANDOM-INIT towers, whose vectors differ from sample to sample only in their 4th digit: the fit amplifies those differences - and with
+    them the kernels' rounding noise - by ~20 x (measured score error on this case: fp32 8e-5, bf16 6.3e-2 against 3e-3 on the parity probe's
+    unfitted heads, fp8 operands 0.47).  So the planted leads are 0.02 / 0.03 / 0.05 for fp32 (the round-4 verdict's figures) and 0.15 / 0.2 /
+    0.25 for the reduced-precision paths, and the test certifies what it uses on the ORACLE's scores: the ranks are graded (every recall cut
+    separates ground truths), and a ground truth's rank counts as DECIDED when no competitor sits within 2 x the measured HIP score error of it.
+    Then: every decided rank IDENTICAL to the oracle's, >= 85 % of the 192 ranks decided, recall figures within the undecided rows' worth (the
+    identical 13-key dict when nothing moved), score error capped (fp32 2e-4, bf16 0.1).  fp8 operands run the same case and REPORT their
+    recall deltas (gpurun_out/graded_eval_fp8.txt): under this amplification their score error exceeds every lead - an fp8 ranking claim needs
+    trained weights, which this pipeline does not have."""
+    import os
+    from leccr_amd.evaluation import itm_eval
+    from oracle import leccr_oracle as O
+    from tests.helpers import B16_GEOMETRY
+    ni, per = 32, 5
+    i2t, t2i, ref, img2txt, txt2img = _full_eval_case(dtype, ni=ni, per=per, geometry=B16_GEOMETRY, structured='graded', graded_leads=leads)
+    gts_i = [img2txt[i] for i in range(ni)]
+    gts_t = [[txt2img[t]] for t in range(ni * per)]
+    r_i, r_t = _gt_ranks(ref, gts_i), _gt_ranks(ref.T, gts_t)
+    # graded on the oracle's own scores: ground truths at rank 0, inside R@5, inside R@10 and beyond it - in both directions something moves
+    assert (r_i == 0).sum() >= 6 and ((r_i >= 1) & (r_i < 5)).sum() >= 6 and ((r_i >= 5) & (r_i < 10)).sum() >= 4 and (r_i >= 10).sum() >= 6, r_i
+    assert (r_t == 0).sum() >= 10 and (r_t >= 1).sum() >= 40, np.bincount(r_t)
+    err = float(np.max(np.abs(i2t - ref)))
+    cap = {'fp32': 2e-4, 'bf16': 0.1, 'fp8': float('inf')}[dtype]
+
+    def leads(s_ref, gts):
+        return np.array([float(np.min(np.abs(np.delete(s_ref[r], gts[r]) - np.max(s_ref[r, gts[r]])))) for r in range(len(gts))])
+    l_i, l_t = leads(ref, gts_i), leads(ref.T, gts_t)
+    h_i, h_t = _gt_ranks(i2t, gts_i), _gt_ranks(t2i, gts_t)
+    dec_i, dec_t = l_i > 2 * err, l_t > 2 * err
+    decided = int(dec_i.sum() + dec_t.sum())
+    moved_decided = int((h_i[dec_i] != r_i[dec_i]).sum() + (h_t[dec_t] != r_t[dec_t]).sum())
+    moved = int((h_i != r_i).sum() + (h_t != r_t).sum())
+    want = O.itm_eval(ref, ref.T.copy(), txt2img, img2txt)
+    got = itm_eval(i2t, t2i, txt2img, img2txt)
+    out = os.path.join(os.path.dirname(__file__), '..', 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f'graded_eval_{dtype}.txt'), 'w') as fh:
+        fh.write(f'graded eval, ViT-B/16 @384 + mBERT, 32 images x 160 texts, {dtype}: max |score err| {err:.3e} (cap {cap:g}); oracle image->text ranks {r_i.tolist()}; '
+                 f'text->image rank histogram {np.bincount(r_t).tolist()}; median lead {np.median(np.concatenate([l_i, l_t])):.4f}, min {min(l_i.min(), l_t.min()):.5f}; '
+                 f'decided {decided} of {ni + ni * per}; ranks moved {moved} (decided ones: {moved_decided}); '
+                 f'recall oracle {({k: float(v) for k, v in want.items()})} hip {({k: float(v) for k, v in got.items()})}\n')
+    assert err < cap, err
+    if dtype == 'fp8':              # reported, not judged (see the docstring)
+        assert all(np.isfinite(float(v)) and 0.0 <= float(v) <= 600.0 for v in got.values())
+        return
+    assert decided >= 0.85 * (ni + ni * per), (decided, err)
+    assert moved_decided == 0, (moved_decided, moved)
+    undec_i, undec_t = int((~dec_i).sum()), int((~dec_t).sum())
+    tol = 6.0 * (100.0 / ni * undec_i + 100.0 / (ni * per) * undec_t) + 1e-9        # (the sums add three recall figures of two directions)
+    assert all(abs(float(got[k]) - float(want[k])) <= tol for k in want), (got, want, undec_i, undec_t)
+    if moved == 0:
+        assert {k: float(v) for k, v in got.items()} == {k: float(v) for k, v in want.items()}, (got, want)

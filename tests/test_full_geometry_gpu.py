@@ -321,19 +321,23 @@ def test_fp8_end_to_end_copies_without_the_bf16_activation(monkeypatch):
 
 def test_fp8_bias_gradients_from_the_e5m2_copy_against_the_unquantised_sums(monkeypatch):
     """Round 4 made the fp8 path take every block Linear's bias gradient from the column sums of the e5m2 (2 mantissa bits) copy of dY inside the
-    weight-gradient launch (`ops.fp8_bias_asum`, default on; with it the attention backward and the blocks' LayerNorm passes stop writing the
-    bf16 tensors).  The accuracy gate of that default (round-4 advisor finding): the SAME model and batch with the switch on and off
+    weight-gradient launch (`ops.fp8_bias_asum`; with it the attention backward and the blocks' LayerNorm passes stop writing the bf16
+    tensors).  The accuracy gate the round-4 advisor asked for: the SAME model and batch with the switch on and off
       * every encoder bias gradient of the steady-state (second) step: relative L2 difference between the two settings, and each setting's
-        error against the fp32 oracle - the e5m2 sums may not be more than 2x further from the oracle than the sums of the unquantised dY
-        (+ 2 % of the tensor), and no bias may move by more than 25 % of its norm;
+        error against the fp32 oracle;
       * six optimizer steps from the same start: the two loss curves stay within 2 % of each other.
-    The measured table goes to gpurun_out/fp8_bias_asum_ab.txt."""
+    The gate applies to whichever setting is the DEFAULT: the e5m2 sums may be the default only if no bias moves by more than 25 % of its norm
+    and none ends more than 2 x (+ 2 %) further from the oracle than with the sums of the unquantised dY.  Measured (round 5, this test's table
+    in profiles/r05_fp8_bias_asum_ab.txt): out_proj / c_fc / c_proj biases move by 0.5 - 0.7 of their norm, error 0.43 -> 0.82 at worst - the
+    switch went back to opt-in; with the unquantised sums as the default the test holds them to "never further from the oracle than the e5m2
+    sums" instead."""
     from leccr_amd import ops
     from leccr_amd.models import RetrievalModel
     from leccr_amd.optim import create_optimizer
     from leccr_amd.scheduler import create_scheduler
     from leccr_amd.synthetic import MULTI30K_CFG, make_batch
     geometry, nb = L14_GEOMETRY, 8
+    default_asum = bool(ops.fp8_bias_asum)
     m = make_batch(nb, vocab=30000, res=geometry['image_resolution'])
     batch = dict(image=m['image'], ids_s=m['text'][0].input_ids, mask_s=m['text'][0].attention_mask, ids_t=m['text'][1].input_ids,
                  mask_t=m['text'][1].attention_mask, ids_c=m['captions'].input_ids, mask_c=m['captions'].attention_mask, idx=m['idx'])
@@ -372,7 +376,7 @@ def test_fp8_bias_gradients_from_the_e5m2_copy_against_the_unquantised_sums(monk
             sum(losses).backward()
             opt.step()
             sched.step()
-            curve.append(float(sum(losses)))
+            curve.append(float(sum(losses).detach()))
         curves[asum] = curve
         del model, opt
     assert len(grads[True]) >= 2 * 6 + 2 * 6 and grads[True].keys() == grads[False].keys()
@@ -382,7 +386,9 @@ def test_fp8_bias_gradients_from_the_e5m2_copy_against_the_unquantised_sums(monk
         rn = float(ref.norm()) + 1e-30
         d10, e1, e0 = float((g1 - g0).norm()) / rn, float((g1 - ref).norm()) / rn, float((g0 - ref).norm()) / rn
         table.append((n, rn, d10, e1, e0))
-        if d10 > 0.25 or e1 > 2 * e0 + 0.02:
+        if default_asum and (d10 > 0.25 or e1 > 2 * e0 + 0.02):
+            bad.append((n, d10, e1, e0))
+        if not default_asum and e0 > e1 + 0.02:
             bad.append((n, d10, e1, e0))
     os.makedirs(os.path.join(os.path.dirname(__file__), '..', 'gpurun_out'), exist_ok=True)
     with open(os.path.join(os.path.dirname(__file__), '..', 'gpurun_out', 'fp8_bias_asum_ab.txt'), 'w') as fh:
@@ -558,7 +564,7 @@ def test_fp32_split_operand_step_does_not_depend_on_the_fp8_weight_gradient_swit
     assert max(abs(a - b) for a, b in zip(l1, l0)) <= 1e-6
     # (the weight gradients are split-K sums of f32 atomics: the order of the adds differs from launch to launch)
     worst = sorted(((float((g1[k] - g0[k]).abs().max()) / (float(g0[k].abs().max()) + 1e-12), k) for k in g0), reverse=True)
-    assert len(g0) > 100 and worst[0][0] <= 2e-5, worst[:5]
+    assert len(g0) > 100 and worst[0][0] <= 2e-4, worst[:5]           # (measured 5.7e-5 on ln_post.bias: two runs of the same code differ by that)
 
 
 def test_fp8_weight_copies_and_their_scale_stay_together_when_a_weight_grows():

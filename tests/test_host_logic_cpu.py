@@ -397,3 +397,33 @@ def test_sharded_evaluation_gives_every_rank_of_a_node_a_group():
     assert eval_group_sizes({}, 1000, 5000, 1) == (256, 1024)                                       # one rank: the measured group sizes stay
     assert eval_group_sizes({'eval_group_images': 0, 'eval_group_texts': 0}, 1000, 1000, 8) == (0, 0)   # 0 = as the loader yields them
     assert eval_group_sizes({'eval_group_images': 64, 'eval_group_texts': 100}, 1000, 1000, 4) == (64, 100)
+
+
+def test_bench_eight_rank_control_flow_dry_run_under_gloo():
+    """`python bench.py --gpus 8` as the driver will start it on an 8-GPU node - bare, no launcher - but on the host: LECCR_BENCH_BACKEND=gloo
+    LECCR_BENCH_DRYRUN=1.  The script starts its own 8 ranks (torch.distributed.run child, 127.0.0.1 rendezvous), every rank passes the
+    world-size check, runs the barrier / timed-region / MAX-over-ranks protocol with the exchange steps' collectives on host tensors, the
+    per-rank stage timers reach rank 0, and exactly ONE JSON line comes out - marked dry_run, value null (nothing about MI355X is measured
+    here; round-4 verdict, next #9: the first multi-GPU lease should meet a launch path that has already run with 8 ranks)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    env.update(LECCR_BENCH_BACKEND='gloo', LECCR_BENCH_DRYRUN='1', OMP_NUM_THREADS='1')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1', '--batch', '32'],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d['dry_run'] is True and d['value'] is None and d['n_gpus'] == 8 and d['config']['world'] == 8 and d['config']['global_batch'] == 256
+    assert sorted(d['stage_ms_per_rank']) == [f'rank{i}' for i in range(8)]
+    assert all(set(v) == {'allgather_ms', 'allreduce_exposed_ms'} for v in d['stage_ms_per_rank'].values())
+    # a wrong world still refuses: 8 ranks asked, launched as 2
+    env2 = dict(env, RANK='0', WORLD_SIZE='2', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29871')
+    r2 = subprocess.Popen([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], env=dict(env2), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    r3 = subprocess.Popen([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '8'], env=dict(env2, RANK='1', LOCAL_RANK='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    o2, e2 = r2.communicate(timeout=300)
+    r3.communicate(timeout=300)
+    assert r2.returncode != 0 and o2.strip() == '' and 'world size 2 != --gpus 8' in e2
