@@ -38,8 +38,10 @@
 #ifndef G256_NT
 #define G256_NT 1
 #endif
+// (a compile-time choice on purpose: behind a runtime switch - `if (a.nt) nontemporal else plain` - hipcc merges the two stores into ONE plain
+// store and the policy is lost without a word: scripts/r5_nt_ab2.sh, qkv 603 - 630 us with the switch, 570 - 579 without it)
 #if G256_NT
-#define G256_STORE(ptr, val) do { if (a.nt) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
+#define G256_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
 #else
 #define G256_STORE(ptr, val) (*(ptr) = (val))
 #endif
@@ -73,7 +75,6 @@ struct Args {
     float* asum;                         // TRANS = 1 with F_ASUM: asum[m] += alpha * sum_k A[k, m] (the bias gradient), or null
     bf16_t* c3;                          // f32 C only: the (hi, lo) split copy of C, [M, 3 N] in form c3_form (split.hip), or null; C may then be null
     int c3_form;
-    int nt;                              // the output tiles leave by non-temporal stores (see G256_NT)
 };
 
 __device__ __attribute__((aligned(256))) unsigned char g_zero_page256[512];
@@ -1017,10 +1018,7 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
     a.asum = p.trans_a == 1 ? p.asum : nullptr;
     a.c3 = (p.trans_a == 0 && p.c_dtype == LECCR_F32) ? (bf16_t*)p.c3 : nullptr;
     a.c3_form = p.c3_form;
-    // LECCR_G256_NT: 0 default-policy stores, 1 non-temporal stores (default), 2 non-temporal only for outputs the 256 MB Infinity Cache
-    // cannot hold anyway (>= 256 MB: qkv, fc1; the N = 768 outputs stay cacheable for the LayerNorm / attention pass that reads them next)
-    static const int env_nt = [] { const char* e = getenv("LECCR_G256_NT"); return e ? atoi(e) : 1; }();
-    a.nt = env_nt == 1 || (env_nt == 2 && (double)p.M * (double)p.N * (p.c_dtype == LECCR_F32 ? 4.0 : 2.0) >= 256.0 * 1048576.0);
+
     a.tiles_m = (int)cdiv(p.M, BM); a.tiles_n = (int)cdiv(p.N, BN);
     const int64_t ktiles = cdiv(p.K, BK);
     const int tiles = a.tiles_m * a.tiles_n;

@@ -6,7 +6,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 M=147712
-OUT=$R/gpurun_out/pmc_gemm_shapes.txt
+OUT=$R/gpurun_out/pmc_gemm_shapes${TAG:+_$TAG}.txt
 : > $OUT
 while read name tn m n k; do
   echo "== $name  tn=$tn M=$m N=$n K=$k" >> $OUT
@@ -15,7 +15,7 @@ while read name tn m n k; do
     i=$((i+1))
     d=$R/gpurun_out/pmc_gs_${name}_$i
     rm -rf $d
-    rocprofv3 --pmc $grp -d $d -o p --output-format csv -- python3 $R/scripts/gemm_one.py $tn $m $n $k 0 4 > /dev/null 2>&1 || { echo "pass $i failed" >> $OUT; continue; }
+    rocprofv3 --pmc $grp -d $d -o p --output-format csv -- python3 $R/scripts/gemm_one.py $tn $m $n $k ${VARIANT:-0} 4 > /dev/null 2>&1 || { echo "pass $i failed" >> $OUT; continue; }
     f=$(find $d -name "*counter_collection.csv" | head -1)
     python3 - "$f" >> $OUT <<'PY'
 import csv, sys, collections
@@ -29,6 +29,6 @@ for k, v in acc.items():
 PY
   done
 done <<LIST
-$( if [ "$SHAPES" = "dw" ]; then printf 'dW_qkv 1 2304 768 %s\ndW_fc1 1 3072 768 %s\ndW_fc2 1 768 3072 %s\n' $M $M $M; else printf 'qkv 0 %s 2304 768\nfc1 0 %s 3072 768\nfc2 0 %s 768 3072\nout 0 %s 768 768\ndW_fc1 1 3072 768 %s\n' $M $M $M $M $M; fi )
+$( if [ "$SHAPES" = "nt2" ]; then printf 'qkv 0 %s 2304 768\nfc1 0 %s 3072 768\n' $M $M; elif [ "$SHAPES" = "dw" ]; then printf 'dW_qkv 1 2304 768 %s\ndW_fc1 1 3072 768 %s\ndW_fc2 1 768 3072 %s\n' $M $M $M; else printf 'qkv 0 %s 2304 768\nfc1 0 %s 3072 768\nfc2 0 %s 768 3072\nout 0 %s 768 768\ndW_fc1 1 3072 768 %s\n' $M $M $M $M $M; fi )
 LIST
 cat $OUT
