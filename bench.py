@@ -807,7 +807,7 @@ def _main(args, real_stdout):
                               'tflops': round(bf_fl / (bf_ms * 1e-3) / 1e12, 1) if bf_ms > 0 else None, 'peak': MFMA_BF16_PEAK_TFLOPS}}
         traffic, traffic_src = None, None
         suf = '' if args.dtype == 'bf16' else '_' + args.dtype
-        tj = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_gemm256_hbm_traffic{suf}.json') for r in (4, 3, 2, 1))
+        tj = next((p for p in (os.path.join(ROOT, 'profiles', f'r{r:02d}_gemm256_hbm_traffic{suf}.json') for r in (5, 4, 3, 2, 1))
                    if os.path.exists(p)), '')
         if tj and args.model == 'image' and args.clip == 'ViT-B/16' and args.batch == 256 and args.dtype in ('bf16', 'fp32'):
             with open(tj) as fh:        # PMC counters cannot be read from inside the run: the committed rocprofv3 passes
