@@ -166,6 +166,11 @@ int leccr_split3(const float* src, void* dst, int64_t rows, int64_t cols, int64_
  * needed widened are the form's own noise (tests/test_model_gpu.py). */
 int leccr_split_n(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld_src, int form, int nseg, int transpose, float* colsum,
                   void* stream);
+/* The two split copies every weight of the fp32 path needs - [out, 3 in] in form 1 for the forward product (clip/model.py:175-191, HF BERT dense layers:
+ * y = x W^T) and [in, 3 out] in form 0 of W^T for the dX product - for ALL weights in one launch, once per optimizer step (the counterpart of
+ * leccr_transpose_cast_batched on the bf16 path).  table: n rows of 6 int64 on the device = {first 32 x 32 tile of this matrix in the launch, src
+ * pointer (f32 [R, C] contiguous), dstG pointer (bf16 [R, 3 C]), dstT pointer (bf16 [C, 3 R]), R, C}, ordered by first tile; total_tiles = the grid. */
+int leccr_split3_weights_batched(const int64_t* table, int64_t n, int64_t total_tiles, void* stream);
 
 /* ---- LayerNorm --------------------------------------------------------------------------------------------
  * y = (x - mean) * rstd * gamma + beta over the last axis, statistics in f32.

@@ -91,6 +91,7 @@ _SIGS = {
     'leccr_cast_bf16': ([vp, vp, i64, vp], C.c_int),
     'leccr_transpose_cast': ([vp, vp, i64, i64, C.c_int, vp], C.c_int),
     'leccr_transpose_cast_batched': ([vp, i64, i64, vp], C.c_int),
+    'leccr_split3_weights_batched': ([vp, i64, i64, vp], C.c_int),
     'leccr_axpy': ([vp, vp, f32, i64, C.c_int, vp], C.c_int),
     'leccr_dropout': ([vp, vp, i64, f32, C.c_uint64, C.c_int, vp], C.c_int),
 }

@@ -72,6 +72,7 @@ class ParamArena:
         self.grad = torch.zeros(self.numel, device=device, dtype=torch.float32)
         self.lp = torch.zeros(self.numel, device=device, dtype=torch.bfloat16) if compute_dtype == torch.bfloat16 else None
         self._transposed = []
+        self._split3 = []               # fp32 path: weights whose bf16 hi / lo split copies are made once per step (need_split3)
         self._tt_cache = {}
         self.post_refresh = []          # callables run after every refresh (derived copies outside the arena)
         self.touched = [False] * len(params)
@@ -114,6 +115,36 @@ class ParamArena:
         holder._lpt = torch.empty(src.shape[1], src.shape[0], device=src.device, dtype=torch.bfloat16)
         self._transposed.append(holder)
 
+    def need_split3(self, holder):
+        """Register a 2-D weight (Parameter or packed group) of the fp32 path whose products run on bf16 hi / lo split copies (ops.X3): the
+        [out, 3 in] G-form copy of the forward product and the [in, 3 out] X-form copy of W^T of the dX product are then made ONCE per
+        optimizer step, all weights in one launch (refresh), instead of by a leccr_split3 pass at every use."""
+        if self.compute_dtype != torch.float32 or getattr(holder, '_s3g', None) is not None:
+            return
+        src = holder.data
+        assert src.dim() == 2 and src.dtype == torch.float32
+        R, Cn = src.shape
+        holder._s3g = torch.empty(R, 3 * Cn, device=src.device, dtype=torch.bfloat16)
+        holder._s3t = torch.empty(Cn, 3 * R, device=src.device, dtype=torch.bfloat16)
+        self._split3.append(holder)
+
+    def _split3_table(self, lo, hi):
+        key = ('s3', lo, hi, len(self._split3))
+        hit = self._tt_cache.get(key)
+        if hit is None:
+            base, rows, tiles = self.data.data_ptr(), [], 0
+            for h in self._split3:
+                off = (h.data.data_ptr() - base) // 4
+                if not (lo <= off < hi):
+                    continue
+                R, Cn = h.data.shape
+                assert h.data.is_contiguous()
+                rows.append([tiles, h.data.data_ptr(), h._s3g.data_ptr(), h._s3t.data_ptr(), R, Cn])
+                tiles += ((R + 31) // 32) * ((Cn + 31) // 32)
+            hit = (torch.tensor(rows, dtype=torch.int64, device=self.data.device) if rows else None, tiles)
+            self._tt_cache[key] = hit
+        return hit
+
     def _transpose_table(self, lo, hi):
         """Batched-transpose table of the [in,out] copies whose master weights live in arena elements [lo, hi)."""
         key = (lo, hi, len(self._transposed))
@@ -137,6 +168,10 @@ class ParamArena:
         """Rebuild the low-precision compute copies from the f32 master weights (call once per optimizer step; [lo, hi):
         only the copies of that element range - the optimizer updates the arena in two parts when it is fused into backward)."""
         if self.lp is None:
+            if getattr(self, '_split3', None):          # fp32 path: the weights' split copies (need_split3)
+                table, tiles = self._split3_table(lo, self.numel if hi is None else hi)
+                if table is not None:
+                    K.split3_weights_batched(table, tiles)
             return
         hi = self.numel if hi is None else hi
         if not adamw_wrote_lp:

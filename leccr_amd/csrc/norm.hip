@@ -2,6 +2,8 @@
 // All HBM-bound: one wave64 per row (bf16: one or two rows with 16-byte accesses where the width allows), statistics in f32,
 // wave-shuffle reductions (no LDS for the row statistics).
 #include "common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace leccr {
 
@@ -228,6 +230,120 @@ __global__ __launch_bounds__(256, NCH <= 3 ? ((CS || EX) ? 4 : 5) : (NCH == 4 ? 
         }
         __syncthreads();
         float* out = pass == 0 ? dgamma : pass == 1 ? dbeta : colsum;
+        for (int c = threadIdx.x; c < d; c += 256) atomicAdd(out + c, red[c]);
+    }
+}
+
+// Backward, bf16 rows, SOFTWARE-PIPELINED over the rows of a wave (round 5).  The kernel above runs one row per wave at a time: load dy and x
+// (a memory latency), reduce, load the residual gradient (a second latency), store - with 5 waves per SIMD the chip has 5120 rows in flight and the
+// launch on [147712, 768] is bound by those two latencies per row (188 us = 4.8 TB/s), not by bytes.  Here a wave issues the NEXT row's dy / x loads
+// and THIS row's residual-gradient load before it touches the current row's values (packed bf16: 18 more registers, 4 waves per SIMD instead of 5,
+// but 2.5 rows in flight per wave instead of 1).  Same arithmetic, same order of the dgamma / dbeta sums per wave: results identical to the plain kernel.
+template <int NCH>
+__global__ __launch_bounds__(256, 4) void layernorm_bwd_pipe_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xin, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                    const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, int64_t rows, int d) {
+    __shared__ float red[NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 dg[NCH], db[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        dg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    bf16x4 dyr[NCH], xr[NCH];
+    float mu = 0.f, rs = 0.f;
+    auto cvt = [](bf16x4 v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; };
+    if (row < rows) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+                dyr[i] = *reinterpret_cast<const bf16x4*>(dy + row * d + c);
+                xr[i] = *reinterpret_cast<const bf16x4*>(xin + row * d + c);
+            }
+        }
+        mu = mean[row];
+        rs = rstd[row];
+    }
+    while (row < rows) {
+        const int64_t nxt = row + stride;
+        bf16x4 dyn[NCH], xn[NCH], rr[NCH];
+        float mun = 0.f, rsn = 0.f;
+        // in flight while this row is worked on: its residual gradient, and the next row's dy / x
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+                if (dres) rr[i] = *reinterpret_cast<const bf16x4*>(dres + row * d + c);
+                if (nxt < rows) {
+                    dyn[i] = *reinterpret_cast<const bf16x4*>(dy + nxt * d + c);
+                    xn[i] = *reinterpret_cast<const bf16x4*>(xin + nxt * d + c);
+                }
+            }
+        }
+        if (nxt < rows) {
+            mun = mean[nxt];
+            rsn = rstd[nxt];
+        }
+        f32x4 xh[NCH], gy[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+                const f32x4 dyv = cvt(dyr[i]);
+                xh[i] = (cvt(xr[i]) - mu) * rs;
+                gy[i] = dyv * load4(gamma + c);
+                dg[i] += dyv * xh[i];
+                db[i] += dyv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s1 += gy[i][j];
+                    s2 += gy[i][j] * xh[i][j];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / d;
+        s2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = (lane + 64 * i) * 4;
+            if (c < d) {
+                f32x4 o = (gy[i] - s1 - xh[i] * s2) * rs;
+                if (dres) o += cvt(rr[i]);
+                store4(dx + row * d + c, o);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            dyr[i] = dyn[i];
+            xr[i] = xn[i];
+        }
+        mu = mun;
+        rs = rsn;
+        row = nxt;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int w = 0; w < 4; ++w) {
+            __syncthreads();
+            if (wave == w) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int c = (lane + 64 * i) * 4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float val = pass == 0 ? dg[i][j] : db[i][j];
+                        red[c + j] = w == 0 ? val : red[c + j] + val;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        float* out = pass == 0 ? dgamma : dbeta;
         for (int c = threadIdx.x; c < d; c += 256) atomicAdd(out + c, red[c]);
     }
 }
@@ -514,6 +630,18 @@ static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, 
                            int64_t rows, int64_t d, void* dx_drop, const DropCfg& drop, const Q8Out& q8, hipStream_t st) {
     int64_t nb = cdiv(rows, 4);
     const bool ex = dx_drop != nullptr || q8.out != nullptr;
+    if constexpr (std::is_same<T, bf16_t>::value) {
+        // the pipelined kernel: plain bf16 launches of the 768-wide (and narrower) rows with enough rows to pipeline over (LECCR_LN_BWD_PIPE=0: the plain kernel)
+        static const int pipe = [] { const char* e = getenv("LECCR_LN_BWD_PIPE"); return e ? atoi(e) : 1; }();
+        if (pipe && !colsum_of && !ex && d <= 768 && rows >= 8192) {
+            const int64_t g = nb > 1024 ? 1024 : nb;
+#define LP(N) hipLaunchKernelGGL((layernorm_bwd_pipe_kernel<N>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)xin, gamma, mean, rstd, \
+                                 (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows, (int)d)
+            if (d <= 256) LP(1); else if (d <= 512) LP(2); else LP(3);
+#undef LP
+            return check_launch("layernorm_bwd (pipelined)");
+        }
+    }
     // 4 / 5 workgroups per CU fit (registers): exactly one round.  768 < d <= 1024 (four chunks per lane: 110 registers) fits 4 - with 1280
     // workgroups a fifth of them ran as a second round: 456 us against 356 us for the (4-per-CU) EX instantiation at [186880, 1024]
     const int64_t resident = (colsum_of || ex || (d > 768 && d <= 1024)) ? 1024 : 1280;

@@ -188,6 +188,53 @@ __global__ __launch_bounds__(256) void split3_t_kernel(const float* __restrict__
 
 using namespace leccr;
 
+// Every weight's two split copies in ONE launch (round 5): table[i] = {first tile, src (f32 [R, C], contiguous), dstG (bf16 [R, 3 C], form 1: the
+// [out, in] weight of the forward product), dstT (bf16 [C, 3 R], form 0 of src^T: the K-contiguous [in, out] copy of the dX product), R, C};
+// a block = one 32 x 32 tile.  The fp32 step used to split each weight at every use - 230 launches of 40 - 90 us for 6 - 28 MB of traffic each.
+__global__ __launch_bounds__(256) void split3_weights_kernel(const int64_t* __restrict__ table, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;                                  // last matrix whose first tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid * 6] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const int64_t* e = table + lo * 6;
+    const float* src = reinterpret_cast<const float*>(e[1]);
+    bf16_t* dg = reinterpret_cast<bf16_t*>(e[2]);
+    bf16_t* dt = reinterpret_cast<bf16_t*>(e[3]);
+    const int R = (int)e[4], C = (int)e[5];
+    const int t = (int)(blockIdx.x - e[0]), tiles_x = (C + 31) >> 5;
+    const int r0 = (t / tiles_x) * 32, c0 = (t % tiles_x) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        if (r0 + k < R && c0 + tx < C) {
+            const float x = src[(int64_t)(r0 + k) * C + c0 + tx];
+            tile[k][tx] = x;
+            bf16_t h, l;
+            split2(x, h, l);
+            bf16_t* d = dg + (int64_t)(r0 + k) * 3 * C + c0 + tx;            // form 1: hi | lo | hi
+            d[0] = h; d[C] = l; d[2 * (int64_t)C] = h;
+        }
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        if (c0 + k < C && r0 + tx < R) {
+            bf16_t h, l;
+            split2(tile[tx][k], h, l);
+            bf16_t* d = dt + (int64_t)(c0 + k) * 3 * R + r0 + tx;            // form 0 of the transpose: hi | hi | lo
+            d[0] = h; d[R] = h; d[2 * (int64_t)R] = l;
+        }
+    }
+}
+
+extern "C" int leccr_split3_weights_batched(const int64_t* table, int64_t n, int64_t total_tiles, void* stream) {
+    LECCR_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), LECCR_EINVAL, "split3_weights_batched: bad argument");
+    hipStream_t st = as_stream(stream);
+    ProfScope prof(PROF_SPLIT, 16.0 * 1024.0 * (double)total_tiles, st);
+    hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, table, (int)n);
+    return check_launch("split3_weights_batched");
+}
+
 extern "C" int leccr_split_n(const float* src, void* dst, int64_t rows, int64_t cols, int64_t ld, int form, int nseg, int transpose,
                              float* colsum, void* stream) {
     if (nseg == 3) return leccr_split3(src, dst, rows, cols, ld, form, transpose, colsum, stream);

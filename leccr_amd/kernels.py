@@ -615,6 +615,12 @@ def transpose_cast_batched(table, total_tiles):
           'leccr_transpose_cast_batched')
 
 
+def split3_weights_batched(table, total_tiles):
+    """Both split copies (G form [R, 3 C]; X form of the transpose [C, 3 R]) of every weight listed in `table` (int64 [n, 6] on the device:
+    first tile, src, dstG, dstT, R, C) in one launch: the fp32 path's counterpart of transpose_cast_batched (leccr_hip.h)."""
+    check(lib().leccr_split3_weights_batched(ptr(table), table.shape[0], int(total_tiles), stream()), 'leccr_split3_weights_batched')
+
+
 def fp8_requantize_weights(holders):
     """All fp8 weight copies in three launches (leccr_fp8_requantize_weights): holders carry _lp (bf16 [R, C]), _q8 ([R, C]), _q8t ([C, R])
     and _wsite.  Returns a closure that re-runs the batch (the table lives on the device, built once)."""

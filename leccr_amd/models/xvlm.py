@@ -17,7 +17,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .. import ops
+from .. import kernels, ops
 from ..arena import ParamArena
 from .bert import BertModel
 from .clip_vit import VIT_GEOMETRY, build_clip
@@ -269,6 +269,15 @@ class XVLMBase(nn.Module):
                     blk.fp8 = ops.X3
             for layer in self.text_encoder.encoder.layer:
                 layer.fp8 = ops.X3
+            # the weights' split copies once per optimizer step, all in one launch (round 5; they used to be split at every use: ~230
+            # launches of 40 - 90 us per step).  LECCR_X3_WCACHE=0: split at every use again.
+            if kernels.f32_mfma and kernels.NS == 3 and os.environ.get('LECCR_X3_WCACHE', '1') != '0':
+                for name, p in self.named_parameters():
+                    if p.dim() == 2 and not getattr(p, '_leccr_unused', False) and 'embeddings' not in name \
+                            and name != 'clip_encoder.visual.positional_embedding' and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
+                        a.need_split3(p)
+                for layer in self.text_encoder.encoder.layer:
+                    a.need_split3(layer._qkv_w)
         if getattr(self, 'caption_encoder_name', None) == 'clip' and self.clip_encoder is not None:
             self.clip_encoder.prepare_text_tower(self.compute_dtype)        # forward-only caption encoder: static compute copies
         a.refresh()

@@ -168,6 +168,16 @@ def _is_x3(t):
     return t is not None and t.dtype == torch.bfloat16
 
 
+def _w_split(w, transposed):
+    """The split copy of weight `w` a product of the fp32 path multiplies: [out, 3 in] in G form (forward), or [in, 3 out] = the X form of
+    W^T (dX).  From the per-step copies the arena keeps (ParamArena.need_split3: one launch for all weights after each optimizer step) where
+    they exist and the 3-segment form is on; else split here and now."""
+    c = getattr(w, '_s3t' if transposed else '_s3g', None)
+    if c is not None and K.NS == 3 and K.f32_mfma:
+        return c
+    return K.split3(w._lp, K.FORM_X, transpose=True) if transposed else K.split3(w._lp, K.FORM_G)
+
+
 def x8_of(fp8, x2, w, x8=None):
     """The e4m3 copy of x2 that Linear `w` multiplies in fp8 mode (x8 if the producer wrote it), None when that product is bf16.
     Mode X3: the X-form split copy of the f32 x2."""
@@ -242,7 +252,7 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
     output: once that site has a scale, the epilogue also writes the output's fp8 copy under it (no separate quantise pass over
     it).  want8: return (y, y8 or None) instead of y.  c8_only (fp8_only_ok): y itself is not written, (None, y8) comes back."""
     if fp8 == X3 and _is_x3(x8):              # f32 operands as bf16 hi / lo splits: x8 = X-form copy of x2, the weight split in G form
-        w3 = K.split3(w._lp, K.FORM_G)
+        w3 = _w_split(w, False)
         K.f32_split_launches += 1             # (counted like the products kernels.gemm splits by itself)
         if want8 and c3_consumer is not None and fuse_x3_copies and K.NS == 3 and _x3_lin_ok(x8.shape[0], c3_consumer):
             # the Linear that consumes this output reads only its X-form split copy (forward and weight-gradient product): the GEMM's
@@ -269,7 +279,7 @@ def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False,
     """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N].
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
     if fp8 == X3 and _is_x3(g8):              # G-form copy of dY against the X-form split of W^T ([in, 3 out], K-contiguous)
-        w3t = K.split3(w._lp, K.FORM_X, transpose=True)
+        w3t = _w_split(w, True)
         K.f32_split_launches += 1
         if want8 and c3_consumer is not None and fuse_x3_copies and K.NS == 3 and _x3_lin_ok(g8.shape[0], c3_consumer) \
                 and K.gemm256_takes(g8.shape[0], w3t.shape[0], w3t.shape[1]):

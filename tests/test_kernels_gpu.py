@@ -1021,6 +1021,27 @@ def test_fp8_quantize_scales_saturates_and_tracks_amax(K, fmt):
     assert torch.equal(y2.view(torch.uint8), (xf[:, :256] * float(s2.row[1])).to(y2.dtype).view(torch.uint8))
 
 
+def test_split3_weights_batched_equals_the_per_tensor_passes(K):
+    """leccr_split3_weights_batched (round 5): the G-form [R, 3 C] copy and the X-form copy of the transpose [C, 3 R] of several weights in ONE
+    launch - bit for bit what leccr_split3 writes for each of them (the fp32 path made these copies at every use of a weight: ~230 launches a
+    step; now once per optimizer step through ParamArena.need_split3)."""
+    shapes = [(768, 768), (2304, 768), (768, 3072), (256, 512), (96, 40)]
+    ws = [_rand(sh, torch.float32, 700 + i).to(DEV).contiguous() for i, sh in enumerate(shapes)]
+    outs, rows, tiles = [], [], 0
+    for w in ws:
+        R, C = w.shape
+        g = torch.full((R, 3 * C), float('nan'), dtype=torch.bfloat16, device=DEV)
+        t = torch.full((C, 3 * R), float('nan'), dtype=torch.bfloat16, device=DEV)
+        outs.append((g, t))
+        rows.append([tiles, w.data_ptr(), g.data_ptr(), t.data_ptr(), R, C])
+        tiles += ((R + 31) // 32) * ((C + 31) // 32)
+    table = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    K.split3_weights_batched(table, tiles)
+    for w, (g, t) in zip(ws, outs):
+        assert torch.equal(g, K.split3(w, K.FORM_G))
+        assert torch.equal(t, K.split3(w, K.FORM_X, transpose=True))
+
+
 @pytest.mark.parametrize('fmt', [0, 1])
 def test_fp8_delayed_scale_follows_an_amax_spike_and_its_decay(K, fmt):
     """Fp8Sites.update() leaves keep = 0.9 x the amax behind as the next step's running maximum (round 4: 5000 resident waves no longer fire
