@@ -482,8 +482,11 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
         i2t, t2i = evaluation_coarse(model, loader, Tok(), device, ecfg)
         return i2t, t2i, itm_eval(i2t, t2i, txt2img, img2txt, device=device)
 
+    from leccr_amd.parallel import collective_path
+    multi = collective_path(world)
+
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -495,7 +498,7 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
         i2t, t2i, res = one_pass()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -557,7 +560,7 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
         print(json.dumps(out), file=real_stdout, flush=True)
         if not out['parity']['ok']:
             raise SystemExit(f"bench.py --mode eval: parity outside tolerance: {out['parity']}")
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -654,7 +657,7 @@ def _main(args, real_stdout):
     import torch.distributed as dist
     from leccr_amd import _lib, ops
     from leccr_amd.optim import create_optimizer
-    from leccr_amd.parallel import attach_grad_sync, init_distributed_mode, rccl_cus
+    from leccr_amd.parallel import attach_grad_sync, collective_path, init_distributed_mode, rccl_cus
     from leccr_amd.scheduler import create_scheduler
     # RCCL ('nccl') over xGMI, one rank per GPU.  LECCR_BENCH_BACKEND=gloo is a rehearsal aid only: it lets two ranks share
     # the single GPU of a development box to exercise this N > 1 control flow (not a measurement configuration).
@@ -663,6 +666,7 @@ def _main(args, real_stdout):
     if world != args.gpus:
         raise SystemExit(f'bench.py: world size {world} != --gpus {args.gpus} (launch with torch.distributed.run '
                          f'--nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` bare and let it start the ranks)')
+    multi = collective_path(world)      # world > 1, or LECCR_ONE_RANK_WORLD=1: a one-rank RCCL world that takes the collective path (rehearsal)
     if os.environ.get('LECCR_BENCH_DRYRUN') == '1':
         return dry_run(args, rank, world, backend, real_stdout)
     if backend != 'nccl':
@@ -677,7 +681,7 @@ def _main(args, real_stdout):
     sched.step()                                                  # leave lr = 0 (first LambdaLR value) behind
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -697,7 +701,7 @@ def _main(args, real_stdout):
     dt = time.perf_counter() - t0
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
@@ -744,7 +748,7 @@ def _main(args, real_stdout):
     # stage, the exposed part of the gradient all-reduce and the backward pass - every rank's figures go into the JSON, so that the first
     # multi-GPU run yields a diagnosis (which rank waits where) and not only a curve.  After the timed region; never inside it.
     stage_ms = None
-    if world > 1 or os.environ.get('LECCR_BENCH_DIAG') == '1':
+    if multi or os.environ.get('LECCR_BENCH_DIAG') == '1':
         from leccr_amd import diag
         diag.enabled = True
         diag.reset()
@@ -763,7 +767,7 @@ def _main(args, real_stdout):
         mine = diag.report()
         diag.enabled = False
         stage_ms = {f'rank{rank}': mine}
-        if world > 1:
+        if multi:
             try:                                    # (diagnostics must never cost the run its result line)
                 allr = [None] * world
                 dist.all_gather_object(allr, mine)
@@ -821,7 +825,7 @@ def _main(args, real_stdout):
                             'algorithmic_gb_per_step': round(leg_work[k] / leg / 1e9, 3), 'achieved_tb_s': round(tbs, 3),
                             'frac_of_hbm_peak': round(tbs / HBM_PEAK_TBS, 3)})
         try:
-            rccl = '.'.join(map(str, torch.cuda.nccl.version())) if world > 1 else None
+            rccl = '.'.join(map(str, torch.cuda.nccl.version())) if multi else None
         except Exception:                                                            # noqa: BLE001 (reporting only)
             rccl = None
         fpair = F_PAIR_GFLOP.get((args.model, args.clip, args.text))
@@ -839,7 +843,7 @@ def _main(args, real_stdout):
                        'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
                        'peak_hbm_reserved_gb': round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
                        'alloc_retries': int(torch.cuda.memory_stats().get('num_alloc_retries', 0)),
-                       'world': world, 'backend': backend if world > 1 else None, 'rccl_version': rccl,
+                       'world': world, 'backend': backend if multi else None, 'rccl_version': rccl,
                        'NCCL_MAX_NCHANNELS': os.environ.get('NCCL_MAX_NCHANNELS'), 'LECCR_RCCL_CUS': rccl_cus()},
             'roofline': {'bound': 'mfma', 'kernel': ('gemm256 family (256x256 MFMA GEMMs: 8-wave NT forward / dX, 4-wave TN weight gradient'
                                                      + (', fp8-operand 4-wave NT / TN' if args.dtype == 'fp8' else '') + ')'
@@ -886,7 +890,7 @@ def _main(args, real_stdout):
             ref_prec = reference_precision_leg(args, device, rank)
             out['reference_precision'] = ref_prec
         print(json.dumps(out), file=real_stdout, flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     if parity is not None and not parity['ok']:

@@ -13,6 +13,7 @@ import torch
 import torch.distributed as dist
 
 from . import kernels as K
+from .parallel import collective_path
 
 
 def _ranks(scores, gt_lists, device):
@@ -172,7 +173,7 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
         D = model.embed_dim
         e = torch.cat(chunks, dim=0).float() if chunks else torch.zeros(0, D, device=device)
         r = torch.cat(rows) if rows else torch.zeros(0, device=device, dtype=torch.int64)
-        return e.contiguous() if world == 1 else _gather_rows_varlen(e.contiguous(), r, total)
+        return e.contiguous() if not collective_path(world) else _gather_rows_varlen(e.contiguous(), r, total)
 
     text_embeds = assemble(text_embeds, text_rows, num_text)
     image_embeds = assemble(image_embeds, image_rows, n_img)

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from .. import kernels, ops
 from ..arena import ParamArena
+from ..parallel import collective_path
 from .bert import BertModel
 from .clip_vit import VIT_GEOMETRY, build_clip
 from .layers import Linear, mark_unused
@@ -97,7 +98,7 @@ class StepGathers:
 
     def rows(self, t):
         rank, world = _dist_info()
-        if world == 1:
+        if not collective_path(world):
             return t
         hit = self.hit.get(self._key(t))
         if hit is not None:
@@ -110,7 +111,7 @@ class StepGathers:
         """All-gather the f32 blocks `tensors` (and the int64 column `idx`, bit-cast to two f32 words per row) in one collective
         and remember the results for rows()."""
         rank, world = _dist_info()
-        if world == 1:
+        if not collective_path(world):
             return
         srcs = [t for t in tensors if self._key(t) not in self.hit]
         assert all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs)
@@ -149,7 +150,7 @@ def gather_rows_packed(tensors, idx=None):
 def local_rows(b):
     """(row0, nrows) of this rank's b rows inside an all-gathered [W*b, ...] tensor, or None on a single rank."""
     rank, world = _dist_info()
-    return None if world == 1 else (rank * b, b)
+    return None if not collective_path(world) else (rank * b, b)
 
 
 def build_mlp(input_dim, output_dim):

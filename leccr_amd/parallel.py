@@ -44,10 +44,23 @@ def init_distributed_mode(backend=None):
     if torch.cuda.is_available():
         torch.cuda.set_device(local % torch.cuda.device_count())     # (ranks outnumber GPUs only in gloo rehearsals)
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend or ('nccl' if torch.cuda.is_available() else 'gloo'),
-                                init_method='env://', world_size=world, rank=rank)
+        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        # RCCL: the rank's device is named up front (no "guessing device ID based on global rank" at the first barrier)
+        dev = {'device_id': torch.device('cuda', torch.cuda.current_device())} if backend == 'nccl' else {}
+        dist.init_process_group(backend=backend, init_method='env://', world_size=world, rank=rank, **dev)
         dist.barrier()
     return rank, world, local
+
+
+def one_rank_world():
+    """LECCR_ONE_RANK_WORLD=1: a process group of ONE rank takes the collective path all the same (packed all-gather, phased all-reduce on the
+    reduce stream, sharded-evaluation gathers).  A rehearsal aid for a one-GPU box: every RCCL call of the N > 1 path is issued for real
+    (tests/test_dist_gpu.py::test_one_rank_rccl_world_*), on a communicator that has nobody to talk to."""
+    return os.environ.get('LECCR_ONE_RANK_WORLD') == '1' and dist.is_available() and dist.is_initialized()
+
+
+def collective_path(world):
+    return world > 1 or one_rank_world()
 
 
 def attach_grad_sync(optimizer):
@@ -57,7 +70,7 @@ def attach_grad_sync(optimizer):
     the ViT backward starts (ops.on_late_backward_start fires in the first ViT backward node, when every other gradient
     is final) and overlaps it on RCCL's stream; the ViT region follows in thirds as the block backwards complete
     (ops.on_vit_block_backward), the last third at optimizer.step()."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or not collective_path(dist.get_world_size()):
         return optimizer
     from . import ops
     world = dist.get_world_size()

@@ -116,5 +116,5 @@ def init_distributed_mode(args):
     args.dist_backend = 'nccl'
     print('| distributed init (rank {}): {}'.format(args.rank, args.dist_url), flush=True)
     dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size,
-                            rank=args.rank)
+                            rank=args.rank, device_id=torch.device('cuda', args.gpu))
     dist.barrier()
