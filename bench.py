@@ -676,7 +676,9 @@ def _main(args, real_stdout):
     if args.mode == 'eval':
         return eval_bench(args, device, rank, world, backend, real_stdout)
     model, cfg, batch, fwd, what = build_workload(args, device, rank)
-    opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model)).enable_backward_fusion()
+    opt = attach_grad_sync(create_optimizer(cfg['optimizer'], model))
+    if os.environ.get('LECCR_BENCH_NO_FUSION') != '1':              # (A/B: the early region's AdamW update beside the ViT backward)
+        opt.enable_backward_fusion()
     sched = create_scheduler(dict(cfg['schedular'], step_per_epoch=1000), opt)
     sched.step()                                                  # leave lr = 0 (first LambdaLR value) behind
 

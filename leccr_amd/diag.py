@@ -7,10 +7,27 @@ synchronises and returns {name: mean ms per occurrence, name + '_n': occurrences
   allreduce_exposed    the time optimizer.step() spends waiting for RCCL (leccr_amd.parallel sync(): what the backward did not hide)
   backward             loss.backward() as seen by the main stream (bench.py)
 """
+import contextlib
+import time
+
 import torch
 
 enabled = False
-_open, _spans = {}, {}
+_open, _spans, _host = {}, {}, {}
+
+
+@contextlib.contextmanager
+def host(name):
+    """Host time of a hook of the exchange path (they run on autograd's thread, where no Python profiler looks): report() gives
+    name + '_host_ms' (mean per call) and name + '_host_n'."""
+    if not enabled:
+        yield
+        return
+    t = time.perf_counter()
+    try:
+        yield
+    finally:
+        _host.setdefault(name, []).append((time.perf_counter() - t) * 1e3)
 
 
 def begin(name):
@@ -30,6 +47,7 @@ def end(name):
 def reset():
     _open.clear()
     _spans.clear()
+    _host.clear()
 
 
 def report():
@@ -39,4 +57,7 @@ def report():
         ms = [a.elapsed_time(b) for a, b in spans]
         out[name + '_ms'] = round(sum(ms) / len(ms), 3)
         out[name + '_n'] = len(ms)
+    for name, ms in _host.items():
+        out[name + '_host_ms'] = round(sum(ms) / len(ms), 3)
+        out[name + '_host_n'] = len(ms)
     return out

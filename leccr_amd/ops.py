@@ -365,6 +365,44 @@ def caption_stream(device):
     return _caption_stream
 
 
+def wgrad_stream(device):
+    """The weight-gradient stream (created at the first weight-gradient launch, or ahead of it by bind_streams)."""
+    global _wgrad_stream
+    if _wgrad_stream is None:
+        _wgrad_stream = torch.cuda.Stream(device=device)
+    return _wgrad_stream
+
+
+_update_stream = None
+
+
+def update_stream(device):
+    """The stream of the early region's fused AdamW update (optim.ArenaAdamW._early_update)."""
+    global _update_stream
+    if _update_stream is None:
+        _update_stream = torch.cuda.Stream(device=device)
+    return _update_stream
+
+
+def bind_streams(device):
+    """HIP binds a stream to one of GPU_MAX_HW_QUEUES (4, and 5 or more is slower: DESIGN.md 5a) hardware queues at its FIRST launch, the
+    least-shared queue first; streams on one queue run in order.  A single process finds main / caption / text / weight-gradient on a
+    queue each (the update stream shares the weight-gradient one) simply by the order its first step uses them.  A process that joins a
+    process group first does not: RCCL and c10d launch on half a dozen streams of their own at communicator creation, and the step's
+    streams then land wherever is left - measured in a one-rank world: the caption tower on the MAIN stream's queue, +2.1 ms per step
+    (profiles/r05_stream_queue_binding.txt).  Called by both init_distributed_mode paths BEFORE init_process_group: one tiny launch
+    on each stream, in the order of a step."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return
+    torch.zeros(1, device=device)
+    for s in (caption_stream(device), text_stream(device), wgrad_stream(device) if wgrad_overlap else None, update_stream(device)):
+        if s is not None:
+            with torch.cuda.stream(s):
+                torch.zeros(1, device=device)
+    torch.cuda.synchronize(device)
+
+
 def side_streams():
     return [s for s in (_wgrad_stream, _text_stream) if s is not None]
 
@@ -425,9 +463,7 @@ def lin_dw(dy2, x2, w, b=None, scale=1.0, dy_bias=None, g8=None, x8=None, bias_d
     if _pass_inline:
         return _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8, bias_done)
     main = torch.cuda.current_stream()
-    if _wgrad_stream is None:
-        _wgrad_stream = torch.cuda.Stream(device=ref.device)
-    side = _wgrad_stream
+    side = wgrad_stream(ref.device)
     side.wait_stream(main)                      # dY and X were produced on the main stream
     with torch.cuda.stream(side):
         _lin_dw(dy2, x2, w, b, scale, dy_bias, g8, x8, bias_done)

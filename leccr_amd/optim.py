@@ -50,12 +50,15 @@ class ArenaAdamW(torch.optim.Optimizer):
         split = a.early_numel
         if not self.backward_fusion or self._early_updated or not (0 < split < a.numel) or not a.data.is_cuda:
             return
-        from . import ops
+        from . import diag, ops
         g = self.param_groups[0]
         main = torch.cuda.current_stream()
-        if self._update_stream is None:
-            self._update_stream = torch.cuda.Stream(device=a.data.device)
-        us = self._update_stream
+        with diag.host('early_update'):
+            self._early_update_launch(a, split, g, main, ops)
+        self._early_updated = True
+
+    def _early_update_launch(self, a, split, g, main, ops):
+        us = self._update_stream = ops.update_stream(a.data.device)
         a.mark_autograd_grads(0, split)
         us.wait_stream(main)                    # interaction / heads / losses backward
         ops.join_wgrad_stream(us)               # text-tower backward and every weight-gradient launch so far
@@ -64,7 +67,6 @@ class ArenaAdamW(torch.optim.Optimizer):
                 w.wait()
             a.adamw_step(g['lr'], g['betas'], g['eps'], self._decay_of, self.grad_scale, 0, split, step=a.step_count + 1)
             a.refresh(adamw_wrote_lp=True, lo=0, hi=split)
-        self._early_updated = True
 
     def zero_grad(self, set_to_none=False):
         self.arena.zero_grad()

@@ -43,6 +43,8 @@ def init_distributed_mode(backend=None):
     setup_rccl_env()
     if torch.cuda.is_available():
         torch.cuda.set_device(local % torch.cuda.device_count())     # (ranks outnumber GPUs only in gloo rehearsals)
+        from . import ops
+        ops.bind_streams(torch.device('cuda', torch.cuda.current_device()))     # before RCCL takes its share of the hardware queues
     if not dist.is_initialized():
         backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
         # RCCL: the rank's device is named up front (no "guessing device ID based on global rank" at the first barrier)
@@ -72,15 +74,33 @@ def attach_grad_sync(optimizer):
     (ops.on_vit_block_backward), the last third at optimizer.step()."""
     if not (dist.is_available() and dist.is_initialized()) or not collective_path(dist.get_world_size()):
         return optimizer
-    from . import ops
+    from . import diag, ops
     world = dist.get_world_size()
     arena = optimizer.arena
     grad, split = arena.grad, arena.early_numel
     pending = []
 
+    # RCCL on device tensors: the collectives are issued as SYNCHRONOUS ops, which c10d enqueues on the CURRENT stream (no internal stream
+    # of RCCL's process group, no handles: torch >= 2.8), and that stream is the caption tower's - idle for the whole backward pass, with a
+    # hardware queue of its own (ops.bind_streams).  What the rest of the code waits for is an event on it.  gloo (CPU tests, the
+    # one-GPU rehearsals): async handles as before.
+    on_stream = grad.is_cuda and dist.get_backend() == 'nccl'
+
+    class _Done:
+        def __init__(self, stream):
+            self.ev = torch.cuda.Event()
+            self.ev.record(stream)
+
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
     def reduce_range(lo, hi):
         for o in range(lo, hi, _BUCKET):
-            pending.append(dist.all_reduce(grad[o:min(o + _BUCKET, hi)], async_op=True))
+            w = dist.all_reduce(grad[o:min(o + _BUCKET, hi)], async_op=not on_stream)
+            if not on_stream:
+                pending.append(w)
+        if on_stream and hi > lo:
+            pending.append(_Done(torch.cuda.current_stream()))
 
     reduce_stream = []
     late = {'hi': grad.numel()}               # [late['hi'], numel) of the ViT region is already handed to RCCL
@@ -92,12 +112,12 @@ def attach_grad_sync(optimizer):
             _lib.lib().leccr_set_gemm_max_blocks(n)
 
     def reduce_async(lo, hi):
-        """All launches that write grad[lo:hi] are enqueued (on the main, text and weight-gradient streams): a stream of its own
-        waits for the three and hands the all-reduces to RCCL, so the main stream goes straight on with the backward pass."""
+        """All launches that write grad[lo:hi] are enqueued (on the main, text and weight-gradient streams): the reduce stream
+        waits for the three and takes the all-reduces, so the main stream goes straight on with the backward pass."""
         if grad.is_cuda:
             gemm_cus(256 - cus)     # from here until sync(): GEMM launches leave RCCL its CUs (no-op unless LECCR_RCCL_CUS > 0)
             if not reduce_stream:
-                reduce_stream.append(torch.cuda.Stream(device=grad.device))
+                reduce_stream.append((ops.caption_stream(grad.device) if on_stream else None) or torch.cuda.Stream(device=grad.device))
             rs = reduce_stream[0]
             rs.wait_stream(torch.cuda.current_stream())
             ops.join_wgrad_stream(rs)
@@ -109,7 +129,8 @@ def attach_grad_sync(optimizer):
     def early():
         # first ViT backward node: autograd has run the younger text-tower / interaction nodes, the early region is final
         if not pending:                       # once per step
-            reduce_async(0, split)
+            with diag.host('reduce_early'):
+                reduce_async(0, split)
             optimizer._early_handles = list(pending)     # a fused early update (optim.py) waits for exactly these
 
     def vit_block(blk):
@@ -119,16 +140,20 @@ def attach_grad_sync(optimizer):
         end = max(arena.offsets[p._aidx] + p.numel() for p in blk.parameters())
         end = min((end + 63) // 64 * 64, late['hi'])
         if late['hi'] - end >= (grad.numel() - split) // 3:
-            reduce_async(end, late['hi'])
+            with diag.host('reduce_vit_third'):
+                reduce_async(end, late['hi'])
             late['hi'] = end
 
     def sync():
+        with diag.host('grad_sync'):
+            _sync()
+
+    def _sync():
         ops.join_wgrad_stream()
         if not pending:                       # no ViT backward ran (e.g. a text-only step): reduce everything now
             reduce_range(0, split)
         reduce_range(split, late['hi'])
         late['hi'] = grad.numel()
-        from . import diag
         diag.begin('allreduce_exposed')          # how long the stream of optimizer.step() waits here = what the backward did not hide
         for w in pending:
             w.wait()
@@ -136,8 +161,9 @@ def attach_grad_sync(optimizer):
         pending.clear()
         gemm_cus(0)
 
-    arena.on_late_backward_start = early if split < grad.numel() else None       # this arena's backward only (ops._fire)
-    arena.on_vit_block_backward = vit_block if split < grad.numel() else None
+    phased = split < grad.numel() and os.environ.get('LECCR_DDP_PHASES', '1') != '0'      # 0: one exchange at optimizer.step() (A/B)
+    arena.on_late_backward_start = early if phased else None       # this arena's backward only (ops._fire)
+    arena.on_vit_block_backward = vit_block if phased else None
     optimizer.grad_sync = sync
     optimizer.grad_scale = 1.0 / world
     return optimizer

@@ -113,6 +113,8 @@ def init_distributed_mode(args):
     from .parallel import setup_rccl_env
     setup_rccl_env()                       # the same RCCL environment as leccr_amd.parallel.init_distributed_mode
     torch.cuda.set_device(args.gpu)
+    from . import ops
+    ops.bind_streams(torch.device('cuda', args.gpu))      # before RCCL takes its share of the hardware queues
     args.dist_backend = 'nccl'
     print('| distributed init (rank {}): {}'.format(args.rank, args.dist_url), flush=True)
     dist.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size,
