@@ -380,7 +380,8 @@ def update_stream(device):
     """The stream of the early region's fused AdamW update (optim.ArenaAdamW._early_update)."""
     global _update_stream
     if _update_stream is None:
-        _update_stream = torch.cuda.Stream(device=device)
+        cap = caption_stream(device) if os.environ.get('LECCR_UPDATE_STREAM', 'own') == 'caption' else None
+        _update_stream = cap if cap is not None else torch.cuda.Stream(device=device)
     return _update_stream
 
 
