@@ -67,6 +67,9 @@ int leccr_debug_set_stamps(void* device_buffer);   /* diagnostic builds only (-D
                                                 * 256x256 GEMM leaves its in-kernel s_memtime stamps; a no-op pointer store in the
                                                 * production build (no stamp instruction is compiled in) */
 
+int leccr_debug_occupy(int blocks, int threads, int64_t microseconds, void* stream);   /* diagnostic: `blocks` workgroups that hold a CU slot for
+                                                * that long and exit - a stand-in for a collective's resident workgroups on a one-GPU box */
+
 /* ---- GEMM -------------------------------------------------------------------------------------------------
  * C[M,N] = epilogue( alpha * sum_k A(m,k) * B(n,k) )      (+ C if accumulate)
  *   trans_a = 0: A is [M,K] row-major (lda >= K)      trans_a = 1: A is [K,M] row-major (lda >= M)

@@ -45,6 +45,7 @@ _SIGS = {
     'leccr_split3': ([vp, vp, i64, i64, i64, C.c_int, C.c_int, vp, vp], C.c_int),
     'leccr_split_n': ([vp, vp, i64, i64, i64, C.c_int, C.c_int, C.c_int, vp, vp], C.c_int),
     'leccr_debug_set_stamps': ([vp], C.c_int),
+    'leccr_debug_occupy': ([C.c_int, C.c_int, C.c_int64, vp], C.c_int),
     'leccr_layernorm_fwd': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, C.c_int, vp], C.c_int),
     'leccr_layernorm_bwd': ([vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, i64, i64, C.c_int, vp], C.c_int),
     'leccr_layernorm_fwd_drop': ([vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, C.c_uint64, C.c_int, vp], C.c_int),

@@ -117,5 +117,19 @@ extern "C" int leccr_prof_read_union(int kind_mask, double* busy_ms, double* wor
     return LECCR_OK;
 }
 
+// Diagnostic: `blocks` workgroups of `threads` lanes that do nothing for `us` microseconds and exit (every wave watches the constant 100 MHz
+// clock, so the grid drains by itself).  Stands in for a collective's resident workgroups when there is no second GPU to talk to: what a
+// communication kernel does to the persistent GEMMs beside it is first of all to HOLD compute units (scripts/r5_rccl_cus.sh).
+__global__ void occupy_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+extern "C" int leccr_debug_occupy(int blocks, int threads, int64_t us, void* stream) {
+    if (blocks < 1 || blocks > 256 || threads < 64 || threads > 1024 || us < 0 || us > 100000) return LECCR_EINVAL;
+    hipLaunchKernelGGL(occupy_kernel, dim3(blocks), dim3(threads), 0, (hipStream_t)stream, (long long)us * 100);
+    return hipGetLastError() == hipSuccess ? LECCR_OK : LECCR_EINVAL;
+}
+
 extern "C" int leccr_version(void) { return 3; }      // 3: leccr_gemm_params.c3 / c3_form, leccr_split3, leccr_debug_set_stamps declared
 extern "C" const char* leccr_last_error(void) { return leccr::g_err; }

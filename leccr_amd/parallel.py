@@ -4,11 +4,15 @@ The reference wraps the model in torch DistributedDataParallel (image_Retrieval_
 gradients live in ONE flat f32 arena, so the gradient exchange is a few large all-reduces over contiguous memory
 (mean over ranks = SUM then the 1/W folded into the fused AdamW launch), issued from optimizer.step().
 """
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
+# LECCR_EMULATE_RCCL="blocks:us_per_GB" (diagnostic, one-rank worlds): after each phased all-reduce, `blocks` workgroups hold their CUs for
+# us_per_GB x the gigabytes reduced - what an RCCL kernel of that many channels does to the GEMMs beside it (scripts/r5_rccl_cus.sh)
+_EMULATE = tuple(int(x) for x in os.environ['LECCR_EMULATE_RCCL'].split(':')) if os.environ.get('LECCR_EMULATE_RCCL') else None
 _BUCKET = 64 * 1024 * 1024      # elements per all-reduce (256 MiB f32): large, few collectives (xGMI per-link bound)
 
 
@@ -123,6 +127,11 @@ def attach_grad_sync(optimizer):
             ops.join_wgrad_stream(rs)
             with torch.cuda.stream(rs):
                 reduce_range(lo, hi)
+                if _EMULATE:            # (diagnostic) stand-in for the collective's resident workgroups: blocks:us per GB reduced
+                    from . import _lib
+                    us = int(_EMULATE[1] * (hi - lo) * 4 / 1e9)
+                    _lib.lib().leccr_debug_occupy(_EMULATE[0], 256, us, ctypes.c_void_p(rs.cuda_stream))
+                    pending.append(_Done(rs))
         else:
             reduce_range(lo, hi)
 
