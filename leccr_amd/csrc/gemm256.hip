@@ -1039,7 +1039,11 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
         // row-major vs 602-640 grouped, fc1 688 vs 684-738): the re-fetched weight panels are Infinity-Cache hits, and the K loop is
         // not waiting for them.  Row-major stays the default.
         static const int env_group = [] { const char* e = getenv("LECCR_G256_COLGROUP"); return e ? atoi(e) : 0; }();
-        const int cg = env_group > 0 && env_group < a.tiles_n ? env_group : 0;
+        // Round 5, with non-temporal output stores: still no lever for the step's shapes (tiles_n <= 16: profiles/r05_gemm256_colgroup_again.txt),
+        // but a very wide output (8192^3: 32 tile columns - the row-major walk streams all of B through each XCD's 4 MiB L2 once per tile row)
+        // gains 5 % from groups of 8 (1245 -> 1307 - 1318 TFLOP/s on one box).  Automatic from 24 tile columns up; LECCR_G256_COLGROUP=-1: never.
+        const int want = env_group != 0 ? env_group : (a.tiles_n >= 24 ? 8 : 0);
+        const int cg = want > 0 && want < a.tiles_n ? want : 0;
         a.col_group = cg;
     }
     a.nkt = (int)cdiv(ktiles, splits);

@@ -696,6 +696,19 @@ def test_gemm256_n4_takes_whole_tiles_only(K):
         lib.leccr_set_gemm_variant(0)
 
 
+@pytest.mark.parametrize('M,N,K_', [(2304, 6400, 192), (2049, 8192, 128), (4352, 6144, 256)])
+def test_gemm256_walks_wide_outputs_in_column_groups(K, M, N, K_):
+    """24 or more tile columns: the 8-wave kernel walks the tiles of an XCD band in groups of 8 columns (decode() with col_group; a last
+    narrower group when the count is no multiple of 8, bands of unequal height, a row tail) - every tile exactly once, bias in the epilogue."""
+    from leccr_amd import _lib
+    a, b = _rand((M, K_), torch.bfloat16, 611), _rand((N, K_), torch.bfloat16, 612, 0.05)
+    bias = _rand((N,), torch.float32, 613)
+    out = K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV))
+    assert _lib.lib().leccr_last_gemm_kernel() == 2
+    e, s = _err(out, a.double() @ b.double().t() + bias.double())
+    assert e <= 1.2e-2 * s
+
+
 @pytest.mark.parametrize('M,N,K_', [(1154, 768, 256), (2000, 1024, 128), (300, 260, 64), (40, 24, 16)])
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32])
 def test_gemm_fused_colsum(K, dtype, M, N, K_):
