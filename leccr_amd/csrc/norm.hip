@@ -239,12 +239,16 @@ __global__ __launch_bounds__(256, NCH <= 3 ? ((CS || EX) ? 4 : 5) : (NCH == 4 ? 
 // launch on [147712, 768] is bound by those two latencies per row (188 us = 4.8 TB/s), not by bytes.  Here a wave issues the NEXT row's dy / x loads
 // and THIS row's residual-gradient load before it touches the current row's values (packed bf16: 18 more registers, 4 waves per SIMD instead of 5,
 // but 2.5 rows in flight per wave instead of 1).  Same arithmetic, same order of the dgamma / dbeta sums per wave: results identical to the plain kernel.
-template <int NCH>
-__global__ __launch_bounds__(256, 4) void layernorm_bwd_pipe_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xin, const float* __restrict__ gamma,
+// EX: the second outputs of the plain kernel's EX instantiation (dropout(dx), the fp8 copy of the gradient the dense layer sees); NCH = 4: the 1024-wide rows
+// of ViT-L / XLM-R-large (3 waves per SIMD there).
+template <int NCH, bool EX>
+__global__ __launch_bounds__(256, (NCH <= 3 && !EX) ? 4 : 3) void layernorm_bwd_pipe_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ xin, const float* __restrict__ gamma,
                                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                     const bf16_t* __restrict__ dres, bf16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                                                    float* __restrict__ dbeta, int64_t rows, int d) {
+                                                                    float* __restrict__ dbeta, int64_t rows, int d, bf16_t* __restrict__ dx_drop, DropCfg drop, Q8Out q8) {
     __shared__ float red[NCH * 256];
+    [[maybe_unused]] float q8sc = 1.f, q8m = 0.f;
+    if constexpr (EX) q8sc = q8.out ? q8.site[1] : 1.f;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 dg[NCH], db[NCH];
 #pragma unroll
@@ -316,6 +320,23 @@ __global__ __launch_bounds__(256, 4) void layernorm_bwd_pipe_kernel(const bf16_t
                 f32x4 o = (gy[i] - s1 - xh[i] * s2) * rs;
                 if (dres) o += cvt(rr[i]);
                 store4(dx + row * d + c, o);
+                if constexpr (EX) {
+                    f32x4 od = o;
+                    if (dx_drop) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) od[j] = to_f32(from_f32<bf16_t>(o[j])) * drop_mul(drop, (uint32_t)(row * d + c + j));
+                        store4(dx_drop + row * d + c, od);
+                    }
+                    if (q8.out) {
+                        float r[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            r[j] = to_f32(from_f32<bf16_t>(od[j]));
+                            q8m = fmaxf(q8m, fabsf(r[j]));
+                        }
+                        *reinterpret_cast<int*>(q8.out + row * d + c) = q8_pack4(q8, q8sc, r[0], r[1], r[2], r[3]);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -326,6 +347,9 @@ __global__ __launch_bounds__(256, 4) void layernorm_bwd_pipe_kernel(const bf16_t
         mu = mun;
         rs = rsn;
         row = nxt;
+    }
+    if constexpr (EX) {
+        if (q8.out) q8_amax(q8, q8m);
     }
     for (int pass = 0; pass < 2; ++pass) {
         for (int w = 0; w < 4; ++w) {
@@ -633,11 +657,14 @@ static int ln_bwd_dispatch(const void* dy, const void* xin, const float* gamma, 
     if constexpr (std::is_same<T, bf16_t>::value) {
         // the pipelined kernel: plain bf16 launches of the 768-wide (and narrower) rows with enough rows to pipeline over (LECCR_LN_BWD_PIPE=0: the plain kernel)
         static const int pipe = [] { const char* e = getenv("LECCR_LN_BWD_PIPE"); return e ? atoi(e) : 1; }();
-        if (pipe && !colsum_of && !ex && d <= 768 && rows >= 8192) {
-            const int64_t g = nb > 1024 ? 1024 : nb;
-#define LP(N) hipLaunchKernelGGL((layernorm_bwd_pipe_kernel<N>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)xin, gamma, mean, rstd, \
-                                 (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows, (int)d)
-            if (d <= 256) LP(1); else if (d <= 512) LP(2); else LP(3);
+        // (round 5, second step: the EX outputs and the 1024-wide rows too - 3 workgroups per CU there; LECCR_LN_BWD_PIPE=2: only the first step's launches)
+        if (pipe && !colsum_of && d <= 1024 && rows >= 8192 && (pipe != 2 || (!ex && d <= 768))) {
+            const int64_t cap = d <= 768 ? 1024 : 768;      // workgroups per CU x 256: 4 up to 768-wide rows (116 - 128 registers), 3 at 1024 (142 - 152)
+            const int64_t g = nb > cap ? cap : nb;
+#define LP(N, EX_) hipLaunchKernelGGL((layernorm_bwd_pipe_kernel<N, EX_>), dim3((unsigned)g), dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)xin, gamma, mean, rstd, \
+                                 (const bf16_t*)dres, (bf16_t*)dx, dgamma, dbeta, rows, (int)d, (bf16_t*)dx_drop, drop, q8)
+            if (ex) { if (d <= 256) LP(1, true); else if (d <= 512) LP(2, true); else if (d <= 768) LP(3, true); else LP(4, true); }
+            else { if (d <= 256) LP(1, false); else if (d <= 512) LP(2, false); else if (d <= 768) LP(3, false); else LP(4, false); }
 #undef LP
             return check_launch("layernorm_bwd (pipelined)");
         }

@@ -1156,6 +1156,61 @@ def test_layernorm_passes_write_the_fp8_copy_their_consumer_needs(K, rows, d):
         assert float(sg.row[0]) == float(sg2.row[0]) > 0
 
 
+@pytest.mark.parametrize('variant', ['plain', 'drop', 'q8', 'drop+q8'])
+@pytest.mark.parametrize('d', [256, 512, 768, 1024, 264])
+def test_layernorm_backward_pipelined_over_rows_equals_the_plain_kernel(K, d, variant):
+    """bf16 launches of >= 8192 rows and <= 1024-wide rows run layernorm_bwd_pipe_kernel (next row's loads in flight under this row's arithmetic;
+    norm.hip): dx, dropout(dx) and the e5m2 copy are row-local, so the 9000-row launch must give, row for row, the bytes of two launches over its
+    halves (< 8192 rows: the plain kernel); dgamma / dbeta are sums over rows in another order; and dx against the f64 LayerNorm gradient."""
+    dt, rows, half = torch.bfloat16, 9000, 4500
+    sites = K.Fp8Sites(DEV, 8)
+    x = _rand((rows, d), dt, 60, 2.0).to(DEV)
+    g, b = (1 + 0.1 * _rand((d,), torch.float32, 61)).to(DEV), _rand((d,), torch.float32, 62).to(DEV)
+    y, mean, rstd = K.layernorm_fwd(x, g, b, 1e-5)[:3]
+    dy, dres = _rand((rows, d), dt, 63).to(DEV), _rand((rows, d), dt, 64).to(DEV)
+    drop = (0.1, 99) if 'drop' in variant else None
+    sg = None
+    if 'q8' in variant:
+        sg = sites.new(1)
+        sg.quantize(dres)                  # any tensor of the gradient's magnitude: the site gets a scale
+        sites.update()
+
+    def run(lo, hi):
+        dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+        kw = dict(dres=dres[lo:hi], drop=None if drop is None else (drop[0], drop[1]))
+        if sg is not None:
+            kw['q8_site'] = sg
+        out = K.layernorm_bwd(dy[lo:hi], x[lo:hi], g, mean[lo:hi], rstd[lo:hi], dg, db, **kw)
+        out = out if isinstance(out, tuple) else (out,)
+        return [o for o in out if o is not None], dg, db
+
+    whole, dg, db = run(0, rows)
+    (a, dga, dba), (c, dgc, dbc) = run(0, half), run(half, rows)
+    assert len(whole) == len(a) == 1 + ('drop' in variant) + ('q8' in variant)
+    # dx is row-local: against the plain kernel's rows (another instantiation: its f32 arithmetic may contract differently - one bf16 ulp)
+    plain = torch.cat([a[0], c[0]]).float()
+    diff = (whole[0].float() - plain).abs()
+    assert float((diff > 2.0 ** -7 * plain.abs().clamp_min(2.0 ** -6)).sum()) == 0
+    assert float((diff > 0).float().mean()) < 0.02
+    # the second outputs are functions of the dx this launch wrote: exactly what the stand-alone passes make of it
+    src = whole[0]
+    if 'drop' in variant:
+        assert torch.equal(whole[1], K.dropout(whole[0], drop[0], drop[1]))
+        src = whole[1]
+    if sg is not None:
+        g8 = whole[-1]
+        assert g8.dtype == torch.float8_e5m2 and torch.equal(g8.view(torch.uint8), sg.quantize(src).view(torch.uint8))
+    e, sc = _err(dg, (dga + dgc).cpu().double())
+    assert e <= 1e-4 * sc + 1e-5
+    e, sc = _err(db, (dba + dbc).cpu().double())
+    assert e <= 1e-4 * sc + 1e-5
+    xin = x.cpu().double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xin, (d,), g.cpu().double(), b.cpu().double(), 1e-5)
+    (ref * dy.cpu().double()).sum().backward()
+    e, sc = _err(whole[0], xin.grad + dres.cpu().double())
+    assert e <= _tol(dt) * sc
+
+
 @pytest.mark.parametrize('M,N,K_,case', [(256, 256, 128, 'plain'), (1154, 768, 1024, 'plain'), (2000, 3072, 768, 'act'),
                                          (1460, 1024, 4096, 'res'), (730 * 4, 4096, 1024, 'gelu'), (1154, 2304, 768, 'bias')])
 def test_gemm_fp8_forward_operands(K, M, N, K_, case):
