@@ -78,7 +78,7 @@ int leccr_debug_occupy(int blocks, int threads, int64_t microseconds, void* stre
  *   clip/model.py:175-191 (in_proj, out_proj, c_fc, c_proj), :211 (conv1 as a GEMM over patches), :342 (@ proj);
  *   HF BertModel dense layers called at models/xvlm.py:238; models/attention.py:28-31,47-52;
  *   models/xvlm.py:241-256 (vision_proj/text_proj); and their autograd backward (dX: trans_b=1, dW: trans_a=1,trans_b=1).
- * Epilogue order: v = alpha*acc (+bias[n]) ; if aux_out: aux_out[m,n] = v ; v = act(v) or v * act'(aux[m,n]) ;
+ * Epilogue order: v = alpha*acc (+bias[n]) ; if aux_out: aux_out[m,n] = v (act'(v) for the _D forms) ; v = act(v) or v * act'(aux[m,n]) or v * aux[m,n] ;
  *                 v += residual[m,n] ; C = v (or C += v).
  */
 #define LECCR_EPI_NONE 0
@@ -86,6 +86,12 @@ int leccr_debug_occupy(int blocks, int threads, int64_t microseconds, void* stre
 #define LECCR_EPI_GELU 2          /* 0.5 x (1 + erf(x / sqrt 2))             attention.py:16-17, HF BERT 'gelu' */
 #define LECCR_EPI_DQUICKGELU 3    /* v * d/du quickgelu(u), u = aux[m,n]     (backward through the activation) */
 #define LECCR_EPI_DGELU 4         /* v * d/du gelu(u)                                                          */
+/* The same two activations with the DERIVATIVE saved instead of the pre-activation (round 5): the forward epilogue has sigmoid / erf in
+ * registers, the derivative is four more plain operations there, and the backward epilogue becomes one multiply instead of an exp2 and a
+ * reciprocal per element after its K loop (dX of c_proj at config B: 870 -> ~690 us; the fp8 product of config E: 1418 -> ~1000 us). */
+#define LECCR_EPI_QUICKGELU_D 5   /* C = quickgelu(v), aux_out[m,n] = d/dv quickgelu(v)  (aux_out required)    */
+#define LECCR_EPI_GELU_D 6        /* C = gelu(v),      aux_out[m,n] = d/dv gelu(v)       (aux_out required)    */
+#define LECCR_EPI_MULAUX 7        /* v * aux[m,n]      (backward through an activation whose derivative was saved) */
 
 typedef struct leccr_gemm_params {
     const void* A;

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get('LECCR_LIB') or os.path.join(_HERE, 'libleccr_hip.so')
 
 F32, BF16, FP8, FP8_BF8A = 0, 1, 2, 3      # FP8 / FP8_BF8A: leccr_gemm operand codes only (e4m3 x e4m3 / A e5m2 x B e4m3)
 EPI_NONE, EPI_QUICKGELU, EPI_GELU, EPI_DQUICKGELU, EPI_DGELU = 0, 1, 2, 3, 4
+EPI_QUICKGELU_D, EPI_GELU_D, EPI_MULAUX = 5, 6, 7      # the activation's DERIVATIVE saved in aux_out / multiplied in by the backward epilogue
 
 vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
 

@@ -145,11 +145,27 @@ __device__ __forceinline__ float dgelu_erf(float x) {
 }
 
 template <int EPI> __device__ __forceinline__ float apply_epi(float v, float aux) {
-    if constexpr (EPI == LECCR_EPI_QUICKGELU) return quick_gelu(v);
-    else if constexpr (EPI == LECCR_EPI_GELU) return gelu_erf(v);
+    if constexpr (EPI == LECCR_EPI_QUICKGELU || EPI == LECCR_EPI_QUICKGELU_D) return quick_gelu(v);
+    else if constexpr (EPI == LECCR_EPI_GELU || EPI == LECCR_EPI_GELU_D) return gelu_erf(v);
     else if constexpr (EPI == LECCR_EPI_DQUICKGELU) return v * dquick_gelu(aux);
     else if constexpr (EPI == LECCR_EPI_DGELU) return v * dgelu_erf(aux);
+    else if constexpr (EPI == LECCR_EPI_MULAUX) return v * aux;
     else return v;
+}
+// epilogues that read aux / that save the derivative in aux_out
+template <int EPI> constexpr bool epi_needs_aux = EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU || EPI == LECCR_EPI_MULAUX;
+template <int EPI> constexpr bool epi_saves_deriv = EPI == LECCR_EPI_QUICKGELU_D || EPI == LECCR_EPI_GELU_D;
+// the _D forms: activation and its derivative from one sigmoid / one erf (the value saved for LECCR_EPI_MULAUX)
+struct ActD { float a, d; };
+template <int EPI> __device__ __forceinline__ ActD apply_epi_d(float v) {
+    if constexpr (EPI == LECCR_EPI_QUICKGELU_D) {
+        const float s = fast_sigmoid(1.702f * v);
+        return ActD{v * s, s * (1.f + 1.702f * v * (1.f - s))};
+    } else {
+        float e;
+        const float cdf = 0.5f * (1.f + erf_half(v, e));
+        return ActD{v * cdf, cdf + v * 0.3989422804014327f * e};
+    }
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -74,10 +74,16 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const TA* __restrict_
             if (n >= N) continue;
             float v = alpha * acc[i][j];
             if (bias) v += bias[n];
-            if (aux_out) aux_out[m * ldc + n] = from_f32<TC>(v);
-            float ax = 0.f;
-            if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) ax = to_f32(aux[m * ldaux + n]);
-            v = apply_epi<EPI>(v, ax);
+            if constexpr (epi_saves_deriv<EPI>) {
+                const ActD t_ = apply_epi_d<EPI>(v);
+                v = t_.a;
+                aux_out[m * ldc + n] = from_f32<TC>(t_.d);
+            } else {
+                if (aux_out) aux_out[m * ldc + n] = from_f32<TC>(v);
+                float ax = 0.f;
+                if constexpr (epi_needs_aux<EPI>) ax = to_f32(aux[m * ldaux + n]);
+                v = apply_epi<EPI>(v, ax);
+            }
             if (residual) v += to_f32(residual[m * ldr + n]);
             if (accumulate) v += to_f32(C[m * ldc + n]);
             C[m * ldc + n] = from_f32<TC>(v);
@@ -235,12 +241,19 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(const bf16_t* __restrict
                 for (int r = 0; r < 4; ++r) atomicAdd(c + r, v[r]);
             } else {
                 if (bias) v += load4(bias + n);
-                if (aux_out) store4(aux_out + m * ldc + n, v);
-                if constexpr (EPI != LECCR_EPI_NONE) {
-                    f32x4 ax = {0.f, 0.f, 0.f, 0.f};
-                    if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) ax = load4(aux + m * ldaux + n);
+                if constexpr (epi_saves_deriv<EPI>) {
+                    f32x4 dv;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = apply_epi<EPI>(v[r], ax[r]);
+                    for (int r = 0; r < 4; ++r) { const ActD t_ = apply_epi_d<EPI>(v[r]); v[r] = t_.a; dv[r] = t_.d; }
+                    store4(aux_out + m * ldc + n, dv);
+                } else {
+                    if (aux_out) store4(aux_out + m * ldc + n, v);
+                    if constexpr (EPI != LECCR_EPI_NONE) {
+                        f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+                        if constexpr (epi_needs_aux<EPI>) ax = load4(aux + m * ldaux + n);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_epi<EPI>(v[r], ax[r]);
+                    }
                 }
                 if (residual) v += load4(residual + m * ldr + n);
                 if (accumulate) v += load4(C + m * ldc + n);
@@ -268,6 +281,9 @@ static int launch_generic(const leccr_gemm_params& p, hipStream_t st) {
         case LECCR_EPI_GELU: LG(LECCR_EPI_GELU); break;
         case LECCR_EPI_DQUICKGELU: LG(LECCR_EPI_DQUICKGELU); break;
         case LECCR_EPI_DGELU: LG(LECCR_EPI_DGELU); break;
+        case LECCR_EPI_QUICKGELU_D: LG(LECCR_EPI_QUICKGELU_D); break;
+        case LECCR_EPI_GELU_D: LG(LECCR_EPI_GELU_D); break;
+        case LECCR_EPI_MULAUX: LG(LECCR_EPI_MULAUX); break;
         default: set_error("gemm: bad epilogue %d", p.epilogue); return LECCR_EINVAL;
     }
 #undef LG
@@ -315,6 +331,9 @@ static int launch_mfma(const leccr_gemm_params& p, hipStream_t st) {
             case LECCR_EPI_GELU: LM(LECCR_EPI_GELU, false); break;
             case LECCR_EPI_DQUICKGELU: LM(LECCR_EPI_DQUICKGELU, false); break;
             case LECCR_EPI_DGELU: LM(LECCR_EPI_DGELU, false); break;
+            case LECCR_EPI_QUICKGELU_D: LM(LECCR_EPI_QUICKGELU_D, false); break;
+            case LECCR_EPI_GELU_D: LM(LECCR_EPI_GELU_D, false); break;
+            case LECCR_EPI_MULAUX: LM(LECCR_EPI_MULAUX, false); break;
             default: set_error("gemm: bad epilogue %d", p.epilogue); return LECCR_EINVAL;
         }
     }
@@ -470,8 +489,10 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
                   "gemm: leading dimension smaller than the row length");
     LECCR_REQUIRE(!(p.aux && p.ldaux < p.N) && !(p.residual && p.ldr < p.N), LECCR_EINVAL,
                   "gemm: ldaux / ldr smaller than the row length");
-    if ((p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU))
+    if ((p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU || p.epilogue == LECCR_EPI_MULAUX))
         LECCR_REQUIRE(p.aux != nullptr, LECCR_EINVAL, "gemm: derivative epilogue needs aux");
+    if ((p.epilogue == LECCR_EPI_QUICKGELU_D || p.epilogue == LECCR_EPI_GELU_D))
+        LECCR_REQUIRE(p.aux_out != nullptr, LECCR_EINVAL, "gemm: the derivative-saving epilogues need aux_out");
     const bool fp8_ab = p.ab_dtype == LECCR_FP8 || p.ab_dtype == LECCR_FP8_BF8A;
     LECCR_REQUIRE(fp8_ab || (p.alpha_dev[0] == nullptr && p.alpha_dev[1] == nullptr), LECCR_EINVAL,
                   "gemm: alpha_dev (device-side operand scales) exists for fp8 operands only");

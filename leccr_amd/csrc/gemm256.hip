@@ -675,7 +675,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                 // The epilogue operand that is READ (the saved pre-activation of a d-activation epilogue, else the
                 // residual) is fetched for all 16 strips up front: loaded inside the strip loop each strip pays a full
                 // memory round trip (16 serial latencies per item - 30-40 % of a K = 768 item).
-                constexpr bool NEED_AUX = EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU;
+                constexpr bool NEED_AUX = epi_needs_aux<EPI>;
                 constexpr bool PRE_RES = (FLAGS & F_RES) != 0 && !NEED_AUX;
                 // The staging buffer holds one whole 16 x 64 strip (rows of 16 chunks of 16 bytes, chunk ^= row): every lane
                 // writes its 4 accumulators of the strip, then reads 8 columns of rows rrow and rrow + 8.  LDS operations of
@@ -734,14 +734,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                             f32x4 v0 = vbuf[mi & 1][2 * hp], v1 = vbuf[mi & 1][2 * hp + 1];
                             const int64_t m = mrow + mi * 16 + hp * 8;
                             const bool ok = !CHECK || (col_ok && m < a.M);
-                            if constexpr ((FLAGS & F_AUXOUT) != 0) {
+                            if constexpr (epi_saves_deriv<EPI>) {
+                                // the derivative goes where the pre-activation went: the backward epilogue (LECCR_EPI_MULAUX) only multiplies
+                                f32x4 d0, d1;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { { const ActD t_ = apply_epi_d<EPI>(v0[r]); v0[r] = t_.a; d0[r] = t_.d; } { const ActD t_ = apply_epi_d<EPI>(v1[r]); v1[r] = t_.a; d1[r] = t_.d; } }
+                                bf16x8 pv;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { pv[r] = (bf16_t)d0[r]; pv[4 + r] = (bf16_t)d1[r]; }
+                                if (ok) G256_STORE(reinterpret_cast<bf16x8*>(optr), pv);
+                                optr += step8;
+                            } else if constexpr ((FLAGS & F_AUXOUT) != 0) {
                                 bf16x8 pv;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { pv[r] = (bf16_t)v0[r]; pv[4 + r] = (bf16_t)v1[r]; }
                                 if (ok) G256_STORE(reinterpret_cast<bf16x8*>(optr), pv);
                                 optr += step8;
                             }
-                            if constexpr (EPI != LECCR_EPI_NONE) {
+                            if constexpr (EPI != LECCR_EPI_NONE && !epi_saves_deriv<EPI>) {
                                 f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
                                 if constexpr (NEED_AUX) {
                                     const bf16x8 xv = pre[(mi & 3) * 2 + hp];
@@ -824,12 +834,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm256_kernel(Args a) {
                     if (!interior && nb + ni * 16 >= a.N) continue;
                     f32x4 v = acc[ni][mi];
                     {
-                        if constexpr ((FLAGS & F_AUXOUT) != 0) store4(orow + ni * 16, v);
-                        if constexpr (EPI != LECCR_EPI_NONE) {
-                            f32x4 ax = {0.f, 0.f, 0.f, 0.f};
-                            if constexpr (EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU) ax = load4(xrow + ni * 16);
+                        if constexpr (epi_saves_deriv<EPI>) {
+                            f32x4 dv;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = apply_epi<EPI>(v[r], ax[r]);
+                            for (int r = 0; r < 4; ++r) { const ActD t_ = apply_epi_d<EPI>(v[r]); v[r] = t_.a; dv[r] = t_.d; }
+                            store4(orow + ni * 16, dv);
+                        } else {
+                            if constexpr ((FLAGS & F_AUXOUT) != 0) store4(orow + ni * 16, v);
+                            if constexpr (EPI != LECCR_EPI_NONE) {
+                                f32x4 ax = {0.f, 0.f, 0.f, 0.f};
+                                if constexpr (epi_needs_aux<EPI>) ax = load4(xrow + ni * 16);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = apply_epi<EPI>(v[r], ax[r]);
+                            }
                         }
                         if constexpr ((FLAGS & F_RES) != 0) v += load4(rrow + ni * 16);
                         if constexpr ((FLAGS & F_ACCUM) != 0) v += load4(crow + ni * 16);
@@ -948,9 +965,12 @@ static bool shape_compiled(const leccr_gemm_params& p) {
     switch (p.epilogue) {
         case LECCR_EPI_NONE: return f == 0 || f == F_RES;
         case LECCR_EPI_QUICKGELU:
-        case LECCR_EPI_GELU: return f == F_AUXOUT;
+        case LECCR_EPI_GELU:
+        case LECCR_EPI_QUICKGELU_D:
+        case LECCR_EPI_GELU_D: return f == F_AUXOUT;
         case LECCR_EPI_DQUICKGELU:
-        case LECCR_EPI_DGELU: return f == 0;
+        case LECCR_EPI_DGELU:
+        case LECCR_EPI_MULAUX: return f == 0;
     }
     return false;
 }
@@ -1066,6 +1086,9 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
             case LECCR_EPI_GELU: launch_inst<0, float, LECCR_EPI_GELU, F_AUXOUT>(a, grid, st); break;
             case LECCR_EPI_DQUICKGELU: launch_inst<0, float, LECCR_EPI_DQUICKGELU, 0>(a, grid, st); break;
             case LECCR_EPI_DGELU: launch_inst<0, float, LECCR_EPI_DGELU, 0>(a, grid, st); break;
+            case LECCR_EPI_QUICKGELU_D: launch_inst<0, float, LECCR_EPI_QUICKGELU_D, F_AUXOUT>(a, grid, st); break;
+            case LECCR_EPI_GELU_D: launch_inst<0, float, LECCR_EPI_GELU_D, F_AUXOUT>(a, grid, st); break;
+            case LECCR_EPI_MULAUX: launch_inst<0, float, LECCR_EPI_MULAUX, 0>(a, grid, st); break;
             default: set_error("gemm256: bad epilogue %d", p.epilogue); return LECCR_EINVAL;
         }
     } else {
@@ -1078,6 +1101,9 @@ int gemm256_launch(const leccr_gemm_params& p, hipStream_t st) {
             case LECCR_EPI_GELU: launch_inst<0, bf16_t, LECCR_EPI_GELU, F_AUXOUT>(a, grid, st); break;
             case LECCR_EPI_DQUICKGELU: launch_inst<0, bf16_t, LECCR_EPI_DQUICKGELU, 0>(a, grid, st); break;
             case LECCR_EPI_DGELU: launch_inst<0, bf16_t, LECCR_EPI_DGELU, 0>(a, grid, st); break;
+            case LECCR_EPI_QUICKGELU_D: launch_inst<0, bf16_t, LECCR_EPI_QUICKGELU_D, F_AUXOUT>(a, grid, st); break;
+            case LECCR_EPI_GELU_D: launch_inst<0, bf16_t, LECCR_EPI_GELU_D, F_AUXOUT>(a, grid, st); break;
+            case LECCR_EPI_MULAUX: launch_inst<0, bf16_t, LECCR_EPI_MULAUX, 0>(a, grid, st); break;
             default: set_error("gemm256: bad epilogue %d", p.epilogue); return LECCR_EINVAL;
         }
     }

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                 // pass AHEAD, so the latency sits under the previous pass's LDS transpose and stores instead of in front of every use
                 // (config E, the 4d-wide dX product: 2.53 ms per launch against 1.53 for the forward twin that only stores)
                 // (the residual of the plain epilogues likewise)
-                constexpr bool NEED_AUX = EPI == LECCR_EPI_DQUICKGELU || EPI == LECCR_EPI_DGELU;
+                constexpr bool NEED_AUX = epi_needs_aux<EPI>;
                 constexpr bool PRE = NEED_AUX || (FLAGS & F_RES) != 0;
                 [[maybe_unused]] bf16x8 xpre[2][4];
                 auto load_pre = [&](int pass, bf16x8* dst) {
@@ -473,13 +473,21 @@ __global__ __launch_bounds__(NTH) void gemm256w4_kernel(Args a) {
                             const int64_t m = m0 + wr * 128 + mi * 32 + hh * 16 + 4 * h8 + rq;
                             const bool ok = !CHECK || (col_ok && m < a.M);
                             const int64_t off = ok ? m * a.ldc + ncol : 0;
-                            if constexpr ((FLAGS & F_AUXOUT) != 0) {
+                            if constexpr (epi_saves_deriv<EPI>) {      // the derivative where the pre-activation went (LECCR_EPI_MULAUX reads it back)
+                                f32x4 d0, d1;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { { const ActD t_ = apply_epi_d<EPI>(v0[e]); v0[e] = t_.a; d0[e] = t_.d; } { const ActD t_ = apply_epi_d<EPI>(v1[e]); v1[e] = t_.a; d1[e] = t_.d; } }
+                                bf16x8 pv;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { pv[e] = (bf16_t)d0[e]; pv[4 + e] = (bf16_t)d1[e]; }
+                                if (ok) *reinterpret_cast<bf16x8*>(a.aux_out + off) = pv;
+                            } else if constexpr ((FLAGS & F_AUXOUT) != 0) {
                                 bf16x8 pv;
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) { pv[e] = (bf16_t)v0[e]; pv[4 + e] = (bf16_t)v1[e]; }
                                 if (ok) *reinterpret_cast<bf16x8*>(a.aux_out + off) = pv;
                             }
-                            if constexpr (EPI != LECCR_EPI_NONE) {
+                            if constexpr (EPI != LECCR_EPI_NONE && !epi_saves_deriv<EPI>) {
                                 f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
                                 if constexpr (NEED_AUX) {
                                     const bf16x8 xv = xpre[(2 * mi + hh) & 1][h8];
@@ -583,9 +591,10 @@ bool gemm256w4_fp8_legal(const leccr_gemm_params& p) {
     const int f = w4_flags(p);
     if (p.ab_dtype == LECCR_FP8)
         return (p.epilogue == LECCR_EPI_NONE && (f == 0 || f == g4::F_RES)) ||
-               ((p.epilogue == LECCR_EPI_QUICKGELU || p.epilogue == LECCR_EPI_GELU) && f == g4::F_AUXOUT);
+               ((p.epilogue == LECCR_EPI_QUICKGELU || p.epilogue == LECCR_EPI_GELU || p.epilogue == LECCR_EPI_QUICKGELU_D || p.epilogue == LECCR_EPI_GELU_D) &&
+                f == g4::F_AUXOUT);
     return (p.epilogue == LECCR_EPI_NONE && (f == 0 || f == g4::F_RES)) ||
-           ((p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU) && f == 0);
+           ((p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU || p.epilogue == LECCR_EPI_MULAUX) && f == 0);
 }
 
 // the fused fp8 copy of C: activation epilogues of a forward product (e4m3 copy) or derivative epilogues of a dX product (e5m2)
@@ -594,8 +603,11 @@ bool gemm256w4_c8_legal(const leccr_gemm_params& p) {
     if (!p.C && !p.c8) return false;                                              // C may be omitted only beside its fp8 copy
     if (!p.c8) return true;
     if (!p.c8_site || (p.ldc8 & 7) || ((uintptr_t)p.c8 & 7) || p.ldc8 < p.N) return false;
-    if (p.ab_dtype == LECCR_FP8) return (p.epilogue == LECCR_EPI_QUICKGELU || p.epilogue == LECCR_EPI_GELU) && p.c8_fmt == 0;
-    if (p.ab_dtype == LECCR_FP8_BF8A) return (p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU) && p.c8_fmt == 1;
+    if (p.ab_dtype == LECCR_FP8)
+        return (p.epilogue == LECCR_EPI_QUICKGELU || p.epilogue == LECCR_EPI_GELU || p.epilogue == LECCR_EPI_QUICKGELU_D || p.epilogue == LECCR_EPI_GELU_D) &&
+               p.c8_fmt == 0;
+    if (p.ab_dtype == LECCR_FP8_BF8A)
+        return (p.epilogue == LECCR_EPI_DQUICKGELU || p.epilogue == LECCR_EPI_DGELU || p.epilogue == LECCR_EPI_MULAUX) && p.c8_fmt == 1;
     return false;
 }
 
@@ -607,9 +619,12 @@ bool gemm256w4_legal(const leccr_gemm_params& p) {
     switch (p.epilogue) {
         case LECCR_EPI_NONE: return f == 0 || f == g4::F_RES;
         case LECCR_EPI_QUICKGELU:
-        case LECCR_EPI_GELU: return f == g4::F_AUXOUT;
+        case LECCR_EPI_GELU:
+        case LECCR_EPI_QUICKGELU_D:
+        case LECCR_EPI_GELU_D: return f == g4::F_AUXOUT;
         case LECCR_EPI_DQUICKGELU:
-        case LECCR_EPI_DGELU: return f == 0;
+        case LECCR_EPI_DGELU:
+        case LECCR_EPI_MULAUX: return f == 0;
     }
     return false;
 }
@@ -644,7 +659,10 @@ int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st) {
         a.c8 = (uint8_t*)p.c8; a.ldc8 = p.ldc8; a.c8_site = p.c8_site; a.colsum = p.colsum;
         if (p.c8) {     // the C written is also the next product's fp8 operand: activation output (e4m3) / its gradient (e5m2)
             if (p.ab_dtype == LECCR_FP8 && p.epilogue == LECCR_EPI_QUICKGELU) launch_fp8<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st, b1);
+            else if (p.ab_dtype == LECCR_FP8 && p.epilogue == LECCR_EPI_QUICKGELU_D) launch_fp8<LECCR_EPI_QUICKGELU_D, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st, b1);
+            else if (p.ab_dtype == LECCR_FP8 && p.epilogue == LECCR_EPI_GELU_D) launch_fp8<LECCR_EPI_GELU_D, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st, b1);
             else if (p.ab_dtype == LECCR_FP8) launch_fp8<LECCR_EPI_GELU, F_AUXOUT | F_FP8 | F_Q8>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_MULAUX) launch_fp8<LECCR_EPI_MULAUX, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st, b1);
             else if (p.epilogue == LECCR_EPI_DQUICKGELU) launch_fp8<LECCR_EPI_DQUICKGELU, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st, b1);
             else launch_fp8<LECCR_EPI_DGELU, F_FP8 | F_BF8A | F_Q8 | F_Q8_BF8>(a, grid, st, b1);
             return check_launch("gemm256w4 fp8 q8");
@@ -653,11 +671,14 @@ int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st) {
             if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_fp8<LECCR_EPI_NONE, F_RES | F_FP8>(a, grid, st, b1);
             else if (p.epilogue == LECCR_EPI_NONE) launch_fp8<LECCR_EPI_NONE, F_FP8>(a, grid, st, b1);
             else if (p.epilogue == LECCR_EPI_QUICKGELU) launch_fp8<LECCR_EPI_QUICKGELU, F_AUXOUT | F_FP8>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_QUICKGELU_D) launch_fp8<LECCR_EPI_QUICKGELU_D, F_AUXOUT | F_FP8>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_GELU_D) launch_fp8<LECCR_EPI_GELU_D, F_AUXOUT | F_FP8>(a, grid, st, b1);
             else launch_fp8<LECCR_EPI_GELU, F_AUXOUT | F_FP8>(a, grid, st, b1);
         } else {
             if (p.epilogue == LECCR_EPI_NONE && f == F_RES) launch_fp8<LECCR_EPI_NONE, F_RES | F_FP8 | F_BF8A>(a, grid, st, b1);
             else if (p.epilogue == LECCR_EPI_NONE) launch_fp8<LECCR_EPI_NONE, F_FP8 | F_BF8A>(a, grid, st, b1);
             else if (p.epilogue == LECCR_EPI_DQUICKGELU) launch_fp8<LECCR_EPI_DQUICKGELU, F_FP8 | F_BF8A>(a, grid, st, b1);
+            else if (p.epilogue == LECCR_EPI_MULAUX) launch_fp8<LECCR_EPI_MULAUX, F_FP8 | F_BF8A>(a, grid, st, b1);
             else launch_fp8<LECCR_EPI_DGELU, F_FP8 | F_BF8A>(a, grid, st, b1);
         }
         return check_launch("gemm256w4 fp8");
@@ -671,6 +692,9 @@ int gemm256w4_launch(const leccr_gemm_params& p, hipStream_t st) {
         case LECCR_EPI_GELU: launch_inst<LECCR_EPI_GELU, F_AUXOUT>(a, grid, st); break;
         case LECCR_EPI_DQUICKGELU: launch_inst<LECCR_EPI_DQUICKGELU, 0>(a, grid, st); break;
         case LECCR_EPI_DGELU: launch_inst<LECCR_EPI_DGELU, 0>(a, grid, st); break;
+        case LECCR_EPI_QUICKGELU_D: launch_inst<LECCR_EPI_QUICKGELU_D, F_AUXOUT>(a, grid, st); break;
+        case LECCR_EPI_GELU_D: launch_inst<LECCR_EPI_GELU_D, F_AUXOUT>(a, grid, st); break;
+        case LECCR_EPI_MULAUX: launch_inst<LECCR_EPI_MULAUX, 0>(a, grid, st); break;
         default: set_error("gemm256w4: bad epilogue %d", p.epilogue); return LECCR_EINVAL;
     }
     return check_launch("gemm256w4");

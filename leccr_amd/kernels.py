@@ -697,6 +697,13 @@ class Fp8Site:
         if not self.primed:
             check(lib().leccr_fp8_amax(ptr(x), rows, cols, x.stride(0), dtype_code(x), ptr(self.row), stream()), 'leccr_fp8_amax')
             check(lib().leccr_fp8_update(ptr(self.row), 1, stream()), 'leccr_fp8_update')
+            # A site can be shared by passes on DIFFERENT streams (the caption encoder IS the text encoder: its forward runs on the caption
+            # stream beside the text pass on the text stream).  `primed` is a host flag: the second pass would go on to read a scale that the
+            # first pass's update kernel, on another stream, may not have written yet - which scale it found decided the first step's
+            # quantisation and, through the gradient sites' first amax, now and then a power of two of a later scale (round 5: the fp8
+            # A/B test differed from run to run with the order of the tests before it).  Priming happens once per site, in the first
+            # step: the host waits for it, so every launch enqueued afterwards - on any stream - sees the scale.
+            torch.cuda.current_stream(x.device).synchronize()
             self.primed = True
         check(lib().leccr_fp8_quantize(ptr(x), ptr(y), rows, cols, x.stride(0), y.stride(0), dtype_code(x), self.fmt, ptr(self.row),
                                        stream()), 'leccr_fp8_quantize')

@@ -17,9 +17,25 @@ import os
 import torch
 
 from . import kernels as K
-from ._lib import EPI_DGELU, EPI_DQUICKGELU, EPI_GELU, EPI_NONE, EPI_QUICKGELU
+from ._lib import EPI_DGELU, EPI_DQUICKGELU, EPI_GELU, EPI_GELU_D, EPI_MULAUX, EPI_NONE, EPI_QUICKGELU, EPI_QUICKGELU_D
 
 _DACT = {EPI_QUICKGELU: EPI_DQUICKGELU, EPI_GELU: EPI_DGELU}
+# What an MLP's first Linear saves for the backward pass beside its activation: the activation's DERIVATIVE (default, round 5) or the
+# pre-activation (LECCR_ACT_DERIV=0).  The forward epilogue has sigmoid(1.702 x) / erf in registers - the derivative is four more plain
+# operations there - and the dX product's epilogue becomes one multiply instead of an exp2 and a reciprocal per element behind its K loop
+# (c_proj's dX at config B: 870 -> ~690 us per launch; the fp8 product of config E: 1418 -> ~1000 us).  Same bytes, nothing else reads them.
+act_deriv = os.environ.get('LECCR_ACT_DERIV', '1') != '0'
+_FWD_D = {EPI_QUICKGELU: EPI_QUICKGELU_D, EPI_GELU: EPI_GELU_D}
+
+
+def _epi_fwd(kw):
+    if act_deriv and kw.get('aux_out') is not None and kw.get('epilogue') in _FWD_D:
+        kw['epilogue'] = _FWD_D[kw['epilogue']]
+
+
+def _epi_bwd(kw):
+    if act_deriv and kw.get('epilogue') in (EPI_DQUICKGELU, EPI_DGELU):
+        kw['epilogue'] = EPI_MULAUX
 
 
 # --------------------------------------------------------------------------------------- dropout plumbing
@@ -251,6 +267,7 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
     x8: x2's fp8 copy when the producer already wrote it (c8_site).  c8_site: the activation site of the Linear that CONSUMES this
     output: once that site has a scale, the epilogue also writes the output's fp8 copy under it (no separate quantise pass over
     it).  want8: return (y, y8 or None) instead of y.  c8_only (fp8_only_ok): y itself is not written, (None, y8) comes back."""
+    _epi_fwd(kw)
     if fp8 == X3 and _is_x3(x8):              # f32 operands as bf16 hi / lo splits: x8 = X-form copy of x2, the weight split in G form
         w3 = _w_split(w, False)
         K.f32_split_launches += 1             # (counted like the products kernels.gemm splits by itself)
@@ -278,6 +295,7 @@ def lin_fwd(x2, w, b=None, fp8=False, x8=None, c8_site=None, want8=False, c8_onl
 def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False, c3_consumer=None, c3_bias=None, **kw):
     """dX = dY @ W.  bf16: NT against the K-contiguous [in,out] copy; f32: the generic kernel reads W as [K,N].
     fp8: dY in e5m2 under the Linear's gradient site against the e4m3 [in, out] weight copy."""
+    _epi_bwd(kw)
     if fp8 == X3 and _is_x3(g8):              # G-form copy of dY against the X-form split of W^T ([in, 3 out], K-contiguous)
         w3t = _w_split(w, True)
         K.f32_split_launches += 1

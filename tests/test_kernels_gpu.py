@@ -47,6 +47,46 @@ def test_gemm_nt(K, dtype, M, N, K_):
     assert e <= _tol(dtype) * s, (e, s)
 
 
+def _act_deriv(epi, u):
+    """f64 derivative of QuickGELU (1) / exact GELU (2) at u."""
+    ud = u.detach().clone().requires_grad_(True)
+    ACT[epi](ud).sum().backward()
+    return ud.grad
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('epi', [1, 2])
+@pytest.mark.parametrize('M,N,K_', [(260, 256, 128), (37, 20, 50), (2304, 3072, 192), (2049, 3080, 128)])
+def test_gemm_epilogues_that_save_the_activation_derivative(K, dtype, epi, M, N, K_):
+    """LECCR_EPI_QUICKGELU_D / GELU_D (5 / 6): C = act(v) and aux_out = act'(v) from one sigmoid / erf; LECCR_EPI_MULAUX (7): C = v * aux -
+    together the forward and backward of an MLP's first Linear with the derivative saved instead of the pre-activation.  Shapes for the
+    scalar kernel, the 128 x 128 MFMA kernel and the 8-wave 256 x 256 kernel (interior tiles and tails)."""
+    a, b = _rand((M, K_), dtype, 14), _rand((N, K_), dtype, 15, 0.1)
+    bias = _rand((N,), torch.float32, 16)
+    dsave = torch.empty(M, N, dtype=dtype, device=DEV)
+    out = K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), epilogue=epi + 4, aux_out=dsave)
+    u = a.double() @ b.double().t() + bias.double()
+    e, s = _err(out, ACT[epi](u))
+    assert e <= _tol(dtype) * s, (e, s)
+    d = _act_deriv(epi, u)
+    e, s = _err(dsave, d)
+    assert e <= _tol(dtype) * max(s, float(u.abs().max())), (e, s)      # |act''| <= ~1: the product's absolute error carries over
+    # the same values as the pre-activation-saving pair gives (epilogues 1 / 2 then 3 / 4) - within the storage rounding of what is saved
+    pre = torch.empty(M, N, dtype=dtype, device=DEV)
+    out0 = K.gemm(a.to(DEV), b.to(DEV), bias=bias.to(DEV), epilogue=epi, aux_out=pre)
+    assert torch.equal(out, out0)
+    dy, w = _rand((M, K_), dtype, 17), _rand((N, K_), dtype, 18, 0.1)
+    got = K.gemm(dy.to(DEV), w.to(DEV), epilogue=7, aux=dsave)
+    ref = (dy.double() @ w.double().t()) * dsave.double().cpu()
+    e, s = _err(got, ref)
+    assert e <= _tol(dtype) * s, (e, s)
+    old = K.gemm(dy.to(DEV), w.to(DEV), epilogue=epi + 2, aux=pre)
+    e, s = _err(got, old.double().cpu())
+    assert e <= 3 * _tol(dtype) * s, (e, s)
+    with pytest.raises(Exception):
+        K.gemm(a.to(DEV), b.to(DEV), epilogue=epi + 4)            # nowhere to save the derivative
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('epi', [1, 2])
 def test_gemm_epilogues(K, dtype, epi):
@@ -1240,6 +1280,12 @@ def test_gemm_fp8_forward_operands(K, M, N, K_, case):
     if pre is not None:
         e, s = _err(pre, u)
         assert e <= 1.2e-2 * s
+        # the derivative-saving form of the same epilogue (LECCR_EPI_QUICKGELU_D / GELU_D): same C, act'(v) where the pre-activation went
+        dsave = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        out_d = K.gemm(a8, b8, bias=bias, alpha_dev=(sa.inv_scale, sb.inv_scale), epilogue=epi + 4, aux_out=dsave)
+        assert _lib.lib().leccr_last_gemm_kernel() == 4 and torch.equal(out_d, out)
+        e, s = _err(dsave, _act_deriv(epi, u))
+        assert e <= 1.2e-2 * max(s, 1.0)
     # and the quantisation itself is a small perturbation of the bf16 product (e4m3: 3 mantissa bits, K-fold averaging)
     full = a.double().cpu() @ b.double().cpu().t() + bias.double().cpu()
     assert float((u - full).norm() / full.norm()) < 0.06
@@ -1275,6 +1321,12 @@ def test_gemm_fp8_gradient_operands(K, M, N, K_, case):
     assert _lib.lib().leccr_last_gemm_kernel() == 4
     e, s = _err(out, ref)
     assert e <= 1.2e-2 * s, (case, e, s)
+    if case in ('dact', 'dgelu'):       # LECCR_EPI_MULAUX: the saved derivative multiplied in
+        dsv = d.to(torch.bfloat16)
+        out_m = K.gemm(a8, b8, alpha_dev=(sa.inv_scale, sb.inv_scale), epilogue=7, aux=dsv.to(DEV))
+        assert _lib.lib().leccr_last_gemm_kernel() == 4
+        e, s = _err(out_m, u * dsv.double())
+        assert e <= 1.2e-2 * s, (case, e, s)
 
 
 def test_fp8_batched_weight_requantisation_matches_the_per_tensor_passes(K):
