@@ -177,7 +177,7 @@ int leccr_split_n(const float* src, void* dst, int64_t rows, int64_t cols, int64
                   void* stream);
 /* The two split copies every weight of the fp32 path needs - [out, 3 in] in form 1 for the forward product (clip/model.py:175-191, HF BERT dense layers:
  * y = x W^T) and [in, 3 out] in form 0 of W^T for the dX product - for ALL weights in one launch, once per optimizer step (the counterpart of
- * leccr_transpose_cast_batched on the bf16 path).  table: n rows of 6 int64 on the device = {first 32 x 32 tile of this matrix in the launch, src
+ * leccr_transpose_cast_batched on the bf16 path).  table: n rows of 6 int64 on the device = {first 64 x 64 tile of this matrix in the launch, src
  * pointer (f32 [R, C] contiguous), dstG pointer (bf16 [R, 3 C]), dstT pointer (bf16 [C, 3 R]), R, C}, ordered by first tile; total_tiles = the grid. */
 int leccr_split3_weights_batched(const int64_t* table, int64_t n, int64_t total_tiles, void* stream);
 
@@ -405,8 +405,8 @@ int leccr_adamw(float* p, const float* g, float* m, float* v, int64_t n, const i
                 float gscale, void* lp_bf16, void* stream);
 int leccr_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int leccr_transpose_cast(const float* src, void* dst, int64_t R, int64_t C, int dtype, void* stream);
-/* Many transposes in one launch.  table: n rows of 5 int64 {first tile index (cumulative, 32x32 tiles, row-major over
- * ceil(R/32) x ceil(C/32)), src pointer (f32 [R,C]), dst pointer (bf16 [C,R]), R, C}, in device memory. */
+/* Many transposes in one launch.  table: n rows of 5 int64 {first tile index (cumulative, 64x64 tiles, row-major over
+ * ceil(R/64) x ceil(C/64)), src pointer (f32 [R,C]), dst pointer (bf16 [C,R]), R, C}, in device memory. */
 int leccr_transpose_cast_batched(const int64_t* table, int64_t n, int64_t total_tiles, void* stream);
 int leccr_axpy(const void* x, void* y, float a, int64_t n, int dtype, void* stream);   /* y += a*x */
 /* Elementwise dropout y[i] = keep(seed, i) ? x[i] / (1-p) : 0 (nn.Dropout at attention.py:29-37,92-100; HF

@@ -140,7 +140,7 @@ class ParamArena:
                 R, Cn = h.data.shape
                 assert h.data.is_contiguous()
                 rows.append([tiles, h.data.data_ptr(), h._s3g.data_ptr(), h._s3t.data_ptr(), R, Cn])
-                tiles += ((R + 31) // 32) * ((Cn + 31) // 32)
+                tiles += ((R + 63) // 64) * ((Cn + 63) // 64)
             hit = (torch.tensor(rows, dtype=torch.int64, device=self.data.device) if rows else None, tiles)
             self._tt_cache[key] = hit
         return hit
@@ -158,7 +158,7 @@ class ParamArena:
                 R, Cn = h.data.shape
                 assert h.data.is_contiguous() and h.data.dtype == torch.float32
                 rows.append([tiles, h.data.data_ptr(), h._lpt.data_ptr(), R, Cn])
-                tiles += ((R + 31) // 32) * ((Cn + 31) // 32)
+                tiles += ((R + 63) // 64) * ((Cn + 63) // 64)
             hit = (torch.tensor(rows, dtype=torch.int64, device=self.data.device) if rows else None, tiles)
             self._tt_cache[key] = hit
         return hit

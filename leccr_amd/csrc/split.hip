@@ -190,9 +190,12 @@ using namespace leccr;
 
 // Every weight's two split copies in ONE launch (round 5): table[i] = {first tile, src (f32 [R, C], contiguous), dstG (bf16 [R, 3 C], form 1: the
 // [out, in] weight of the forward product), dstT (bf16 [C, 3 R], form 0 of src^T: the K-contiguous [in, out] copy of the dX product), R, C};
-// a block = one 32 x 32 tile.  The fp32 step used to split each weight at every use - 230 launches of 40 - 90 us for 6 - 28 MB of traffic each.
+// a block = one 64 x 64 tile.  The fp32 step used to split each weight at every use - 230 launches of 40 - 90 us for 6 - 28 MB of traffic each.
+// The tile moves as in split3_t_kernel (the first batched version went back to 32 x 32 tiles and 2-byte pieces): float4 source rows; the G copy
+// straight from those registers (8-byte stores, 16 lanes = 128 bytes of a segment row); the transposed copy from the LDS tile, thread
+// (c = tid >> 2, q = tid & 3) = 16 consecutive r of destination row c, two bf16x8 per segment (four adjacent lanes = one 128-byte line).
 __global__ __launch_bounds__(256) void split3_weights_kernel(const int64_t* __restrict__ table, int n) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     int lo = 0, hi = n - 1;                                  // last matrix whose first tile <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -202,27 +205,69 @@ __global__ __launch_bounds__(256) void split3_weights_kernel(const int64_t* __re
     const float* src = reinterpret_cast<const float*>(e[1]);
     bf16_t* dg = reinterpret_cast<bf16_t*>(e[2]);
     bf16_t* dt = reinterpret_cast<bf16_t*>(e[3]);
-    const int R = (int)e[4], C = (int)e[5];
-    const int t = (int)(blockIdx.x - e[0]), tiles_x = (C + 31) >> 5;
-    const int r0 = (t / tiles_x) * 32, c0 = (t % tiles_x) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    for (int k = ty; k < 32; k += 8) {
-        if (r0 + k < R && c0 + tx < C) {
-            const float x = src[(int64_t)(r0 + k) * C + c0 + tx];
-            tile[k][tx] = x;
-            bf16_t h, l;
-            split2(x, h, l);
-            bf16_t* d = dg + (int64_t)(r0 + k) * 3 * C + c0 + tx;            // form 1: hi | lo | hi
-            d[0] = h; d[C] = l; d[2 * (int64_t)C] = h;
+    const int64_t R = e[4], C = e[5];
+    const int t = (int)(blockIdx.x - e[0]), tiles_x = (int)((C + 63) >> 6);
+    const int64_t r0 = (int64_t)(t / tiles_x) * 64, c0 = (int64_t)(t % tiles_x) * 64;
+    const int tid = threadIdx.x;
+    const bool full = r0 + 64 <= R && c0 + 64 <= C && (C & 3) == 0 && (R & 7) == 0 &&
+                      ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dg) | reinterpret_cast<uintptr_t>(dt)) & 15) == 0;
+    if (full) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 4) + 16 * i, c4 = (tid & 15) * 4;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (r0 + r) * C + c0 + c4);
+            bf16x4 h, l;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tile[r][c4 + k] = v[k];
+                bf16_t hh, ll;
+                split2(v[k], hh, ll);
+                h[k] = hh; l[k] = ll;
+            }
+            bf16_t* d = dg + (r0 + r) * 3 * C + c0 + c4;                    // form 1: hi | lo | hi
+            *reinterpret_cast<bf16x4*>(d) = h;
+            *reinterpret_cast<bf16x4*>(d + C) = l;
+            *reinterpret_cast<bf16x4*>(d + 2 * C) = h;
+        }
+    } else {
+        for (int k = tid; k < 64 * 64; k += 256) {
+            const int r = k >> 6, c = k & 63;
+            const bool in = r0 + r < R && c0 + c < C;
+            const float x = in ? src[(r0 + r) * C + c0 + c] : 0.f;
+            tile[r][c] = x;
+            if (in) {
+                bf16_t h, l;
+                split2(x, h, l);
+                bf16_t* d = dg + (r0 + r) * 3 * C + c0 + c;
+                d[0] = h; d[C] = l; d[2 * C] = h;
+            }
         }
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        if (c0 + k < C && r0 + tx < R) {
+    const int c = tid >> 2, q = tid & 3;                     // destination row c0 + c, source rows r0 + 16 q .. + 15
+    if (full) {
+        bf16_t* d = dt + (c0 + c) * 3 * R + r0 + 16 * q;                    // form 0 of the transpose: hi | hi | lo
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            bf16x8 h, l;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bf16_t hh, ll;
+                split2(tile[16 * q + 8 * k + j][c], hh, ll);
+                h[j] = hh; l[j] = ll;
+            }
+            *reinterpret_cast<bf16x8*>(d + 8 * k) = h;
+            *reinterpret_cast<bf16x8*>(d + R + 8 * k) = h;
+            *reinterpret_cast<bf16x8*>(d + 2 * R + 8 * k) = l;
+        }
+    } else if (c0 + c < C) {
+        for (int j = 0; j < 16; ++j) {
+            const int64_t r = r0 + 16 * q + j;
+            if (r >= R) break;
             bf16_t h, l;
-            split2(tile[tx][k], h, l);
-            bf16_t* d = dt + (int64_t)(c0 + k) * 3 * R + r0 + tx;            // form 0 of the transpose: hi | hi | lo
-            d[0] = h; d[R] = h; d[2 * (int64_t)R] = l;
+            split2(tile[16 * q + j][c], h, l);
+            bf16_t* d = dt + (c0 + c) * 3 * R + r;
+            d[0] = h; d[R] = h; d[2 * R] = l;
         }
     }
 }
@@ -230,7 +275,7 @@ __global__ __launch_bounds__(256) void split3_weights_kernel(const int64_t* __re
 extern "C" int leccr_split3_weights_batched(const int64_t* table, int64_t n, int64_t total_tiles, void* stream) {
     LECCR_REQUIRE(table && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31), LECCR_EINVAL, "split3_weights_batched: bad argument");
     hipStream_t st = as_stream(stream);
-    ProfScope prof(PROF_SPLIT, 16.0 * 1024.0 * (double)total_tiles, st);
+    ProfScope prof(PROF_SPLIT, 16.0 * 4096.0 * (double)total_tiles, st);
     hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, table, (int)n);
     return check_launch("split3_weights_batched");
 }

@@ -602,12 +602,12 @@ def test_rank_of_gt_and_optimizer(K):
     assert torch.equal(pd2[:400].cpu(), p2[:400]) and not torch.equal(pd2[400:].cpu(), p2[400:])     # first segment untouched
     assert torch.equal(lp, pd2.to(torch.bfloat16))                                                     # copy covers both
     # all [in,out] copies in one launch == one transpose_cast per matrix
-    mats = [_rand(shape, torch.float32, 86 + i).to(DEV) for i, shape in enumerate([(70, 130), (32, 32), (5, 257), (96, 64)])]
+    mats = [_rand(shape, torch.float32, 86 + i).to(DEV) for i, shape in enumerate([(70, 130), (32, 32), (5, 257), (96, 64), (768, 2304), (128, 192), (64, 72)])]   # edge tiles, whole 64 x 64 tiles, R % 8 != 0
     outs = [torch.empty(m_.shape[1], m_.shape[0], dtype=torch.bfloat16, device=DEV) for m_ in mats]
     rows, tiles = [], 0
     for m_, o_ in zip(mats, outs):
         rows.append([tiles, m_.data_ptr(), o_.data_ptr(), m_.shape[0], m_.shape[1]])
-        tiles += ((m_.shape[0] + 31) // 32) * ((m_.shape[1] + 31) // 32)
+        tiles += ((m_.shape[0] + 63) // 64) * ((m_.shape[1] + 63) // 64)
     K.transpose_cast_batched(torch.tensor(rows, dtype=torch.int64, device=DEV), tiles)
     for m_, o_ in zip(mats, outs):
         assert torch.equal(o_, m_.t().contiguous().to(torch.bfloat16))
@@ -1087,7 +1087,7 @@ def test_split3_weights_batched_equals_the_per_tensor_passes(K):
         t = torch.full((C, 3 * R), float('nan'), dtype=torch.bfloat16, device=DEV)
         outs.append((g, t))
         rows.append([tiles, w.data_ptr(), g.data_ptr(), t.data_ptr(), R, C])
-        tiles += ((R + 31) // 32) * ((C + 31) // 32)
+        tiles += ((R + 63) // 64) * ((C + 63) // 64)
     table = torch.tensor(rows, dtype=torch.int64, device=DEV)
     K.split3_weights_batched(table, tiles)
     for w, (g, t) in zip(ws, outs):
