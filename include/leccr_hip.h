@@ -149,7 +149,12 @@ typedef struct leccr_gemm_params {
                                     may be NULL when the 256x256 kernel takes the shape (M, N >= 256, >= 192 tiles, N % 8 == 0): a consumer
                                     chain that reads only the copy (the 4d-wide MLP activation and its gradient) */
     int32_t c3_form;
-    int32_t reserved3;
+    int32_t asum_x3;             /* 1 (with asum; bf16 operands, trans_a = 1, K % 3 == 0): A is the 3-segment G-form split copy [rows, 3 M] (hi | lo | hi,
+                                    leccr_split3) of an f32 dY read as [3 rows, M] - the fp32 path's weight-gradient product - and asum adds its hi and lo
+                                    segments ONCE each (reduction indices k with k mod 3 = 0, 1): asum[m] += alpha * sum_r (hi + lo)(r, m) = the bias
+                                    gradient colsum(dY) to the split's 2^-17, inside the weight-gradient launch (the 4-wave TN kernel weights the
+                                    fragment pairs of its column sums by k mod 3; other kernels: two leccr_colsum passes over the copy's first two
+                                    column blocks).  Was `reserved3` (0 = the plain sum). */
 } leccr_gemm_params;
 
 int leccr_gemm(const leccr_gemm_params* p, void* stream);

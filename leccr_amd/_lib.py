@@ -23,7 +23,7 @@ class GemmParams(C.Structure):
                 ('ldc', i64), ('ab_dtype', i32), ('c_dtype', i32), ('trans_a', i32), ('trans_b', i32), ('bias', vp),
                 ('epilogue', i32), ('accumulate', i32), ('aux', vp), ('ldaux', i64), ('aux_out', vp),
                 ('residual', vp), ('ldr', i64), ('alpha', f32), ('reserved', i32), ('colsum', vp), ('asum', vp), ('alpha_dev', vp * 2), ('c8', vp), ('ldc8', i64), ('c8_site', vp), ('c8_fmt', i32),
-                ('reserved2', i32), ('c3', vp), ('c3_form', i32), ('reserved3', i32)]
+                ('reserved2', i32), ('c3', vp), ('c3_form', i32), ('asum_x3', i32)]
 
 
 _SIGS = {

@@ -526,12 +526,23 @@ extern "C" int leccr_gemm(const leccr_gemm_params* pp, void* stream) {
     hipStream_t st = as_stream(stream);
     LECCR_REQUIRE(!(p.colsum && p.accumulate), LECCR_EINVAL, "gemm: colsum with accumulate is not defined");
     LECCR_REQUIRE(!(p.asum && !p.trans_a), LECCR_EINVAL, "gemm: asum is defined for trans_a = 1 only");
+    LECCR_REQUIRE(!p.asum_x3 || (p.asum && p.ab_dtype == LECCR_BF16 && p.K % 3 == 0), LECCR_EINVAL,
+                  "gemm: asum_x3 needs asum, bf16 operands (a 3-segment split copy read as [3 rows, M]) and K a multiple of 3");
     bool colsum_fused = false;
     int rc = gemm_dispatch(p, st, &colsum_fused);
     if (rc == LECCR_OK && p.c3 && g_last_kernel != 2)      // kernels without the split epilogue: leccr_split3 over the C just written
         rc = leccr_split3((const float*)p.C, p.c3, p.M, p.N, p.ldc, p.c3_form, 0, nullptr, stream);
     if (rc == LECCR_OK && p.colsum && !colsum_fused)     // paths without the fused epilogue: one pass over the C just written
         rc = leccr_colsum(p.C, p.colsum, p.M, p.N, p.ldc, p.c_dtype, stream);
+    if (rc == LECCR_OK && p.asum && p.asum_x3 && g_last_kernel != 5) {
+        // asum over the hi and lo segments of a 3-segment split copy (leccr_gemm_params.asum_x3) outside the 4-wave TN kernel: A [3 rows, M] read as
+        // [rows, 3 M] - two passes over its first two column blocks
+        if (p.alpha != 1.0f) { set_error("gemm: asum_x3 with alpha != 1 needs the 4-wave TN kernel"); return LECCR_EINVAL; }
+        const char* a0 = (const char*)p.A;
+        rc = leccr_colsum(a0, p.asum, p.K / 3, p.M, 3 * p.lda, p.ab_dtype, stream);
+        if (rc == LECCR_OK) rc = leccr_colsum(a0 + 2 * p.lda, p.asum, p.K / 3, p.M, 3 * p.lda, p.ab_dtype, stream);
+        return rc;
+    }
     if (rc == LECCR_OK && p.asum && !(g_last_kernel == 5 || (g_last_kernel == 2 && gemm256_fuses_asum(p)))) {
         // kernels without the fused sum: one pass over A ([K, M] row-major), scaled like the product
         if (p.alpha == 1.0f) rc = leccr_colsum(p.A, p.asum, p.K, p.M, p.lda, p.ab_dtype, stream);

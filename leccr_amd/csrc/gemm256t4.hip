@@ -37,6 +37,7 @@ constexpr int OPT = 32768;                        // bytes of one operand K-tile
 constexpr int SLOT = 2 * OPT, NTH = 256;
 constexpr int LDS_BYTES = 2 * SLOT;               // 131072: no epilogue staging
 constexpr int F_ASUM = 1;
+constexpr int F_ASUM3 = 2;       // with F_ASUM: A is a 3-segment split copy read as [3 rows, M] (below): asum counts its hi and lo segments once each
 #ifndef T4_BURST
 #define T4_BURST 0            // (experiment) bit ks: k-step ks of the bf16 kernel issues its fragment reads and DMA pieces in one burst ahead of its 16 MFMAs
 #endif
@@ -74,6 +75,21 @@ __device__ __forceinline__ float colsum8(const bf16x8& f, float acc) {
     return acc;
 }
 
+// F_ASUM3 - the fp32 path's weight-gradient product (split.hip): A is the G-form copy [rows, 3 M] (hi | lo | hi) of an f32 dY read as [3 rows, M], so
+// reduction index k = 3 r + s carries segment s of row r and the bias gradient colsum(dY) is the sum over k of the hi and lo segments ONCE each
+// (s = 0, 1; the plain sum would count hi twice).  A fragment holds k = kbase + 0..7 of its column (element j = row j of the transposing reads:
+// cdna_hip_programming.md T10), taken in as four pairs (k, k + 1) with k even; a pair's weights depend on k mod 3 only:
+//   k mod 3 = 0: segments (0, 1) -> (1, 1)     1: segments (1, 2) -> (1, 0)     2: segments (2, 0) -> (0, 1)
+// `ph` = kbase mod 3; pair w starts at k = kbase + 2 w: phases ph, ph + 2, ph + 1, ph.
+__device__ __forceinline__ uint32_t asum3_weight(int ph) { return ph == 0 ? 0x3F803F80u : ph == 1 ? 0x00003F80u : 0x3F800000u; }   // bf16 pairs, element 0 in the low half
+__device__ __forceinline__ float colsum8_x3(const bf16x8& f, uint32_t w0, uint32_t w1, uint32_t w2, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{f[0], f[1]}, __builtin_bit_cast(bf16x2_t, w0), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{f[2], f[3]}, __builtin_bit_cast(bf16x2_t, w2), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{f[4], f[5]}, __builtin_bit_cast(bf16x2_t, w1), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{f[6], f[7]}, __builtin_bit_cast(bf16x2_t, w0), acc, false);
+    return acc;
+}
+
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -91,6 +107,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 struct Cursor {                // position of one K-tile of this block's stream (wave-uniform)
     int j, kt, nkt;            // item ordinal, K-tile within the item, K-tiles of the item (the last split may be shorter)
+    int kph;                   // (first K-tile of the item) mod 3: with 64 = 1 (mod 3), K-tile kt0 + kt starts at k = kt0 + kt (mod 3)  (F_ASUM3)
     int64_t m0, n0;
     const bf16_t* pa;          // A + k0 * lda + m0
     const bf16_t* pb;          // B + k0 * ldb + n0
@@ -105,6 +122,7 @@ __device__ __forceinline__ void decode(const Args& a, int first_item, int stride
     c.m0 = (int64_t)tm * BM;
     c.n0 = (int64_t)(tile - tm * a.tiles_n) * BN;
     const int kt0 = split * a.nkt, left = a.ktiles - kt0;
+    c.kph = kt0 % 3;
     c.nkt = left < a.nkt ? left : a.nkt;
     const int64_t k0 = (int64_t)(kt0 + c.kt) * BK;
     c.pa = a.A + k0 * a.lda + c.m0;
@@ -250,6 +268,7 @@ __global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
             for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
         if constexpr ((FLAGS & F_ASUM) != 0) { cs[0] = 0.f; cs[1] = 0.f; }
         [[maybe_unused]] int cs_ctr = (int)(cur.n0 >> 8);      // K-tiles until this item's next turn (BN = 256)
+        [[maybe_unused]] int kph = cur.kph;                    // (this K-tile's first k) mod 3  (F_ASUM3)
 
         for (int kt = 0; kt < cur.nkt; ++kt, ++t) {
             const uint32_t sc = (t & 1) * SLOT, sn = SLOT - sc;
@@ -275,7 +294,20 @@ __global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
                     if constexpr (!BURST) fill(ic);
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                if constexpr ((FLAGS & F_ASUM) != 0) {
+                if constexpr ((FLAGS & F_ASUM3) != 0) {
+                    if (do_cs) {           // this lane's fragment starts at k = 64 (kt0 + kt) + 16 KS + 8 h: kph + KS + 2 h (mod 3)
+                        int ph = kph + KS + ((lane >> 5) << 1);
+                        ph = ph >= 6 ? ph - 6 : ph >= 3 ? ph - 3 : ph;
+                        const int ph1 = ph == 2 ? 0 : ph + 1, ph2 = ph1 == 2 ? 0 : ph1 + 1;
+                        const uint32_t w0 = asum3_weight(ph), w1 = asum3_weight(ph1), w2 = asum3_weight(ph2);
+                        // (a fragment's four dot2 start from 0 and join the running sum by one v_add_f32: the dot2 accumulate does not round to
+                        //  nearest, and carried through a 36928-row column of one sign its error reached 5e-6 of the sum - the fp32 path's bias
+                        //  gradients are held to the split's 2^-17 per term, not to a drift)
+                        if (wc == 0) { cs[0] += colsum8_x3(fa[cb][0], w0, w1, w2, 0.f); cs[1] += colsum8_x3(fa[cb][1], w0, w1, w2, 0.f); }
+                        else { cs[0] += colsum8_x3(fa[cb][2], w0, w1, w2, 0.f); cs[1] += colsum8_x3(fa[cb][3], w0, w1, w2, 0.f); }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else if constexpr ((FLAGS & F_ASUM) != 0) {
                     if (do_cs) {           // (the fragments just used: their registers are rewritten only by the NEXT k-step's fill)
                         if (wc == 0) { cs[0] = colsum8(fa[cb][0], cs[0]); cs[1] = colsum8(fa[cb][1], cs[1]); }
                         else { cs[0] = colsum8(fa[cb][2], cs[0]); cs[1] = colsum8(fa[cb][3], cs[1]); }
@@ -309,6 +341,7 @@ __global__ __launch_bounds__(NTH) void gemm256t4_kernel(Args a) {
             // k-step 3 reads k-step 0 of K-tile t+1 and starts K-tile t+2 into the slot just freed
             kstep(std::integral_constant<int, 3>{}, FILL(3, 0, sn, 0, sc));
             WAIT_FRAGS(0);
+            if constexpr ((FLAGS & F_ASUM3) != 0) kph = kph == 2 ? 0 : kph + 1;
         }
 
         // ---- epilogue of this item: f32 atomics straight from the accumulators.  Register i of acc[mi * 4 + ni], lane (r, h):
@@ -730,7 +763,8 @@ int gemm256t4_launch(const leccr_gemm_params& p, int cap, hipStream_t st) {
     a.ktiles = (int)ktiles;
     a.n_items = tiles * splits;
     const int grid = a.n_items < cap ? a.n_items : cap;
-    if (a.asum) launch_inst<F_ASUM>(a, grid, st);
+    if (a.asum && p.asum_x3) launch_inst<F_ASUM | F_ASUM3>(a, grid, st);
+    else if (a.asum) launch_inst<F_ASUM>(a, grid, st);
     else launch_inst<0>(a, grid, st);
     return check_launch("gemm256t4");
 }

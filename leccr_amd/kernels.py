@@ -66,6 +66,13 @@ def gemm256_takes(M, N, Kd):
     return M >= 256 and N >= 256 and N % 8 == 0 and Kd >= 128 and Kd % 64 == 0 and -(-M // 256) * -(-N // 256) >= 192
 
 
+def tn4_takes(M, N, Kd):
+    """Shapes of a bf16 weight-gradient product (C [M, N] f32 += A[Kd, M]^T B[Kd, N]) the 4-wave TN kernel takes (gemm256t4_legal in gemm256t4.hip,
+    contiguous operands): the launches whose column sums (asum / asum_x3) ride inside the product."""
+    return (M >= 256 and N >= 256 and M % 256 == 0 and N % 256 == 0 and Kd % 64 == 0 and Kd >= 4096 and max(M, N) < (1 << 22)
+            and os.environ.get('LECCR_GEMM_TN4', '1')[:1] != '0')
+
+
 def split3_colsum_ok(x):
     """Shapes whose split pass can carry the column sums (leccr_split3's colsum)."""
     return NS == 6 or (x.shape[1] % 8 == 0 and x.shape[1] <= 8192 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
@@ -91,7 +98,7 @@ def _split_plan(a, b, trans_a, trans_b, out, accumulate, asum):
 
 def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, aux=None, aux_out=None, residual=None,
          out=None, out_dtype=None, accumulate=False, alpha=1.0, colsum=None, asum=None, alpha_dev=None, c8=None, write_c=True,
-         a3=None, b3=None, c3_form=None):
+         a3=None, b3=None, c3_form=None, asum_x3=False):
     """C = epilogue(alpha * A' B'^T).  a: [M,K] (or [K,M] if trans_a); b: [N,K] (or [K,N] if trans_b); 2-D, row-major.
     write_c=False (fp8 operands with c8 only): the bf16 C is not written - only its fp8 copy c8 (and aux_out / colsum); returns None.
     f32 operands: see f32_mfma above.  a3 / b3 = (split copy, form): the caller already holds leccr_split3 copies of a / b (as they
@@ -169,6 +176,9 @@ def gemm(a, b, *, trans_a=False, trans_b=False, bias=None, epilogue=EPI_NONE, au
     if asum is not None:        # [M] f32 += alpha * column sums of the stored [K, M] A over K (the bias gradient beside a dW product)
         assert trans_a and asum.dtype == torch.float32 and asum.numel() == M and asum.is_contiguous()
     p.asum = ptr(asum)
+    if asum_x3:                 # a = the G-form split copy of an f32 dY read as [3 rows, M]: asum takes its hi and lo segments once each (leccr_hip.h)
+        assert asum is not None and a.dtype == torch.bfloat16 and trans_a and K % 3 == 0 and NS == 3
+        p.asum_x3 = 1
     if c8 is not None:          # (fp8 tensor [M, N], Fp8Site): the fused fp8 copy of C for the product that consumes it
         t8, site8 = c8
         assert t8.shape == (M, N) and t8.stride(1) == 1 and t8.element_size() == 1

@@ -171,6 +171,17 @@ fuse_x3_copies = os.environ.get('LECCR_X3_FUSE', '1') != '0'      # the GEMM epi
 ln_x3_copies = os.environ.get('LECCR_X3_LN', '1') != '0'       # .. and the encoder blocks' LayerNorm passes write h1 / h2 as split copies only
 attn_x3_copies = os.environ.get('LECCR_X3_ATTN', '1') != '0'   # .. and the attention kernels write o / dqkv as the copies out_proj / in_proj read
 share_x3_copies = os.environ.get('LECCR_X3_SHARE', '1') != '0'   # .. and the Linears outside the blocks make one copy per operand for all their products
+# .. and a bias gradient whose dY exists only as the G-form copy a GEMM epilogue wrote (c_fc / intermediate.dense: two colsum passes over the copy's hi and
+# lo segments, 48 launches and 10 ms of the fp32 step) is summed INSIDE the weight-gradient launch that reads the copy anyway (leccr_gemm_params.asum_x3);
+# 2: also the bias gradients that rode in the split passes over an f32 dY (leccr_split3's colsum) - those passes become plain splits; 0: as before
+x3_asum = int(os.environ.get('LECCR_X3_ASUM', '1'))
+
+
+def _x3_asum_ok(g_rows, w):
+    """The weight-gradient product of Linear `w` from 3-segment copies of g_rows rows runs on the 4-wave TN kernel (whose column sums can skip the
+    repeated hi segment)."""
+    out_f, in_f = w._lp.shape
+    return x3_asum and fuse_bias_grad and K.NS == 3 and K.tn4_takes(out_f, in_f, 3 * g_rows)
 
 
 def _x3_lin_ok(rows, w):
@@ -217,7 +228,7 @@ def g8_of(fp8, dy2, w, g8=None, bias=None):
             return None
         if g8 is not None:
             return g8
-        fuse = bias is not None and fuse_bias_grad and K.split3_colsum_ok(dy2)
+        fuse = bias is not None and fuse_bias_grad and K.split3_colsum_ok(dy2) and not (x3_asum >= 2 and _x3_asum_ok(dy2.shape[0], w))
         g3 = K.split3(dy2, K.FORM_G, colsum=bias._g.reshape(-1) if fuse else None)
         if fuse:
             g3._bias_done = True
@@ -304,7 +315,7 @@ def lin_dx(dy2, w, fp8=False, g8=None, c8_site=None, want8=False, c8_only=False,
             # the gradient this product writes is read only through its G-form copy (dX and weight-gradient product of the consumer):
             # written by the epilogue, no f32 tensor; the consumer's bias gradient = column sums of the copy's hi and lo segments
             _, y3 = K.gemm(g8, w3t, out_dtype=torch.float32, c3_form=K.FORM_G, write_c=False, **kw)
-            if c3_bias is not None:
+            if c3_bias is not None and not _x3_asum_ok(g8.shape[0], c3_consumer):      # (else: inside the consumer's weight-gradient launch, _lin_dw)
                 n = w3t.shape[0]
                 K.colsum(y3[:, :n], c3_bias._g.reshape(-1))
                 K.colsum(y3[:, n:2 * n], c3_bias._g.reshape(-1))
@@ -558,9 +569,12 @@ def _lin_dw(dy2, x2, w, b, scale, dy_bias=None, g8=None, x8=None, bias_done=Fals
         # f32 operands as bf16 hi / lo splits: the [rows, 3 cols] copies read as [3 rows, cols], one TN launch over 3 x rows
         rows = g8.shape[0]
         K.f32_split_launches += 1
+        # (the split copy's plain column sums would count hi twice: the 4-wave TN kernel's asum_x3 form skips the repeated segment; where that
+        #  kernel does not take the shape, a colsum pass over the f32 gradient below)
+        fused = fused and _x3_asum_ok(rows, w)
+        assert fused or b is None or dy2 is not None or dy_bias is not None, 'lin_dw: the bias gradient of a copy-only dY needs the asum_x3 product'
         K.gemm(g8.view(K.NS * rows, g8.shape[1] // K.NS), x8.view(K.NS * rows, x8.shape[1] // K.NS), trans_a=True, trans_b=True, out=w._g,
-               accumulate=True, alpha=scale)
-        fused = False           # (the split copy's own column sums would count hi twice: colsum over the f32 gradient below)
+               accumulate=True, alpha=scale, asum=b._g.reshape(-1) if fused else None, asum_x3=fused)
     elif g8 is not None:
         # fp8 operands: whole 128-row K-tiles on the scaled-MFMA kernel, the (< 128-row) tail and the bias sums from the bf16 tensors
         global fp8_dw_launches
@@ -825,7 +839,8 @@ class ViTBlockFn(torch.autograd.Function):
         dh2 = lin_dx(dpre if dpre is not None else dpre8, blk.mlp.c_fc.weight, fp8=blk.fp8, g8=dpre8)
         # c_fc's bias gradient = column sums of dpre: an HBM-bound pass, issued with the dW GEMM on the weight-gradient stream
         # where it runs beside the (MFMA-bound) dX chain instead of in front of it
-        lin_dw(dpre, h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, g8=dpre8, x8=h2_8, bias_done=dpre is None)
+        lin_dw(dpre, h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, g8=dpre8, x8=h2_8,
+               bias_done=getattr(dpre8, '_bias_done', False) if _is_x3(dpre8) else dpre is None)
         dx1, _, g1_8 = _ln_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g, blk.ln_2.bias._g,
                                site=_q8_site(blk.fp8, b * N, blk.attn.out_proj.weight, '_gsite'), dres=dx2)
         g1 = _rows(dx1)
@@ -1030,7 +1045,7 @@ class BertLayerFn(torch.autograd.Function):
         if dpre is not None:
             dpre8 = g8_of(layer.fp8, dpre, inter.weight, dpre8, bias=inter.bias)
         dx1 = lin_dx(dpre if dpre is not None else dpre8, inter.weight, fp8=layer.fp8, g8=dpre8, residual=g2)          # + residual path of s2 = .. + x1
-        lin_dw(dpre, x1, inter.weight, inter.bias, g8=dpre8, x8=x1_8, bias_done=dpre is None)
+        lin_dw(dpre, x1, inter.weight, inter.bias, g8=dpre8, x8=x1_8, bias_done=getattr(dpre8, '_bias_done', False) if _is_x3(dpre8) else dpre is None)
         g1, gd1, gd1_8 = _ln_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                                  ao.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, ao.dense.weight, '_gsite'),
                                  drop=(ph, seeds[1]) if ph > 0 else None)

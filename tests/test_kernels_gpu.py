@@ -1635,6 +1635,42 @@ def test_gemm_f32_operands_run_as_bf16_splits_on_the_matrix_cores(K, M, N, K_, c
     assert float((out2 - out).abs().max()) <= 3e-5 * s
 
 
+@pytest.mark.parametrize('rows,M,N,alpha', [(4096, 512, 256, 1.0), (8256, 256, 768, 1.0), (64 * 577, 768, 256, 0.5), (147712 // 4, 3072, 768, 1.0),
+                                            (1024, 256, 256, 1.0), (1344, 320, 264, 1.0)])
+def test_gemm_weight_gradient_sums_the_bias_gradient_from_the_split_copy(K, rows, M, N, alpha):
+    """leccr_gemm_params.asum_x3 (round 5): the fp32 path's weight-gradient product reads the G-form split copy [rows, 3 M] (hi | lo | hi) of dY as
+    [3 rows, M]; its column sums must take the hi and lo segments ONCE each - the 4-wave TN kernel weights the fragment pairs of its sums by
+    k mod 3 (every split-K offset and K-tile phase occurs in these shapes), other kernels run two colsum passes over the copy's first two column
+    blocks.  Against the f64 sums of the very bf16 values in the copy (exact up to f32 accumulation), and against colsum(dY) at the split's 2^-17;
+    the product itself is what the launch without the sums writes."""
+    from leccr_amd._lib import lib
+    dy, x = _rand((rows, M), torch.float32, 41), _rand((rows, N), torch.float32, 42)
+    dy[:, 7] += 0.25                                                 # a column whose sum does not cancel
+    dy[:, 9] = torch.arange(rows, dtype=torch.float32) % 7 * 0.125 + 1e-3     # .. and one whose hi and lo segments differ in a known pattern
+    g3, x3 = K.split3(dy.to(DEV), K.FORM_G), K.split3(x.to(DEV), K.FORM_X)
+    w0, b0 = _rand((M, N), torch.float32, 43), _rand((M,), torch.float32, 44)
+    out, ob = w0.clone().to(DEV), b0.clone().to(DEV)
+    K.gemm(g3.view(3 * rows, M), x3.view(3 * rows, N), trans_a=True, trans_b=True, out=out, accumulate=True, alpha=alpha, asum=ob, asum_x3=True)
+    kernel = lib().leccr_last_gemm_kernel()
+    if alpha != 1.0 or K.tn4_takes(M, N, 3 * rows):
+        assert kernel == 5 and K.tn4_takes(M, N, 3 * rows)          # the 4-wave TN kernel (scaled sums exist only there)
+    else:
+        assert kernel != 5
+    seg = g3.cpu().double()
+    want = b0.double() + alpha * (seg[:, :M].sum(0) + seg[:, M:2 * M].sum(0))
+    scale = float((seg[:, :M].abs().sum(0) + seg[:, M:2 * M].abs().sum(0)).max())
+    err = float((ob.cpu().double() - want).abs().max())
+    assert err <= 1e-6 * scale + 1e-6, (kernel, err, scale)          # f32 accumulation of exact bf16 terms (per-fragment partial sums: no dot2 drift)
+    err = float((ob.cpu().double() - (b0.double() + alpha * dy.double().sum(0))).abs().max())
+    assert err <= 2e-5 * float(dy.double().abs().sum(0).max()) + 1e-6, (kernel, err)
+    out2 = w0.clone().to(DEV)
+    K.gemm(g3.view(3 * rows, M), x3.view(3 * rows, N), trans_a=True, trans_b=True, out=out2, accumulate=True, alpha=alpha)
+    e, s_ = _err(out, out2.cpu().double())
+    assert e <= 3e-6 * s_ + 1e-6, (e, s_)                            # same product (split-K atomics: the order of the f32 adds differs)
+    e, s_ = _err(out, w0.double() + alpha * (dy.double().t() @ x.double()))
+    assert e <= 2e-5 * s_, (e, s_)
+
+
 @pytest.mark.parametrize('Kt,M,N,alpha', [(20000, 768, 768, 1.0), (577 * 16, 2304, 768, 1.0), (64 * 300, 3072, 512, 0.5), (1000, 264, 136, 1.0)])
 def test_gemm_f32_weight_gradient_as_row_interleaved_splits(K, Kt, M, N, alpha, monkeypatch):
     """dW += alpha dY^T X with f32 operands: the [rows, 3 cols] split copies read as [3 rows, cols] (reduction over rows), the bias
