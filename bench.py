@@ -440,7 +440,7 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
     import torch
     import torch.distributed as dist
     from leccr_amd import _lib
-    from leccr_amd.evaluation import evaluation_coarse, itm_eval
+    from leccr_amd.evaluation import evaluation_coarse, itm_eval, eval_graphs_on
     from leccr_amd.models import RetrievalModel
     from leccr_amd.synthetic import MULTI30K_CFG, make_batch
     torch.manual_seed(1234)
@@ -508,7 +508,7 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
     ms, work, n = (C.c_double * NK)(), (C.c_double * NK)(), (C.c_int64 * NK)()
     barrier()
     lib.leccr_prof_enable(1)
-    one_pass()
+    evaluation_coarse(model, loader, Tok(), device, dict(ecfg, eval_graphs=False))       # (launch by launch: a replayed graph gives the event profiler nothing)
     barrier()
     lib.leccr_prof_enable(0)
     lib.leccr_prof_read_n(NK, ms, work, n)
@@ -542,7 +542,7 @@ def eval_bench(args, device, rank, world, backend, real_stdout):
                'dtype': args.dtype, 'data': 'synthetic',
                'config': {'workload': f'evaluation_coarse + itm_eval, {ni} images x {nt} texts (Multi30K-test shaped), {args.clip}@384 + {args.text}, '
                                       f'{args.dtype}, batch_size_test {bs}, batch_size_test_text {args.eval_text_batch}'
-                                      + (' (run as yielded)' if args.eval_no_regroup else ' (regrouped to >= 256 images / 1024 texts per forward inside evaluation_coarse)')
+                                      + ((' (run as yielded, whole batches as replayed HIP graphs)' if eval_graphs_on(ecfg, device) else ' (run as yielded)') if args.eval_no_regroup else ' (regrouped to >= 256 images / 1024 texts per forward inside evaluation_coarse)')
                                       + ', L_t=32, L_c=64, eval mode'
                                       + (f', encoders sharded over {world} ranks' if world > 1 else ''),
                           'parallelism': f'dp{world}', 'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},

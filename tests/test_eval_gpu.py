@@ -83,6 +83,42 @@ def test_evaluation_coarse_synthetic_loader():
     assert np.max(np.abs(asis - i2t)) <= 1e-6
 
 
+def test_evaluation_as_yielded_replays_captured_graphs_with_the_same_scores():
+    """Run as the loader yields them (eval_group_images = eval_group_texts = 0: the reference's batching), whole batches replay ONE captured forward per
+    tower (evaluation.GraphedForward: two instances on two streams) - the same launches on the same inputs, so the score matrix is bit for bit the
+    launch-by-launch one; a shorter last batch runs as it is; the graphs are kept on the model and reused by the next pass."""
+    from leccr_amd.evaluation import evaluation_coarse
+    from tests.helpers import load_npz, weights
+    from tests.test_model_gpu import MODEL_VIT, TINY_BERT, build
+    z = load_npz('model_tiny_w1.npz')
+    model = build(dict(clip_geometry=MODEL_VIT, text_config=TINY_BERT, compute_dtype='bf16'), weights(z))
+    ids_s, m_s = torch.from_numpy(z['ids_s']), torch.from_numpy(z['mask_s'])
+    ids_c, m_c = torch.from_numpy(z['ids_c']), torch.from_numpy(z['mask_c'])
+    image = torch.from_numpy(z['image'])
+
+    class Tok:
+        def __call__(self, text, **kw):
+            ids, m = (ids_s, m_s) if text[0][0] == 't' else (ids_c, m_c)
+            sel = torch.tensor([int(t[1:]) for t in text])
+            o = types.SimpleNamespace(input_ids=ids[sel], attention_mask=m[sel])
+            o.to = lambda dev: types.SimpleNamespace(input_ids=o.input_ids.to(dev), attention_mask=o.attention_mask.to(dev))
+            return o
+
+    class Loader(list):
+        dataset = types.SimpleNamespace(text=[f't{i}' for i in range(8)])
+    cuts = [0, 1, 2, 3, 4, 5, 6, 8]                                    # six batches of one image, a last batch of two
+    loader = Loader([(image[a:b], [f'c{j}' for j in range(a, b)], None) for a, b in zip(cuts[:-1], cuts[1:])])
+    cfg = {'batch_size_test_text': 2, 'max_tokens': 200, 'eval_group_images': 0, 'eval_group_texts': 0}
+    plain, _ = evaluation_coarse(model, loader, Tok(), 'cuda', dict(cfg, eval_graphs=False))
+    assert not getattr(model, '_eval_graphs', None)
+    got, got_t = evaluation_coarse(model, loader, Tok(), 'cuda', cfg)
+    graphs = model._eval_graphs
+    assert sorted(k[0] for k in graphs) == ['image', 'text'] and sorted(g.calls for g in graphs.values()) == [4, 6]
+    assert np.array_equal(got, plain) and np.array_equal(got_t, got.T)
+    again, _ = evaluation_coarse(model, loader, Tok(), 'cuda', cfg)          # the kept graphs, replayed
+    assert model._eval_graphs is graphs and sorted(g.calls for g in graphs.values()) == [8, 12] and np.array_equal(again, plain)
+
+
 def test_evaluation_coarse_video_double_sim():
     """evaluation_coarse_video (video_Retrieval_caption_double_sim.py:94-190) == the same formula on the oracle's features."""
     from leccr_amd.evaluation import evaluation_coarse_video
