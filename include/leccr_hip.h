@@ -229,6 +229,10 @@ int leccr_layernorm_fwd_ex(const void* x, const void* add, const float* gamma, c
  * next product; y itself may be NULL when nothing else reads it.  f32 rows only. */
 int leccr_layernorm_fwd_s3(const void* x, const void* add, const float* gamma, const float* beta, void* y, void* sum_out, float* mean,
                            float* rstd, int64_t rows, int64_t d, float eps, float p, uint64_t seed, void* y3, int form, void* stream);
+/* leccr_layernorm_bwd_ex with g8_fmt 2 / 3 and g8_site = NULL (round 5, f32 rows only): g8 is the bf16 (hi, lo) split copy [rows, 3 d] of the gradient
+ * the dense layer in front of the residual add sees (dx_drop if given, else dx) in leccr_split3's form g8_fmt - 2 (0: hi|hi|lo, 1: hi|lo|hi) - the
+ * operand copy of that Linear's dX and weight-gradient products on the fp32 path, without leccr_split3's pass over the tensor just written
+ * (the bias gradient then rides in the weight-gradient launch: leccr_gemm_params.asum_x3). */
 int leccr_layernorm_bwd_ex(const void* dy, const void* x_in, const float* gamma, const float* mean, const float* rstd,
                            const void* dres, void* dx, float* dgamma, float* dbeta, void* dx_drop, float p, uint64_t seed,
                            void* g8, float* g8_site, int g8_fmt, int64_t rows, int64_t d, int dtype, void* stream);

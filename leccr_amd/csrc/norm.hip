@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256, NCH <= 3 ? ((CS || EX) ? 4 : 5) : (NCH == 4 ? 
         if constexpr (CS) dc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     [[maybe_unused]] float q8sc = 1.f, q8m = 0.f;      // fp8 copy of the gradient the dense layer sees (dx_drop if given, else dx)
-    if constexpr (EX) q8sc = q8.out ? q8.site[1] : 1.f;
+    if constexpr (EX) q8sc = (q8.out && q8.fmt < 2) ? q8.site[1] : 1.f;
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[NCH], gy[NCH];
@@ -196,7 +196,18 @@ __global__ __launch_bounds__(256, NCH <= 3 ? ((CS || EX) ? 4 : 5) : (NCH == 4 ? 
                         for (int j = 0; j < 4; ++j) od[j] = to_f32(from_f32<T>(o[j])) * drop_mul(drop, (uint32_t)(row * d + c + j));
                         store4(dx_drop + row * d + c, od);
                     }
-                    if (q8.out) {
+                    if (q8.out && q8.fmt >= 2) {       // the fp32 path's split copy of that gradient (f32 rows; fmt 2: hi | hi | lo, 3: hi | lo | hi)
+                        bf16x4 h4, l4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            h4[j] = (bf16_t)od[j];
+                            l4[j] = (bf16_t)(od[j] - (float)h4[j]);
+                        }
+                        bf16_t* d3 = reinterpret_cast<bf16_t*>(q8.out) + row * 3 * d + c;
+                        *reinterpret_cast<bf16x4*>(d3) = h4;
+                        *reinterpret_cast<bf16x4*>(d3 + d) = q8.fmt == 2 ? h4 : l4;
+                        *reinterpret_cast<bf16x4*>(d3 + 2 * d) = q8.fmt == 2 ? l4 : h4;
+                    } else if (q8.out) {
                         float r[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(256, NCH <= 3 ? ((CS || EX) ? 4 : 5) : (NCH == 4 ? 
         }
     }
     if constexpr (EX) {
-        if (q8.out) q8_amax(q8, q8m);
+        if (q8.out && q8.fmt < 2) q8_amax(q8, q8m);
     }
     // reduce the 4 waves' partials through LDS (one wave at a time), then one f32 atomic per column
     for (int pass = 0; pass < (CS ? 3 : 2); ++pass) {
@@ -766,7 +777,10 @@ static int ln_bwd_entry(const void* dy, const void* x_in, const float* gamma, co
                         const void* dres, void* dx, float* dgamma, float* dbeta, float* colsum, int colsum_of, void* dx_drop,
                         float p, uint64_t seed, void* g8, float* g8_site, int g8_fmt, int64_t rows, int64_t d, int dtype,
                         void* stream) {
-    if (int rc = q8_check("layernorm_bwd", g8, g8_site, g8_fmt, d)) return rc;
+    if (g8 && g8_fmt >= 2) {       // the bf16 split copy of the fp32 path (leccr_layernorm_bwd_ex, fmt 2 / 3): f32 rows, 8-byte aligned copy, no site
+        LECCR_REQUIRE((g8_fmt == 2 || g8_fmt == 3) && dtype == LECCR_F32 && ((uintptr_t)g8 & 7) == 0, LECCR_EINVAL,
+                      "layernorm_bwd_ex: the split copy needs fmt 2 (hi|hi|lo) / 3 (hi|lo|hi), f32 rows and an 8-byte aligned buffer");
+    } else if (int rc = q8_check("layernorm_bwd", g8, g8_site, g8_fmt, d)) return rc;
     const Q8Out q8{(uint8_t*)g8, g8_site, g8_fmt};
     LECCR_REQUIRE(dy && x_in && gamma && mean && rstd && dx && dgamma && dbeta, LECCR_EINVAL, "layernorm_bwd: null pointer");
     LECCR_REQUIRE(colsum_of == 0 || (colsum && (colsum_of == 2 || (colsum_of == 1 && dres))), LECCR_EINVAL,
@@ -778,7 +792,7 @@ static int ln_bwd_entry(const void* dy, const void* x_in, const float* gamma, co
     hipStream_t st = as_stream(stream);
     const DropCfg drop = make_drop(dx_drop ? p : 0.f, seed);
     const double esz = dtype == LECCR_BF16 ? 2.0 : 4.0;
-    ProfScope prof(PROF_LN_BWD, (double)rows * d * (esz * (3 + (dres ? 1 : 0) + (dx_drop ? 1 : 0)) + (g8 ? 1.0 : 0.0)) + 8.0 * rows, st);
+    ProfScope prof(PROF_LN_BWD, (double)rows * d * (esz * (3 + (dres ? 1 : 0) + (dx_drop ? 1 : 0)) + (g8 ? (g8_fmt >= 2 ? 6.0 : 1.0) : 0.0)) + 8.0 * rows, st);
     DISPATCH_T(dtype, ln_bwd_dispatch<float>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, q8, st),
                ln_bwd_dispatch<bf16_t>(dy, x_in, gamma, mean, rstd, dres, dx, dgamma, dbeta, colsum, colsum_of, rows, d, dx_drop, drop, q8, st));
 }

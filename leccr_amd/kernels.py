@@ -248,16 +248,27 @@ def layernorm_fwd(x, gamma, beta, eps, add=None, want_sum=False, drop=None, q8_s
     return y.view(x.shape), mean, rstd, (s.view(x.shape) if s is not None else None)
 
 
-def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None, colsum=None, colsum_of=0, drop=None, q8_site=None):
+def layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, dres=None, colsum=None, colsum_of=0, drop=None, q8_site=None, s3_form=None):
     """colsum_of: 1 = colsum += column sums of dres, 2 = of the returned dx (fused bias gradient, see leccr_hip.h).
     drop = (p, seed): returns (dx, dropout(dx; p, seed)) from one pass.
     q8_site (an Fp8Site): returns (dx, dropout(dx) or None, g8): g8 = the fp8 copy of dropout(dx) (of dx without drop) under that
-    site, None until the site is primed."""
+    site, None until the site is primed.
+    s3_form (f32 rows, 3-segment copies): returns (dx, dropout(dx) or None, g3): g3 [rows, 3 d] = the bf16 (hi, lo) split copy of dropout(dx) (of dx
+    without drop) in that form, written by the pass itself."""
     dy2, rows, d, ld = _rows2d(dy)
     assert ld == d and x_in.is_contiguous()
     dx = torch.empty_like(dy2)
     if dres is not None:
         assert dres.is_contiguous() and dres.dtype == dy.dtype
+    if s3_form is not None:
+        assert q8_site is None and not colsum_of and dy.dtype == torch.float32 and NS == 3 and s3_form in (FORM_X, FORM_G) and d % 4 == 0
+        g3 = torch.empty(rows, 3 * d, device=dy.device, dtype=torch.bfloat16)
+        dxd = torch.empty_like(dy2) if drop is not None else None
+        p_, seed_ = (float(drop[0]), int(drop[1])) if drop is not None else (0.0, 0)
+        check(lib().leccr_layernorm_bwd_ex(ptr(dy2), ptr(x_in), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                                           ptr(dgamma), ptr(dbeta), ptr(dxd), p_, seed_, ptr(g3), None, 2 + s3_form, rows, d,
+                                           dtype_code(dy), stream()), 'leccr_layernorm_bwd_ex')
+        return dx.view(dy.shape), (dxd.view(dy.shape) if dxd is not None else None), g3
     if q8_site is not None:
         assert not colsum_of
         g8, site_row, fmt = _q8_out(q8_site, rows, d, dy.device)

@@ -266,8 +266,11 @@ class XVLMBase(nn.Module):
             # reference precision (xvlm.py:88: fp32 throughout) on the matrix cores: the encoder blocks hand bf16 hi / lo split copies
             # of their f32 activations / gradients from product to product (ops.X3; kernels.f32_mfma = False at run time: scalar kernels)
             if self.clip_encoder is not None:
-                for blk in self.clip_encoder.visual.transformer.resblocks:
+                blocks = list(self.clip_encoder.visual.transformer.resblocks)
+                for blk in blocks:
                     blk.fp8 = ops.X3
+                for prev, blk in zip(blocks[:-1], blocks[1:]):          # block i's backward output is block i-1's c_proj dY: its LayerNorm-1 backward
+                    blk._dx_consumer = (prev.mlp.c_proj.weight,)        # writes that product's G-form copy (ops._ln_bwd x3_for, ops._g8_give)
             for layer in self.text_encoder.encoder.layer:
                 layer.fp8 = ops.X3
             # the weights' split copies once per optimizer step, all in one launch (round 5; they used to be split at every use: ~230

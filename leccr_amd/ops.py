@@ -113,9 +113,16 @@ def _ln_fwd(x, gamma, beta, eps, site=None, x3_for=None, x3_only=False, q8_only=
     return K.layernorm_fwd(x, gamma, beta, eps, q8_site=site, write_y=not (q8_only and ln_q8_only and site.primed and x.shape[-1] % 8 == 0), **kw)
 
 
-def _ln_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, site=None, drop=None, **kw):
+def _ln_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, site=None, drop=None, x3_for=None, **kw):
     """K.layernorm_bwd -> (dx, g, g8): g = dropout(dx) with drop = (p, seed), else dx - the gradient the dense layer in front of the
-    residual add sees; g8 = its fp8 copy under `site` (fp8 mode, once the site has a scale), else None."""
+    residual add sees; g8 = its fp8 copy under `site` (fp8 mode, once the site has a scale), else None.
+    x3_for (mode X3: the Linear whose incoming gradient g is): the pass writes g's G-form split copy as g8 - the operand of that Linear's dX and
+    weight-gradient products, no leccr_split3 pass over g (24 ViT + 24 BERT launches of the fp32 step); the Linear's bias gradient then rides in the
+    weight-gradient launch (asum_x3), which is why this needs _x3_asum_ok."""
+    if (site is None and x3_for is not None and ln_x3_bwd_copies and dy.dtype == torch.float32 and K.f32_mfma and K.NS == 3
+            and _x3_lin_ok(dy.numel() // dy.shape[-1], x3_for) and _x3_asum_ok(dy.numel() // dy.shape[-1], x3_for)):
+        dx, dxd, g3 = K.layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, drop=drop, s3_form=K.FORM_G, **kw)
+        return dx, (dxd if dxd is not None else dx), g3
     if site is None:
         r = K.layernorm_bwd(dy, x_in, gamma, mean, rstd, dgamma, dbeta, drop=drop, **kw)
         return (r[0], r[1], None) if drop is not None else (r, r, None)
@@ -175,6 +182,7 @@ share_x3_copies = os.environ.get('LECCR_X3_SHARE', '1') != '0'   # .. and the Li
 # lo segments, 48 launches and 10 ms of the fp32 step) is summed INSIDE the weight-gradient launch that reads the copy anyway (leccr_gemm_params.asum_x3);
 # 2: also the bias gradients that rode in the split passes over an f32 dY (leccr_split3's colsum) - those passes become plain splits; 0: as before
 x3_asum = int(os.environ.get('LECCR_X3_ASUM', '1'))
+ln_x3_bwd_copies = os.environ.get('LECCR_X3_LN_BWD', '1') != '0'   # .. and the LayerNorm BACKWARD passes write the G-form copy of the gradient the next dX / dW products read
 
 
 def _x3_asum_ok(g_rows, w):
@@ -842,7 +850,8 @@ class ViTBlockFn(torch.autograd.Function):
         lin_dw(dpre, h2, blk.mlp.c_fc.weight, blk.mlp.c_fc.bias, g8=dpre8, x8=h2_8,
                bias_done=getattr(dpre8, '_bias_done', False) if _is_x3(dpre8) else dpre is None)
         dx1, _, g1_8 = _ln_bwd(dh2.view(b, N, d), x1, blk.ln_2.weight.data, mean2, rstd2, blk.ln_2.weight._g, blk.ln_2.bias._g,
-                               site=_q8_site(blk.fp8, b * N, blk.attn.out_proj.weight, '_gsite'), dres=dx2)
+                               site=_q8_site(blk.fp8, b * N, blk.attn.out_proj.weight, '_gsite'), dres=dx2,
+                               x3_for=blk.attn.out_proj.weight if blk.fp8 == X3 else None)
         g1 = _rows(dx1)
         g1_8 = g8_of(blk.fp8, g1, blk.attn.out_proj.weight, g1_8, bias=blk.attn.out_proj.bias)
         do = lin_dx(g1, blk.attn.out_proj.weight, fp8=blk.fp8, g8=g1_8).view(b, N, d)
@@ -886,7 +895,8 @@ class ViTBlockFn(torch.autograd.Function):
         # (fp8: dx is the gradient the previous block's c_proj dX product consumes: its e5m2 copy goes with it)
         prev = getattr(blk, '_dx_consumer', (None,))[0]
         dx, _, dx_8 = _ln_bwd(dh1.view(b, N, d), x, blk.ln_1.weight.data, mean1, rstd1, blk.ln_1.weight._g, blk.ln_1.bias._g,
-                              site=_q8_site(blk.fp8 and prev is not None, b * N, prev, '_gsite'), dres=dx1)
+                              site=_q8_site(blk.fp8 and prev is not None, b * N, prev, '_gsite'), dres=dx1,
+                              x3_for=prev if blk.fp8 == X3 else None)
         if blk.fp8:
             _g8_give(_rows(dx), dx_8)
         for p in (blk.ln_1.weight, blk.ln_1.bias, blk.ln_2.weight, blk.ln_2.bias):
@@ -1033,7 +1043,7 @@ class BertLayerFn(torch.autograd.Function):
         # written by the LayerNorm backward pass (fp8: with gd2's e5m2 copy)
         g2, gd2, gd2_8 = _ln_bwd(dx2.contiguous(), s2, out.LayerNorm.weight.data, mean2, rstd2, out.LayerNorm.weight._g,
                                  out.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, out.dense.weight, '_gsite'),
-                                 drop=(ph, seeds[2]) if ph > 0 else None)
+                                 drop=(ph, seeds[2]) if ph > 0 else None, x3_for=out.dense.weight if layer.fp8 == X3 else None)
         g2, gd2 = _rows(g2), _rows(gd2)
         gd2_8 = g8_of(layer.fp8, gd2, out.dense.weight, gd2_8, bias=out.dense.bias)
         inter = layer.intermediate.dense
@@ -1048,7 +1058,7 @@ class BertLayerFn(torch.autograd.Function):
         lin_dw(dpre, x1, inter.weight, inter.bias, g8=dpre8, x8=x1_8, bias_done=getattr(dpre8, '_bias_done', False) if _is_x3(dpre8) else dpre is None)
         g1, gd1, gd1_8 = _ln_bwd(dx1.view(b, L, d), s1, ao.LayerNorm.weight.data, mean1, rstd1, ao.LayerNorm.weight._g,
                                  ao.LayerNorm.bias._g, site=_q8_site(layer.fp8, b * L, ao.dense.weight, '_gsite'),
-                                 drop=(ph, seeds[1]) if ph > 0 else None)
+                                 drop=(ph, seeds[1]) if ph > 0 else None, x3_for=ao.dense.weight if layer.fp8 == X3 else None)
         g1, gd1 = _rows(g1), _rows(gd1)
         gd1_8 = g8_of(layer.fp8, gd1, ao.dense.weight, gd1_8, bias=ao.dense.bias)
         do = lin_dx(gd1, ao.dense.weight, fp8=layer.fp8, g8=gd1_8).view(b, L, d)

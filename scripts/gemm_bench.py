@@ -10,6 +10,11 @@ SH = [('qkv', 0, M, 2304, 768), ('out', 0, M, 768, 768), ('fc1', 0, M, 3072, 768
       ('dW qkv', 1, 2304, 768, M), ('dW out', 1, 768, 768, M), ('dW fc1', 1, 3072, 768, M), ('dW fc2', 1, 768, 3072, M),
       ('bert out', 0, 16384, 768, 768), ('bert qkv', 0, 16384, 2304, 768), ('bert fc1', 0, 16384, 3072, 768), ('bert fc2', 0, 16384, 768, 3072),
       ('bert dW fc1', 1, 3072, 768, 16384), ('bert dW out', 1, 768, 768, 16384), ('cap qkv', 0, 16384, 1536, 768), ('sq 4096', 0, 4096, 4096, 4096), ('sq 8192', 0, 8192, 8192, 8192)]
+if os.environ.get('SMALL_M'):       # evaluation as yielded: 6 images x 577 tokens (ViT) and 6 x 64 caption / 32 x 32 text tokens (BERT) per forward
+    m6 = int(os.environ['SMALL_M'])
+    SH = [('qkv', 0, m6, 2304, 768), ('out', 0, m6, 768, 768), ('fc1', 0, m6, 3072, 768), ('fc2', 0, m6, 768, 3072),
+          ('bert qkv', 0, 1024, 2304, 768), ('bert out', 0, 1024, 768, 768), ('bert fc1', 0, 1024, 3072, 768), ('bert fc2', 0, 1024, 768, 3072),
+          ('cap qkv', 0, 384, 2304, 768), ('cap fc1', 0, 384, 3072, 768)]
 reps = int(os.environ.get('REPS', 5))
 from leccr_amd import _lib
 if os.environ.get('LECCR_LIB'): _lib.LIB_PATH = os.environ['LECCR_LIB']

@@ -1196,6 +1196,35 @@ def test_layernorm_passes_write_the_fp8_copy_their_consumer_needs(K, rows, d):
         assert float(sg.row[0]) == float(sg2.row[0]) > 0
 
 
+@pytest.mark.parametrize('drop', [None, (0.1, 77)])
+@pytest.mark.parametrize('rows,d,form', [(577 * 3, 768, 1), (1000, 1024, 1), (130, 264, 0), (64, 2048, 1)])
+def test_layernorm_backward_writes_the_split_copy_of_the_gradient_it_returns(K, rows, d, form, drop):
+    """leccr_layernorm_bwd_ex with g8_fmt 2 / 3 (round 5, f32 rows): the pass also writes the bf16 (hi, lo) split copy of the gradient the dense layer
+    sees - dropout(dx) with drop, else dx - bit for bit what leccr_split3 makes of the tensor it returned; dx / dgamma / dbeta as the plain pass's."""
+    x = _rand((rows, d), torch.float32, 70, 2.0).to(DEV)
+    g, b = (1 + 0.1 * _rand((d,), torch.float32, 71)).to(DEV), _rand((d,), torch.float32, 72).to(DEV)
+    mean, rstd = K.layernorm_fwd(x, g, b, 1e-5)[1:3]
+    dy, dres = _rand((rows, d), torch.float32, 73).to(DEV), _rand((rows, d), torch.float32, 74).to(DEV)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    dx, dxd, g3 = K.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dres=dres, drop=drop, s3_form=form)
+    assert (dxd is None) == (drop is None) and g3.shape == (rows, 3 * d) and g3.dtype == torch.bfloat16
+    if drop is not None:
+        assert torch.equal(dxd, K.dropout(dx, drop[0], drop[1]))
+    assert torch.equal(g3, K.split3(dxd if drop is not None else dx, form))
+    dg0, db0 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    dx0 = K.layernorm_bwd(dy, x, g, mean, rstd, dg0, db0, dres=dres)
+    e, s_ = _err(dx, dx0.cpu().double())
+    assert e <= 2e-6 * s_, (e, s_)                    # (another instantiation of the kernel: its f32 arithmetic may contract differently)
+    for a, b_ in ((dg, dg0), (db, db0)):
+        e, s_ = _err(a, b_.cpu().double())
+        assert e <= 1e-5 * s_ + 1e-6, (e, s_)
+    with pytest.raises(RuntimeError):                # f32 rows only
+        from leccr_amd._lib import lib, check, ptr, stream
+        xb, dyb = x.bfloat16(), dy.bfloat16()
+        check(lib().leccr_layernorm_bwd_ex(ptr(dyb), ptr(xb), ptr(g), ptr(mean), ptr(rstd), None, ptr(torch.empty_like(dyb)), ptr(dg), ptr(db), None, 0.0, 0,
+                                           ptr(g3), None, 2 + form, rows, d, K.BF16, stream()), 'leccr_layernorm_bwd_ex')
+
+
 @pytest.mark.parametrize('variant', ['plain', 'drop', 'q8', 'drop+q8'])
 @pytest.mark.parametrize('d', [256, 512, 768, 1024, 264])
 def test_layernorm_backward_pipelined_over_rows_equals_the_plain_kernel(K, d, variant):
