@@ -138,7 +138,12 @@ def _graph_for(model, kind, fn, example):
     cache = model.__dict__.setdefault('_eval_graphs', {})
     key = (kind, next(model.parameters()).data_ptr()) + tuple((tuple(t.shape), t.dtype) for t in example)
     if key not in cache:
-        cache[key] = GraphedForward(fn, example)
+        try:
+            cache[key] = GraphedForward(fn, example)
+        except RuntimeError as e:          # a forward that cannot be captured (a host read inside it, ...): say so once and run launch by launch
+            print('evaluation: HIP graph capture of the %s forward failed (%s); running it launch by launch' % (kind, str(e).splitlines()[0][:200]))
+            torch.cuda.synchronize()
+            cache[key] = None
     return cache[key]
 
 
@@ -202,9 +207,9 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
                        return_tensors='pt').to(device)
         if graphs and gt == 0 and len(text) == text_bs and num_text >= 4 * text_bs:      # as yielded: whole batches replay one captured forward
             text_graph = _graph_for(model, 'text', text_fwd, (ti.input_ids, ti.attention_mask))
-            if text_graph not in graphed:
+            if text_graph is not None and text_graph not in graphed:
                 graphed.append(text_graph)
-            text_embeds.append(text_graph(ti.input_ids, ti.attention_mask))
+            text_embeds.append((text_graph or text_fwd)(ti.input_ids, ti.attention_mask))
         else:
             text_embeds.append(text_fwd(ti.input_ids, ti.attention_mask))
         text_rows.append(torch.arange(i, i + len(text), device=device))
@@ -234,10 +239,11 @@ def evaluation_coarse(model, data_loader, tokenizer, device, config, shard=True)
                            return_tensors='pt').to(device)
             if graphs and gi == 0 and n_batches >= 4:       # as yielded (batch_size_test images): whole batches replay one captured forward
                 if image_graph[0] is None:                                   # the first batch sets the shape; a shorter last batch runs as it is
-                    image_graph[0] = _graph_for(model, 'image', image_fwd, (image, ci.input_ids, ci.attention_mask))
-                    graphed.append(image_graph[0])
+                    image_graph[0] = _graph_for(model, 'image', image_fwd, (image, ci.input_ids, ci.attention_mask)) or False
+                    if image_graph[0]:
+                        graphed.append(image_graph[0])
                 g = image_graph[0]
-                if all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(g.inst[0][2], (image, ci.input_ids, ci.attention_mask))):
+                if g and all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(g.inst[0][2], (image, ci.input_ids, ci.attention_mask))):
                     image_embeds.append(g(image, ci.input_ids, ci.attention_mask))
                     image_rows.append(torch.arange(first, first + image.shape[0], device=device))
                     return
