@@ -100,7 +100,7 @@ class GraphedForward:
                 fn(*ins)                                  # once outside the capture: lazy initialisation (function attributes, allocator pools)
             st.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=st):
+            with torch.cuda.graph(g, stream=st, capture_error_mode='thread_local'):      # (a loader's pin-memory thread may allocate meanwhile)
                 out = fn(*ins)
             self.inst.append((st, g, ins, out))
 
